@@ -1,0 +1,195 @@
+/*
+ * vc_hip.h -- C ABI of libvc_hip.so, the MI355X (gfx950) implementation of the per-B-frame codec
+ * hot path  flow -> warp -> residual analysis -> hyperprior -> arithmetic code -> synthesis.
+ *
+ * The reference (KUIS-AI-Tekalp-Research-Group/video-compression) is pure Python on PyTorch +
+ * CompressAI: it has NO FFI of its own.  Each entry point below therefore replaces a PyTorch /
+ * CompressAI operator *call site* of the reference, cited as file:line under /root/reference.
+ * The Python host layer (video-compression_amd/vcamd) binds these with ctypes and mirrors the
+ * reference's module surface (m.Model, b_model.BidirFlowRef, encode_B, decode_B).
+ *
+ * Conventions
+ *   - every device entry point takes a hipStream_t (passed as void*), enqueues asynchronously and
+ *     returns 0 on success or a negative VC_E* code; no exceptions, no allocation, no sync inside
+ *     (graph-capturable); all buffers are caller-owned device memory;
+ *   - activations are fp32, channels-last ("NHWC"): a vc_view addresses element (n,y,x,c) at
+ *     p[n*sn + y*sh + x*sw + c] (strides in floats), which lets callers express channel slices of a
+ *     concat buffer and spatial crops without copies;
+ *   - host entry points (vc_pmf_to_quantized_cdf, vc_rans_*, vc_conv_pack_*) touch host memory only.
+ */
+#ifndef VC_HIP_H
+#define VC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_OK 0
+#define VC_EINVAL (-1)   /* bad argument / unsupported shape */
+#define VC_ELAUNCH (-2)  /* HIP launch failure */
+#define VC_ENOMEM (-3)
+#define VC_EDATA (-4)    /* corrupt bitstream / degenerate pmf */
+
+typedef void *vc_stream; /* hipStream_t */
+
+typedef struct {
+    float *p;
+    int n, h, w, c;
+    long long sn, sh, sw; /* strides in floats; channel stride is 1 */
+} vc_view;
+
+/* ------------------------------------------------------------------------------------------
+ * Library info
+ * ---------------------------------------------------------------------------------------- */
+const char *vc_version(void);
+/* Name of the code-object target compiled in ("gfx950"). */
+const char *vc_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution engine (im2col-free implicit GEMM on fp32 MFMA, LDS-staged NHWC input tiles).
+ * Replaces: torch.nn.Conv2d call sites  LHBDC/model/flow.py:52-62 (7x7), layers.py:202-209 (5x5/3x3),
+ *           compressai conv3x3/conv1x1/subpel_conv3x3 inside layers.py:48-91,123-166 and
+ *           Flex.../b_model/unet.py:27-31,62-74, layers.py:79-123;
+ *           compressai GDN (1x1 contraction on x^2) -- SURVEY.md A.2.
+ * ---------------------------------------------------------------------------------------- */
+enum { VC_ACT_NONE = 0, VC_ACT_RELU = 1, VC_ACT_LRELU = 2, VC_ACT_SIGMOID = 3 };
+enum { VC_EPI_NONE = 0, VC_EPI_GDN = 1, VC_EPI_IGDN = 2 };   /* out = mul * rsqrt(acc) / mul * sqrt(acc) */
+enum { VC_IN_NONE = 0, VC_IN_SQUARE = 1 };                   /* transform applied to the staged input */
+enum { VC_OUT_PLAIN = 0, VC_OUT_PIXELSHUFFLE2 = 1 };         /* nn.PixelShuffle(2) fused into the store */
+
+/* Tile configurations (output-channel block / MFMA shape).  Chosen by vc_conv_select_cfg. */
+enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3 };
+
+typedef struct {
+    vc_view in;            /* [n,h,w,cin] */
+    vc_view out;           /* [n,ho,wo,cout]  (PIXELSHUFFLE2: [n,2ho,2wo,cout/4]) */
+    const float *wpk;      /* packed weights from vc_conv_pack_weights (device) */
+    const float *bias;     /* packed bias, vc_conv_packed_bias_floats() entries (device) */
+    const float *res;      /* optional residual added after the activation, laid out like `out` */
+    long long res_sn, res_sh, res_sw;
+    const float *mul;      /* GDN/IGDN: the un-squared input, laid out like `out` */
+    long long mul_sn, mul_sh, mul_sw;
+    const float *chscale;  /* optional per-output-channel gain applied before the residual add */
+    int kh, kw, stride;    /* square "same" padding kh/2, kw/2 */
+    int act; float slope;
+    int epi, in_xform, out_mode;
+    int cfg;
+} vc_conv_desc;
+
+int vc_conv_select_cfg(int cout, int cin, int k, int stride);
+/* channel chunk (K-granule) of a (cfg,k,stride) instance; weights are zero-padded to a multiple of it */
+int vc_conv_chunk(int cfg, int k, int stride, int cin);
+size_t vc_conv_packed_weight_floats(int cfg, int cout, int cin, int kh, int kw, int stride);
+size_t vc_conv_packed_bias_floats(int cfg, int cout);
+/* Host: OIHW fp32 -> fragment-ordered packed weights/bias.  `pixelshuffle` applies the
+ * (c*4+dy*2+dx) -> ((dy*2+dx)*cout/4 + c) output-channel permutation the fused store expects. */
+int vc_conv_pack_weights(const float *w_oihw, const float *bias, int cout, int cin, int kh, int kw,
+                         int stride, int cfg, int pixelshuffle, float *wpk_out, float *bias_out);
+int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout conversion at the module boundary (reference tensors are NCHW: m.py:32, b_model.py:49)
+ * ---------------------------------------------------------------------------------------- */
+int vc_nchw_to_nhwc(vc_stream s, const float *src_nchw, vc_view dst);
+int vc_nhwc_to_nchw(vc_stream s, vc_view src, float *dst_nchw);
+
+/* ------------------------------------------------------------------------------------------
+ * Resampling / pooling / padding
+ * ---------------------------------------------------------------------------------------- */
+/* F.avg_pool2d(x*scale, k) followed by ReflectionPad2d bottom/right to out.h x out.w
+ * (flow.py:86-87 with k=2; m.py:38-50 with k=4, scale .5 or 1, pad to x64). */
+int vc_avgpool_reflectpad(vc_stream s, vc_view in, vc_view out, int k, float scale);
+/* nn.MaxPool2d(2,2) (layers.py:200) */
+int vc_maxpool2(vc_stream s, vc_view in, vc_view out);
+/* F.interpolate / nn.Upsample bilinear by an integer factor (layers.py:232,238,244; m.py:30;
+ * unet.py:63), out = scale * bilinear(in); out.h/out.w = factor * in.h/in.w. */
+int vc_upsample_bilinear(vc_stream s, vc_view in, vc_view out, int factor, int align_corners, float scale);
+/* out = alpha*a + beta*b (b may be NULL-pointer view with p==0) -- m.py:52,56-59,71 */
+int vc_axpby(vc_stream s, vc_view a, vc_view b, vc_view out, float alpha, float beta);
+/* out[...,c] = gain[c] * a[...,c] -- Flex Gain_Module.forward (Flex.../b_model/layers.py:54-73) */
+int vc_channel_scale(vc_stream s, vc_view a, const float *gain, vc_view out);
+
+/* ------------------------------------------------------------------------------------------
+ * Warping (torch grid_sample call sites)
+ *   VC_WARP_W1: LHBDC flow.py:15-25, m.py:111-126 -- sample at (x+u*W/(W-1), y+v*H/(H-1)), border clamp
+ *   VC_WARP_W2: Flex b_model.py:99-112           -- sample at (x+u-.5, y+v-.5), zeros outside
+ * ---------------------------------------------------------------------------------------- */
+enum { VC_WARP_W1 = 1, VC_WARP_W2 = 2 };
+int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, vc_view out);
+
+/* SPyNet pre-processing (flow.py:39-45): NCHW frame -> normalised, channel-flipped NHWC level-0 image */
+int vc_spynet_preprocess(vc_stream s, const float *src_nchw, vc_view dst);
+/* One pyramid level's network input (flow.py:93-98): up = 2*bilinear_x2(flow_coarse, align_corners=True)
+ * (replicate-padded when the level is odd-sized; zeros when flow_coarse.p==NULL), feat = [first,
+ * warp_W1(second, up), up] (8 ch), and `up` alone (2 ch) for the residual add after the last conv. */
+int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second, vc_view flow_coarse,
+                          vc_view feat8, vc_view up2);
+
+/* LHBDC mask blend + residual (m.py:63-67): pred = m*fw + (1-m)*bw ; resid = cur - pred.
+ * fwbw holds fw in channels 0..2 and bw in 3..5; mask has 1 channel. resid.p may be NULL. */
+int vc_lhbdc_blend(vc_stream s, vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid);
+/* Flex blend (b_model.py:68-73): mask has 2 channels (already through sigmoid),
+ * pred = (.5m0*xb + .5m1*xa)/(.5m0+.5m1+1e-8) ; resid = cur - pred. */
+int vc_flex_blend(vc_stream s, vc_view xb, vc_view xa, vc_view mask, vc_view cur, vc_view pred, vc_view resid);
+/* Flex linear-motion split (b_model.py:38-40): flow4=[F01,F10] -> ft0, ft1 (2 ch each) */
+int vc_flex_motion_split(vc_stream s, vc_view flow4, vc_view ft0, vc_view ft1, float t);
+
+/* ------------------------------------------------------------------------------------------
+ * Entropy models (CompressAI EntropyBottleneck / GaussianConditional)
+ * ---------------------------------------------------------------------------------------- */
+/* Factorised prior parameters for C channels, pre-resolved on the host at load time:
+ *   per channel 60 floats: softplus(M0)[3], b0[3], tanh(f0)[3], softplus(M1)[9], b1[3], tanh(f1)[3],
+ *   softplus(M2)[9], b2[3], tanh(f2)[3], softplus(M3)[9], b3[3], tanh(f3)[3], softplus(M4)[3], b4[1],
+ *   median[1], pad[1]  (matrices row-major [out][in]) */
+#define VC_EB_PARAMS_PER_CHANNEL 60
+/* EntropyBottleneck.forward (eval): z_hat = round(z*gain - med) + med, likelihood through the
+ * logistic-CDF MLP, lower-bounded 1e-9; bits += sum(-log2 p) into bits_partial (see vc_bits_reduce).
+ * `in_gain` (nullable, per channel) is Flex's hyper_gain_unit, `out_gain` (nullable) its
+ * hyper_inv_gain_unit applied to the stored z_hat (layers.py:139-141).
+ * symbols (nullable, int32 NCHW order n,c,y,x) receives round(z*gain - med) for the range coder. */
+int vc_eb_forward(vc_stream s, vc_view z, const float *params, const float *in_gain, const float *out_gain,
+                  vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots);
+/* inverse for the decoder: z_hat = (sym + med) * out_gain */
+int vc_eb_dequant(vc_stream s, const int32_t *symbols, const float *params, const float *out_gain, vc_view z_hat);
+
+/* GaussianConditional.forward (eval) on y with (scales, means) = chunk(h_s output, 2):
+ *   y_hat = (round(y*gain - mu) + mu) * out_gain ; p = Phi((.5-|v|)/s) - Phi((-.5-|v|)/s), s>=0.11, p>=1e-9.
+ * sym_src (nullable) lets Flex's compress() quantise the UN-gained y (layers.py:167): symbols are
+ * round(sym_src - mu) when given, else round(y*gain - mu).  indexes = build_indexes(scales) against
+ * scale_table[n_scales] (nullable together with symbols). */
+int vc_gc_forward(vc_stream s, vc_view y, vc_view scales, vc_view means, const float *in_gain,
+                  const float *out_gain, vc_view y_hat, double *bits_partial, int bits_slots,
+                  const float *sym_src_p, int32_t *symbols, int32_t *indexes, const float *scale_table,
+                  int n_scales);
+/* decoder side: indexes from scales; y_hat = (sym + mu) * out_gain */
+int vc_gc_indexes(vc_stream s, vc_view scales, const float *scale_table, int n_scales, int32_t *indexes);
+int vc_gc_dequant(vc_stream s, const int32_t *symbols, vc_view means, const float *out_gain, vc_view y_hat);
+/* Deterministic two-stage reduction of the per-workgroup partial sums written by the kernels above:
+ * out[i] = sum_j partial[i*slots + j], i < count. */
+int vc_bits_reduce(vc_stream s, const double *partial, int slots, int count, double *out);
+/* number of partial-sum slots each entropy launch uses (size bits_partial accordingly) */
+int vc_bits_slots(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Range coder (host).  Replaces compressai._CXX.pmf_to_quantized_cdf and
+ * compressai.ans.RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes as called from
+ * EntropyModel.compress/decompress (reached from LHBDC/model/layers.py:97-98,103,108,112).
+ * cdfs: dense int32 [n_tables][cdf_stride].
+ * ---------------------------------------------------------------------------------------- */
+int vc_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf_out /* n+1 */);
+/* returns bytes written (>=0) or a negative VC_E* code; out_cap >= 4*(count*? ) -- use vc_rans_bound */
+size_t vc_rans_bound(size_t count);
+long long vc_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes, size_t count,
+                                      const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                      const int32_t *offsets, uint8_t *out, size_t out_cap);
+int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, const int32_t *indexes, size_t count,
+                                const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                const int32_t *offsets, int32_t *symbols_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VC_HIP_H */

@@ -1,0 +1,36 @@
+"""Shared test helpers (no reference access: only fixtures + seeded weights)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fixture(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def frame_tensor(u8):
+    """HWC uint8 -> [1,3,H,W] float32 in [0,1] (how gen_golden.py fed the reference)."""
+    return torch.from_numpy(u8.astype(np.float32).transpose(2, 0, 1))[None] / 255.0
+
+
+def psnr(a, b):
+    mse = ((a.double() - b.double()) ** 2).mean().item()
+    return 10.0 * np.log10(1.0 / mse) if mse > 0 else float("inf")
+
+
+def lhbdc_pair(seed, device=None):
+    """(oracle model, product model) carrying the same seeded checkpoint."""
+    from oracle import lhbdc as ol
+    from vcamd import lhbdc
+    from vcamd.seeding import seeded_state_dict
+    prod = lhbdc.Model()
+    sd = seeded_state_dict(prod.state_dict(), seed=seed)
+    prod.load_state_dict(sd)
+    ora = ol.LhbdcModel().eval()
+    ora.load_state_dict(sd)
+    if device is not None:
+        prod = prod.to(device)
+    return ora, prod.eval()

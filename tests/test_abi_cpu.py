@@ -1,0 +1,80 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/vc_hip.h declares;
+host-side entry points (weight packing, table construction) behave."""
+import os
+import re
+
+import numpy as np
+import torch
+
+from vcamd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "vc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = hip.lib()
+    names = _declared_functions()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(hip.EXPORTED_SYMBOLS) == names
+    assert lib.vc_target_arch() == b"gfx950"
+
+
+def test_library_is_in_tree():
+    assert os.path.dirname(hip.LIB_PATH) == os.path.join(ROOT, "video-compression_amd")
+
+
+def _unpack(wpk, cfg, cout, cin, k, stride, ps):
+    """inverse of the documented fragment layout [n-tile][tap][k-step][lane][4]"""
+    L = hip.lib()
+    mt = 16 if cfg == 3 else 32
+    ks = 16 if mt == 16 else 8
+    ck = L.vc_conv_chunk(cfg, k, stride, cin)
+    cin_pad = -(-cin // ck) * ck
+    bn = {0: 128, 1: 64, 2: 32, 3: 16}[cfg]
+    cout_pad = -(-cout // bn) * bn
+    arr = wpk.reshape(cout_pad // mt, k * k, cin_pad // ks, 64, 4)
+    w = np.zeros((cout, cin, k, k), dtype=np.float32)
+    cps = cout // 4 if ps else 0
+    for cop in range(cout):
+        co = (cop % cps) * 4 + cop // cps if ps else cop
+        for ci in range(cin):
+            kst, r = divmod(ci, ks)
+            kk, e = divmod(r, 4)
+            lane = kk * mt + cop % mt
+            w[co, ci] = arr[cop // mt, :, kst, lane, e].reshape(k, k)
+    return w
+
+
+def test_weight_packing_is_a_permutation_with_zero_padding():
+    L = hip.lib()
+    g = np.random.default_rng(0)
+    for cout, cin, k, stride, ps in ((128, 128, 3, 1, False), (512, 128, 3, 1, True), (32, 8, 7, 1, False),
+                                     (2, 16, 7, 1, False), (128, 3, 3, 2, False), (12, 128, 3, 1, True),
+                                     (192, 128, 3, 1, False), (128, 19, 1, 2, False)):
+        w = g.standard_normal((cout, cin, k, k)).astype(np.float32)
+        b = g.standard_normal(cout).astype(np.float32)
+        pc = hip.PackedConv(torch.from_numpy(w), torch.from_numpy(b), stride=stride, pixelshuffle=ps, device="cpu")
+        wpk = pc.wpk.numpy()
+        assert wpk.size == L.vc_conv_packed_weight_floats(pc.cfg, cout, cin, k, k, stride)
+        assert np.array_equal(_unpack(wpk, pc.cfg, cout, cin, k, stride, ps), w)
+        assert np.isclose(np.abs(wpk).sum(), np.abs(w).sum(), rtol=1e-5)        # padding is zeros
+        bias = pc.bias.numpy()
+        if ps:
+            cps = cout // 4
+            assert np.array_equal(bias[:cout], b.reshape(cps, 4).T.reshape(-1))
+        else:
+            assert np.array_equal(bias[:cout], b)
+        assert (bias[cout:] == 0).all()
+
+
+def test_conv_desc_rejects_bad_shapes_without_touching_a_gpu():
+    d = hip.ConvDesc()
+    assert hip.lib().vc_conv2d_nhwc(None, d) == -1

@@ -1,0 +1,114 @@
+"""-m gpu: the LHBDC B-frame path (C-ABI HIP kernels behind the m.Model surface) against
+(1) golden fixtures recorded from the REFERENCE in the build container, (2) the CPU oracle on the
+same seeded inputs, (3) size-independent properties (encode -> decode round trip)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import frame_tensor, lhbdc_pair, load_fixture, psnr
+
+pytestmark = pytest.mark.gpu
+
+# floating-point bar (BASELINE.json north_star): reconstructions within 1e-3 dB PSNR of the CPU path.
+PSNR_TOL_DB = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    return lhbdc_pair(1234, dev)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_forward_matches_reference_fixture(dev, models, tag):
+    _, prod = models
+    fx = load_fixture(f"lhbdc_forward_{tag}.npz")
+    assert int(fx["seed"]) == 1234
+    xb, xc, xa = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    with torch.no_grad():
+        x_hat, rate, bits = prod(xb, xc, xa, False)
+    ref = torch.from_numpy(fx["x_hat"])
+    err = (x_hat.cpu() - ref).abs().max().item()
+    # PSNR of both reconstructions against the source frame: must agree to 1e-3 dB
+    src = frame_tensor(fx["current"])
+    d_psnr = abs(psnr(x_hat.cpu(), src) - psnr(ref, src))
+    rel_bits = abs(bits - float(fx["bits"])) / float(fx["bits"])
+    print(f"fixture {tag}: max|d|={err:.3e} dPSNR={d_psnr:.2e} dB bits rel={rel_bits:.2e}")
+    assert d_psnr < PSNR_TOL_DB
+    assert rel_bits < 2e-3
+    assert abs(rate.item() - float(fx["rate"])) / float(fx["rate"]) < 2e-3
+    assert err < 2e-2   # a flipped rounding of one latent moves a few pixels by ~1e-2; bulk is ~1e-5
+
+
+def test_flownet_matches_reference_fixture(dev, models):
+    _, prod = models
+    fx = load_fixture("lhbdc_forward_a.npz")
+    xb, xc = frame_tensor(fx["ref_1"]).to(dev), frame_tensor(fx["current"]).to(dev)
+    flow = prod.FlowNet(xc, xb)
+    assert (flow.cpu() - torch.from_numpy(fx["flow_cb"])).abs().max().item() < 2e-4
+
+
+def test_forward_matches_oracle_other_size(dev, models):
+    ora, prod = models
+    g = torch.Generator().manual_seed(5)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 266, 396, generator=g), 9, 1)
+    xb, xc, xa = (base[..., i:i + 256, 2 * i:2 * i + 384].contiguous() for i in (0, 1, 2))
+    with torch.no_grad():
+        ref, rate_ref, bits_ref = ora(xb, xc, xa, False)
+        out, rate, bits = prod(xb.to(dev), xc.to(dev), xa.to(dev), False)
+    assert abs(psnr(out.cpu(), xc) - psnr(ref, xc)) < PSNR_TOL_DB
+    assert abs(bits - bits_ref) / bits_ref < 2e-3
+    out2, rate2 = prod(xb.to(dev), xc.to(dev), xa.to(dev), True)       # train=True only changes the tuple
+    assert torch.equal(out2, out)
+
+
+def test_codec_roundtrip_and_reference_bitstream(dev, models):
+    """encode_B -> container -> decode_B on the GPU; the strings are compared with the reference's own
+    bitstream for the same inputs (byte-exact when no latent rounding flips; else length within 1%)."""
+    from vcamd import lhbdc
+    _, prod = models
+    prod.mv_compressor.update(force=True)
+    prod.residual_compressor.update(force=True)
+    fx = load_fixture("lhbdc_codec_a.npz")
+    h, w = fx["current"].shape[:2]
+    xb, xc, xa = (lhbdc.process_frame(fx[k].astype(np.float32), dev) for k in ("ref_1", "current", "ref_2"))
+    with torch.no_grad():
+        mv_bits, res_bits = lhbdc.encode_B(prod, xa, xc, xb)
+    blob = lhbdc.write_container(None, 1626, mv_bits, res_bits)
+    lm, s_mv, s_res, shape_mv, shape_res = lhbdc.read_container(blob)
+    assert lm == 1626 and tuple(shape_mv) == tuple(fx["mv_shape"]) and tuple(shape_res) == tuple(fx["res_shape"])
+    with torch.no_grad():
+        dec = lhbdc.decode_B(xb, xa, prod, s_mv, s_res, shape_mv, shape_res)
+    ref_dec = torch.from_numpy(fx["decoded"])
+    src = frame_tensor(fx["current"])
+    d_psnr = abs(psnr(dec.cpu()[..., :h, :w], src) - psnr(ref_dec[..., :h, :w], src))
+    same = {k: bytes(fx[k].tobytes()) == s for k, s in
+            (("mv_y", mv_bits["strings"][0][0]), ("mv_z", mv_bits["strings"][1][0]),
+             ("res_y", res_bits["strings"][0][0]), ("res_z", res_bits["strings"][1][0]))}
+    print("byte-identical to the reference bitstream:", same, f"dPSNR={d_psnr:.2e}")
+    for k, s in (("mv_y", mv_bits["strings"][0][0]), ("mv_z", mv_bits["strings"][1][0]),
+                 ("res_y", res_bits["strings"][0][0]), ("res_z", res_bits["strings"][1][0])):
+        assert abs(len(s) - fx[k].size) <= max(8, 0.01 * fx[k].size), k
+    assert d_psnr < 5e-3
+    u8 = lhbdc.float_to_uint8(dec[0].cpu().numpy())[:h, :w]
+    assert (np.abs(u8.astype(int) - fx["decoded_u8"].astype(int)) > 1).mean() < 1e-3
+
+
+def test_decoder_reproduces_encoder_reconstruction(dev, models):
+    """Property (any size): decoding the product's own bitstream reproduces exactly the symbols that were
+    coded, so decode_B == the encoder-side reconstruction built from the same quantised latents."""
+    from vcamd import hip, lhbdc
+    _, prod = models
+    prod.residual_compressor.update(force=True)
+    x = (torch.rand(1, 3, 128, 192, generator=torch.Generator().manual_seed(3)) - 0.5).to(dev)
+    with torch.no_grad():
+        enc = prod.residual_compressor.compress(x)
+        dec = prod.residual_compressor.decompress(enc["strings"], enc["shape"])["x_hat"]
+        fwd = prod.residual_compressor(x)["x_hat"]
+    assert torch.equal(dec, fwd)

@@ -1,0 +1,302 @@
+"""-m gpu: every HIP entry point against the CPU PyTorch operator the reference calls at that site.
+
+The CPU side here is plain torch (fp32) on the same seeded inputs -- the operators `oracle/` is built
+from.  Tolerances: convolutions 2e-5 * (1 + |ref|) (fp32 FMA chains in a different order), resampling /
+warping 1e-5, entropy bit counts 1e-5 relative, integer outputs exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _close(a, b, tol, what=""):
+    a, b = a.double().cpu(), b.double().cpu()
+    err = ((a - b).abs() / (1.0 + b.abs())).max().item()
+    assert err <= tol, f"{what}: max rel-abs err {err:.3e} > {tol}"
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, h, w, n, act, pixelshuffle
+    (128, 128, 3, 1, 24, 40, 1, "lrelu", False),   # N128
+    (128, 128, 3, 2, 34, 66, 1, "none", False),    # stride 2, odd tiles
+    (3, 128, 3, 2, 64, 64, 2, "lrelu", False),     # tiny Cin, scalar staging path
+    (4, 128, 3, 2, 64, 64, 1, "lrelu", False),
+    (19, 128, 3, 2, 32, 64, 1, "lrelu", False),
+    (128, 512, 3, 1, 17, 30, 1, "lrelu", True),    # subpel 128->512 + pixel shuffle
+    (128, 192, 3, 1, 16, 32, 1, "lrelu", False),   # N64 x3
+    (192, 768, 3, 1, 9, 33, 1, "lrelu", True),
+    (192, 256, 3, 1, 20, 20, 1, "none", False),
+    (128, 12, 3, 1, 16, 48, 1, "none", True),      # N16 + pixel shuffle to 3 channels
+    (128, 16, 3, 1, 16, 48, 1, "none", True),
+    (128, 128, 1, 2, 32, 64, 1, "none", False),    # skip projection
+    (3, 128, 1, 2, 32, 64, 1, "none", False),
+    (8, 32, 7, 1, 40, 72, 2, "relu", False),       # SPyNet
+    (32, 64, 7, 1, 34, 60, 1, "relu", False),
+    (64, 32, 7, 1, 34, 60, 1, "relu", False),
+    (32, 16, 7, 1, 34, 60, 1, "relu", False),
+    (16, 2, 7, 1, 34, 60, 4, "none", False),
+    (6, 32, 5, 1, 32, 64, 1, "relu", False),       # mask net
+    (32, 64, 5, 1, 32, 64, 1, "relu", False),
+    (192, 64, 5, 1, 16, 32, 1, "relu", False),
+    (96, 32, 5, 1, 16, 32, 1, "relu", False),
+    (32, 1, 5, 1, 24, 40, 1, "sigmoid", False),
+    (64, 128, 3, 1, 16, 32, 1, "relu", False),
+    (256, 128, 3, 1, 16, 32, 1, "relu", False),
+    (6, 32, 3, 1, 32, 32, 1, "lrelu", False),      # Flex U-Net
+    (512, 512, 3, 1, 8, 16, 1, "lrelu", False),
+    (32, 4, 3, 1, 32, 32, 1, "none", False),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w,n,act,ps", CONV_CASES)
+def test_conv2d(dev, cin, cout, k, stride, h, w, n, act, ps):
+    from vcamd import hip
+    x = _rand((n, cin, h, w), 1)
+    wt = _rand((cout, cin, k, k), 2, 1.0 / np.sqrt(cin * k * k))
+    b = _rand((cout,), 3, 0.1)
+    ref = F.conv2d(x, wt, b, stride=stride, padding=k // 2)
+    if ps:
+        ref = F.pixel_shuffle(ref, 2)
+    slope = 0.01
+    ref = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, slope),
+           "sigmoid": torch.sigmoid}[act](ref)
+    pc = hip.PackedConv(wt, b, stride=stride, pixelshuffle=ps, device=dev)
+    code = {"none": hip.ACT_NONE, "relu": hip.ACT_RELU, "lrelu": hip.ACT_LRELU, "sigmoid": hip.ACT_SIGMOID}[act]
+    out = hip.nhwc_to_nchw(pc(hip.nchw_to_nhwc(x.to(dev)), act=code, slope=slope))
+    assert out.shape == ref.shape
+    _close(out, ref, 2e-5, f"conv {cin}->{cout} k{k} s{stride}")
+
+
+def test_conv_residual_and_channel_slices(dev):
+    """residual add + reading/writing channel slices of wider buffers (concat-free U-Net plumbing)"""
+    from vcamd import hip
+    from vcamd.hip import T
+    x = _rand((1, 96, 16, 32), 4)
+    wt = _rand((32, 96, 5, 5), 5, 0.02)
+    b = _rand((32,), 6, 0.1)
+    res = _rand((1, 32, 16, 32), 7)
+    ref = F.relu(F.conv2d(x, wt, b, padding=2)) + res
+    wide_in = T.empty(1, 16, 32, 128, dev)
+    wide_in.buf.fill_(123.0)
+    hip.check(hip.lib().vc_nchw_to_nhwc(hip.stream(), x.to(dev).contiguous().data_ptr(), wide_in.channels(16, 112).view()), "x")
+    wide_out = T.empty(1, 16, 32, 64, dev)
+    wide_out.buf.fill_(-7.0)
+    pc = hip.PackedConv(wt, b, device=dev)
+    pc(wide_in.channels(16, 112), out=wide_out.channels(8, 40), act=hip.ACT_RELU, res=hip.nchw_to_nhwc(res.to(dev)))
+    full = wide_out.to_nchw()
+    _close(full[:, 8:40], ref, 2e-5, "sliced conv")
+    assert (full[:, :8] == -7.0).all() and (full[:, 40:] == -7.0).all()
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn(dev, inverse):
+    from oracle.cai.layers import GDN as OGDN
+    from vcamd import hip
+    from vcamd.layers import GDN
+    from vcamd.seeding import seeded_state_dict
+    o = OGDN(128, inverse=inverse)
+    sd = seeded_state_dict(o.state_dict(), 5)
+    o.load_state_dict(sd)
+    g = GDN(128, inverse=inverse)
+    g.load_state_dict(sd)
+    g = g.to(dev)
+    x = _rand((2, 128, 20, 36), 8, 2.0)
+    res = _rand((2, 128, 20, 36), 9)
+    with torch.no_grad():
+        ref = o(x) + res
+    out = hip.nhwc_to_nchw(g.run(hip.nchw_to_nhwc(x.to(dev)), res=hip.nchw_to_nhwc(res.to(dev))))
+    _close(out, ref, 2e-5, "gdn")
+
+
+def test_layout_roundtrip(dev):
+    from vcamd import hip
+    x = _rand((2, 5, 7, 9), 10).to(dev)
+    assert torch.equal(hip.nhwc_to_nchw(hip.nchw_to_nhwc(x)), x)
+
+
+@pytest.mark.parametrize("k,scale,h,w,oh,ow", [(2, 1.0, 68, 120, 34, 60), (4, 0.5, 192, 256, 64, 64),
+                                                (4, 1.0, 256, 192, 64, 64), (1, 1.0, 48, 80, 64, 128)])
+def test_avgpool_reflectpad(dev, k, scale, h, w, oh, ow):
+    from vcamd import hip
+    x = _rand((2, 2, h, w), 11)
+    ref = F.avg_pool2d(x * scale, k) if k > 1 else x * scale
+    ref = F.pad(ref, (0, ow - ref.shape[3], 0, oh - ref.shape[2]), mode="reflect") if (oh, ow) != tuple(ref.shape[2:]) else ref
+    out = hip.nhwc_to_nchw(hip.avgpool_reflectpad(hip.nchw_to_nhwc(x.to(dev)), k, scale, oh, ow))
+    _close(out, ref, 1e-6, "avgpool+reflect")
+
+
+def test_maxpool(dev):
+    from vcamd import hip
+    x = _rand((1, 32, 16, 24), 12)
+    out = hip.nhwc_to_nchw(hip.maxpool2(hip.nchw_to_nhwc(x.to(dev))))
+    assert torch.equal(out.cpu(), F.max_pool2d(x, 2, 2))
+
+
+@pytest.mark.parametrize("factor,align,c,h,w", [(2, False, 128, 8, 12), (4, False, 2, 48, 64), (2, True, 2, 17, 30),
+                                                (2, False, 512, 4, 4)])
+def test_upsample(dev, factor, align, c, h, w):
+    from vcamd import hip
+    x = _rand((2, c, h, w), 13)
+    ref = F.interpolate(x, scale_factor=factor, mode="bilinear", align_corners=align)
+    out = hip.nhwc_to_nchw(hip.upsample_bilinear(hip.nchw_to_nhwc(x.to(dev)), factor, align))
+    _close(out, ref, 1e-6, "upsample")
+
+
+@pytest.mark.parametrize("convention", [1, 2])
+def test_warp(dev, convention):
+    from oracle.flex import warp_w2
+    from oracle.lhbdc import warp_w1
+    from vcamd import hip
+    img = torch.rand(2, 3, 40, 56, generator=torch.Generator().manual_seed(14))
+    flow = _rand((2, 2, 40, 56), 15, 4.0)
+    flow[:, :, :4, :4] = 100.0     # far out of range: border clamp / zero padding
+    flow[:, :, -4:, -4:] = -100.0
+    ref = warp_w1(img, flow) if convention == 1 else warp_w2(img, flow)
+    out = hip.nhwc_to_nchw(hip.warp(convention, hip.nchw_to_nhwc(img.to(dev)), hip.nchw_to_nhwc(flow.to(dev))))
+    _close(out, ref, 2e-5, f"warp W{convention}")
+
+
+@pytest.mark.parametrize("h,w", [(64, 96), (70, 100), (192, 256)])
+def test_spynet(dev, h, w):
+    """whole SPyNet (pre-process, pyramid, level inputs incl. odd-size replicate pad, 7x7 stacks)"""
+    from oracle.lhbdc import SpyNet
+    from vcamd.lhbdc import Network
+    from vcamd.seeding import seeded_state_dict
+    o = SpyNet()
+    sd = seeded_state_dict(o.state_dict(), 21)
+    o.load_state_dict(sd)
+    net = Network()
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    g = torch.Generator().manual_seed(16)
+    a = F.avg_pool2d(torch.rand(1, 3, h + 4, w + 4, generator=g), 5, 1)
+    b = torch.roll(a, shifts=(1, 2), dims=(2, 3)) * 0.98 + 0.01
+    with torch.no_grad():
+        ref = o(a, b)
+    out = net(a.to(dev), b.to(dev))
+    _close(out, ref, 2e-4, "spynet")
+
+
+def test_masknet(dev):
+    from oracle.lhbdc import MaskNet
+    from vcamd.lhbdc import Mask
+    from vcamd.seeding import seeded_state_dict
+    o = MaskNet()
+    sd = seeded_state_dict(o.state_dict(), 22)
+    o.load_state_dict(sd)
+    m = Mask()
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x = torch.rand(1, 6, 64, 96, generator=torch.Generator().manual_seed(17))
+    with torch.no_grad():
+        ref = o(x)
+    _close(m(x.to(dev)), ref, 2e-5, "masknet")
+
+
+def test_blend(dev):
+    from vcamd import hip
+    from vcamd.hip import T
+    g = torch.Generator().manual_seed(18)
+    fw, bw, cur = (torch.rand(1, 3, 16, 24, generator=g) for _ in range(3))
+    m = torch.rand(1, 1, 16, 24, generator=g)
+    pred_ref = m * fw + (1.0 - m) * bw
+    fwbw = hip.nchw_to_nhwc(torch.cat([fw, bw], 1).to(dev))
+    mt, ct = hip.nchw_to_nhwc(m.to(dev)), hip.nchw_to_nhwc(cur.to(dev))   # keep the buffers alive
+    pred, resid = T.empty(1, 16, 24, 3, dev), T.empty(1, 16, 24, 3, dev)
+    hip.check(hip.lib().vc_lhbdc_blend(hip.stream(), fwbw.view(), mt.view(), ct.view(), pred.view(), resid.view()), "blend")
+    _close(hip.nhwc_to_nchw(pred), pred_ref, 1e-6, "blend pred")
+    _close(hip.nhwc_to_nchw(resid), cur - pred_ref, 1e-6, "blend resid")
+
+
+def _codec_pair(dev, io, seed):
+    from oracle.lhbdc import HyperpriorCodec
+    from vcamd.lhbdc import MVCompressor, ResidualCompressor
+    from vcamd.seeding import seeded_state_dict
+    o = HyperpriorCodec(io).eval()
+    sd = seeded_state_dict(o.state_dict(), seed)
+    o.load_state_dict(sd)
+    c = (MVCompressor if io == 4 else ResidualCompressor)()
+    c.load_state_dict(sd)
+    return o, c.to(dev).eval()
+
+
+@pytest.mark.parametrize("io", [3, 4])
+def test_hyperprior_forward(dev, io):
+    o, c = _codec_pair(dev, io, 30 + io)
+    x = _rand((1, io, 128, 192), 19, 0.5)
+    with torch.no_grad():
+        ref = o(x)
+    out = c(x.to(dev))
+    _close(out["x_hat"], ref["x_hat"], 5e-4, "codec x_hat")
+    for k in "yz":
+        rb = (-torch.log2(ref["likelihoods"][k])).sum().item()
+        assert abs(out["bits"][k].item() - rb) / rb < 2e-3, (k, out["bits"][k].item(), rb)
+
+
+def test_entropy_kernels_exact_inputs(dev):
+    """factorised + Gaussian likelihood kernels on IDENTICAL inputs (no conv noise): bits within 1e-5,
+    quantised tensors / symbols / indexes exact."""
+    from oracle.cai.entropy_models import EntropyBottleneck as OEB, GaussianConditional as OGC, get_scale_table
+    from vcamd import hip
+    from vcamd.hip import T
+    from vcamd.layers import BitCounter, EntropyBottleneck
+    from vcamd.seeding import seeded_state_dict
+    o = OEB(128)
+    sd = seeded_state_dict(o.state_dict(), 41)
+    o.load_state_dict(sd)
+    eb = EntropyBottleneck(128)
+    eb.load_state_dict(sd)
+    eb = eb.to(dev)
+    z = _rand((2, 128, 9, 14), 20, 4.0)
+    with torch.no_grad():
+        z_ref, lik = o(z)
+    bits = BitCounter(dev)
+    zt = hip.nchw_to_nhwc(z.to(dev))
+    z_hat = T.empty(zt.n, zt.h, zt.w, zt.c, dev)
+    sym = torch.empty(z.numel(), dtype=torch.int32, device=dev)
+    hip.check(hip.lib().vc_eb_forward(hip.stream(), zt.view(), eb.device_params().data_ptr(), None, None, z_hat.view(),
+                                      sym.data_ptr(), bits.next_row_ptr(), bits.slots), "eb")
+    assert torch.equal(hip.nhwc_to_nchw(z_hat).cpu(), z_ref)
+    med = o.quantiles[:, 0, 1].detach().view(1, -1, 1, 1)
+    assert torch.equal(sym.cpu().view(z.shape), torch.round(z - med).int())
+    rb = (-torch.log2(lik)).sum().item()
+    assert abs(bits.totals()[0].item() - rb) / rb < 1e-5
+
+    gc = OGC(None)
+    gc.update_scale_table(get_scale_table(), force=True)
+    y = _rand((1, 128, 12, 20), 21, 6.0)
+    sc = torch.exp(_rand((1, 128, 12, 20), 22, 1.5)) * 0.3
+    sc[0, 0, 0, :5] = torch.tensor([0.0, 0.11, -3.0, 256.0, 1e4])
+    mu = _rand((1, 128, 12, 20), 23, 2.0)
+    with torch.no_grad():
+        y_ref, lik = gc(y, sc, means=mu)
+        idx_ref = gc.build_indexes(sc)
+    bits = BitCounter(dev)
+    yt, st, mt = (hip.nchw_to_nhwc(t.to(dev)) for t in (y, sc, mu))
+    y_hat = T.empty(yt.n, yt.h, yt.w, yt.c, dev)
+    sym = torch.empty(y.numel(), dtype=torch.int32, device=dev)
+    idx = torch.empty_like(sym)
+    table = gc.scale_table.to(dev)
+    hip.check(hip.lib().vc_gc_forward(hip.stream(), yt.view(), st.view(), mt.view(), None, None, y_hat.view(),
+                                      bits.next_row_ptr(), bits.slots, None, sym.data_ptr(), idx.data_ptr(),
+                                      table.data_ptr(), table.numel()), "gc")
+    assert torch.equal(hip.nhwc_to_nchw(y_hat).cpu(), y_ref)
+    assert torch.equal(sym.cpu().view(y.shape), torch.round(y - mu).int())
+    assert torch.equal(idx.cpu().view(y.shape), idx_ref)
+    rb = (-torch.log2(lik)).sum().item()
+    assert abs(bits.totals()[0].item() - rb) / rb < 1e-5

@@ -1,0 +1,140 @@
+// C-ABI front end of the convolution engine: tile-config selection, weight packing, launch.
+#include <string.h>
+#include "conv_mfma.h"
+
+static inline int cfg_mt(int cfg) { return cfg == VC_CFG_N16 ? 16 : 32; }
+static inline int cfg_bn(int cfg)
+{
+    switch (cfg) {
+    case VC_CFG_N128: return 128;
+    case VC_CFG_N64: return 64;
+    case VC_CFG_N32: return 32;
+    default: return 16;
+    }
+}
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+extern "C" int vc_conv_select_cfg(int cout, int cin, int k, int stride)
+{
+    (void)cin;
+    int cfg;
+    if (cout <= 16) cfg = VC_CFG_N16;
+    else if (cout <= 32) cfg = VC_CFG_N32;
+    else if (cout <= 64 || (cout % 128 != 0 && cout % 64 == 0)) cfg = VC_CFG_N64;
+    else cfg = VC_CFG_N128;
+    if (cfg == VC_CFG_N16 && stride == 2) cfg = VC_CFG_N32;  // no 16-wide stride-2 instance
+    (void)k;
+    return cfg;
+}
+
+extern "C" int vc_conv_chunk(int cfg, int k, int stride, int cin)
+{
+    switch (k) {
+    case 1: return 32;
+    case 3: return stride == 2 ? 8 : 32;
+    case 5: return 16;
+    case 7: return (cfg == VC_CFG_N32 && cin <= 8) ? 8 : 16;
+    }
+    return -1;
+}
+
+extern "C" size_t vc_conv_packed_weight_floats(int cfg, int cout, int cin, int kh, int kw, int stride)
+{
+    const int ck = vc_conv_chunk(cfg, kh, stride, cin);
+    if (ck <= 0) return 0;
+    const int cin_pad = round_up(cin, ck), cout_pad = round_up(cout, cfg_bn(cfg));
+    return (size_t)cout_pad * kh * kw * cin_pad;
+}
+
+extern "C" size_t vc_conv_packed_bias_floats(int cfg, int cout) { return (size_t)round_up(cout, cfg_bn(cfg)); }
+
+extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout, int cin, int kh, int kw,
+                                    int stride, int cfg, int pixelshuffle, float *wpk, float *bpk)
+{
+    if (kh != kw) return VC_EINVAL;
+    const int ck = vc_conv_chunk(cfg, kh, stride, cin);
+    if (ck <= 0) return VC_EINVAL;
+    if (pixelshuffle && (cout % 4)) return VC_EINVAL;
+    const int mt = cfg_mt(cfg), ks = (mt == 32) ? 8 : 16;
+    const int cin_pad = round_up(cin, ck), cout_pad = round_up(cout, cfg_bn(cfg));
+    const int taps = kh * kw, ksteps = cin_pad / ks, ntiles = cout_pad / mt;
+    const int cps = cout / 4;
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int kst = 0; kst < ksteps; ++kst)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = lane % mt, kk = lane / mt;
+                    const int cop = nt * mt + j;  // packed (possibly permuted) output channel
+                    int co = cop;
+                    if (pixelshuffle && cop < cout) {
+                        const int pos = cop / cps, c = cop % cps;
+                        co = c * 4 + pos;
+                    }
+                    float *dst = wpk + ((((size_t)nt * taps + tap) * ksteps + kst) * 64 + lane) * 4;
+                    for (int e = 0; e < 4; ++e) {
+                        const int ci = kst * ks + kk * 4 + e;
+                        float v = 0.0f;
+                        if (cop < cout && ci < cin) v = w[(((size_t)co * cin + ci) * kh + tap / kw) * kw + tap % kw];
+                        dst[e] = v;
+                    }
+                }
+    for (int cop = 0; cop < cout_pad; ++cop) {
+        float v = 0.0f;
+        if (cop < cout && bias) {
+            int co = cop;
+            if (pixelshuffle) co = (cop % cps) * 4 + cop / cps;
+            v = bias[co];
+        }
+        bpk[cop] = v;
+    }
+    return VC_OK;
+}
+
+extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
+{
+    if (!d || !d->in.p || !d->out.p || !d->wpk || !d->bias) return VC_EINVAL;
+    if (d->kh != d->kw) return VC_EINVAL;
+    const int k = d->kh, st = d->stride;
+    const int ck = vc_conv_chunk(d->cfg, k, st, d->in.c);
+    if (ck <= 0) return VC_EINVAL;
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d->in.p; a.in_sn = d->in.sn; a.in_sh = d->in.sh; a.in_sw = d->in.sw;
+    a.N = d->in.n; a.H = d->in.h; a.W = d->in.w; a.Cin = d->in.c;
+    a.Ho = (d->in.h + 2 * (k / 2) - k) / st + 1;
+    a.Wo = (d->in.w + 2 * (k / 2) - k) / st + 1;
+    a.out = d->out.p; a.out_sn = d->out.sn; a.out_sh = d->out.sh; a.out_sw = d->out.sw;
+    if (d->out_mode == VC_OUT_PIXELSHUFFLE2) {
+        a.Cout = d->out.c * 4;
+        if (d->out.h != 2 * a.Ho || d->out.w != 2 * a.Wo) return VC_EINVAL;
+    } else {
+        a.Cout = d->out.c;
+        if (d->out.h != a.Ho || d->out.w != a.Wo) return VC_EINVAL;
+    }
+    if (d->out.n != d->in.n) return VC_EINVAL;
+    if (d->epi != VC_EPI_NONE && !d->mul) return VC_EINVAL;
+    a.wpk = d->wpk; a.bias = d->bias;
+    a.res = d->res; a.res_sn = d->res_sn; a.res_sh = d->res_sh; a.res_sw = d->res_sw;
+    a.mul = d->mul; a.mul_sn = d->mul_sn; a.mul_sh = d->mul_sh; a.mul_sw = d->mul_sw;
+    a.chscale = d->chscale;
+    a.cin_pad = round_up(a.Cin, ck);
+    const int bn = cfg_bn(d->cfg);
+    const int th = 8, tw = 32;
+    a.tiles_x = (a.Wo + tw - 1) / tw;
+    a.tiles_y = (a.Ho + th - 1) / th;
+    a.nblks = round_up(a.Cout, bn) / bn;
+    a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
+    a.act = d->act; a.slope = d->slope;
+    a.epi = d->epi; a.in_xform = d->in_xform; a.out_mode = d->out_mode;
+    a.vec4 = ((a.Cin % 4) == 0 && (a.in_sw % 4) == 0 && (a.in_sh % 4) == 0 && (a.in_sn % 4) == 0 &&
+              ((uintptr_t)a.in % 16) == 0) ? 1 : 0;
+    if (a.total_blocks <= 0) return VC_EINVAL;
+    hipStream_t stream = as_stream(s);
+    switch (k) {
+    case 1: return conv_dispatch_k1(stream, a, st, d->cfg, ck);
+    case 3: return conv_dispatch_k3(stream, a, st, d->cfg, ck);
+    case 5: return conv_dispatch_k5(stream, a, st, d->cfg, ck);
+    case 7: return conv_dispatch_k7(stream, a, st, d->cfg, ck);
+    }
+    return VC_EINVAL;
+}

@@ -1,0 +1,13 @@
+// 5x5 convolutions of the LHBDC mask U-Net (LHBDC/model/layers.py:202-209).
+#include "conv_mfma.h"
+int conv_dispatch_k5(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck)
+{
+    if (stride != 1 || ck != 16) return VC_EINVAL;
+    switch (cfg) {
+    case VC_CFG_N128: return launch_conv<5, 5, 1, 16, CfgN128>(st, a);
+    case VC_CFG_N64: return launch_conv<5, 5, 1, 16, CfgN64>(st, a);
+    case VC_CFG_N32: return launch_conv<5, 5, 1, 16, CfgN32>(st, a);
+    case VC_CFG_N16: return launch_conv<5, 5, 1, 16, CfgN16>(st, a);
+    }
+    return VC_EINVAL;
+}

@@ -1,0 +1,15 @@
+// 7x7 convolutions of SPyNet's Basic blocks (LHBDC/model/flow.py:52-62).
+#include "conv_mfma.h"
+int conv_dispatch_k7(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck)
+{
+    if (stride != 1) return VC_EINVAL;
+    if (ck == 8 && cfg == VC_CFG_N32) return launch_conv<7, 7, 1, 8, CfgN32>(st, a);
+    if (ck != 16) return VC_EINVAL;
+    switch (cfg) {
+    case VC_CFG_N128: return launch_conv<7, 7, 1, 16, CfgN128>(st, a);
+    case VC_CFG_N64: return launch_conv<7, 7, 1, 16, CfgN64>(st, a);
+    case VC_CFG_N32: return launch_conv<7, 7, 1, 16, CfgN32>(st, a);
+    case VC_CFG_N16: return launch_conv<7, 7, 1, 16, CfgN16>(st, a);
+    }
+    return VC_EINVAL;
+}

@@ -1,0 +1,279 @@
+// Implicit-GEMM convolution on the CDNA4 fp32 matrix pipe (v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
+//
+//   GEMM view:  M = output pixels (one M-tile = MT consecutive x of one output row)
+//               N = output channels (N-tile = MT channels)
+//               K = taps x input channels, walked as  channel-chunk(CK) -> tap -> k-step(KS)
+//
+//   A (pixels x k): a TH x TW output tile's input footprint (with halo) is staged once per channel
+//       chunk into LDS as [row][col][CK+4] floats.  The +4 pad makes the lane stride an odd number
+//       of 16-byte slots, so the per-lane ds_read_b128 (4 consecutive channels) is conflict-free.
+//       Stride-2 convolutions de-interleave even/odd columns while staging so that the lanes of an
+//       M-tile still read consecutive LDS columns.
+//   B (k x channels): weights are re-packed once at model load into *fragment order*
+//       [n-tile][tap][k-step][lane][4] so that each wave fetches a B fragment with one fully
+//       coalesced 1 KiB global_load_dwordx4 straight from L2 -- no LDS round trip, no barrier.
+//   One ds_read_b128 + one global_load_dwordx4 feed 4 MFMAs (the 4 floats are 4 k-sub-steps).
+//
+//   The fp32 MFMA is bit-for-bit an fp32 FMA chain (cdna guide section 3), so results differ from the
+//   PyTorch-CPU reference only by summation order.
+#pragma once
+#include "common.h"
+
+#include <type_traits>
+#include <utility>
+
+// compile-time loop: keeps accumulator indices static so the tiles stay in registers
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(std::forward<F>(f));
+    }
+}
+
+struct ConvArgs {
+    const float *in;
+    long long in_sn, in_sh, in_sw;
+    int N, H, W, Cin;
+    float *out;
+    long long out_sn, out_sh, out_sw;
+    int Ho, Wo, Cout;
+    const float *wpk;
+    const float *bias;
+    const float *res;
+    long long res_sn, res_sh, res_sw;
+    const float *mul;
+    long long mul_sn, mul_sh, mul_sw;
+    const float *chscale;
+    int cin_pad;       // Cin rounded up to the channel chunk
+    int tiles_x, tiles_y, nblks, total_blocks;
+    int act;
+    float slope;
+    int epi, in_xform, out_mode, vec4;
+};
+
+template <int MT> struct Mfma;
+template <> struct Mfma<32> {
+    typedef f32x16 acc_t;
+    static constexpr int NREG = 16, KS = 8;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+};
+template <> struct Mfma<16> {
+    typedef f32x4 acc_t;
+    static constexpr int NREG = 4, KS = 16;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int reg, int lane) { return (lane >> 4) * 4 + reg; }
+};
+
+// Tile configuration: 4 waves split the M-tiles of a TH x (XT*MT) output tile; every wave covers all
+// WN N-tiles of the block (BN = WN*MT output channels).
+template <int MT_, int TH_, int XT_, int WM_, int WN_> struct TileCfg {
+    static constexpr int MT = MT_, TH = TH_, XT = XT_, WM = WM_, WN = WN_;
+    static constexpr int TW = XT * MT, BN = WN * MT;
+    static_assert(TH * XT == 4 * WM, "4 waves x WM M-tiles must cover the tile");
+};
+typedef TileCfg<32, 8, 1, 2, 4> CfgN128;
+typedef TileCfg<32, 8, 1, 2, 2> CfgN64;
+typedef TileCfg<32, 8, 1, 2, 1> CfgN32;
+typedef TileCfg<16, 8, 2, 4, 1> CfgN16;
+
+template <int KH, int KW, int S, int CK, class C> struct ConvGeom {
+    static constexpr bool POINT = (KH == 1 && KW == 1);
+    static constexpr int LS = POINT ? 1 : S;                  // stride as seen by the LDS image
+    static constexpr int ROWS_IN = (C::TH - 1) * LS + KH;
+    static constexpr int COLS_IN = (C::TW - 1) * LS + KW;
+    static constexpr int HALF = (COLS_IN + 1) / 2;
+    static constexpr int COLS_L = (LS == 2) ? 2 * HALF : COLS_IN;
+    static constexpr int CKP = CK + 4;
+    static constexpr int LDS_FLOATS = ROWS_IN * COLS_L * CKP;
+    static constexpr int KS = Mfma<C::MT>::KS;
+    static constexpr int KSTEPS = CK / KS;
+    static_assert(CK % KS == 0, "chunk must be a whole number of k-steps");
+    static_assert(LDS_FLOATS * 4 <= 65536, "keep two workgroups per CU");
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope)
+{
+    if (act == VC_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == VC_ACT_LRELU) return v >= 0.0f ? v : v * slope;
+    if (act == VC_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+template <int KH, int KW, int S, int CK, class C>
+__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs p)
+{
+    typedef ConvGeom<KH, KW, S, CK, C> G;
+    typedef Mfma<C::MT> M;
+    constexpr int MT = C::MT, WM = C::WM, WN = C::WN, KS = G::KS, KSTEPS = G::KSTEPS;
+    constexpr int TAPS = KH * KW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    // ---- block -> (n-block, tile x, tile y, image); consecutive ids share an XCD (and its L2) ----
+    int bid = blockIdx.x;
+    {
+        const int nb = p.total_blocks, xcd = bid & 7, local = bid >> 3;
+        const int q = nb >> 3, r = nb & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int nblk = bid % p.nblks;
+    int t1 = bid / p.nblks;
+    const int tx = t1 % p.tiles_x;
+    t1 /= p.tiles_x;
+    const int ty = t1 % p.tiles_y;
+    const int img = t1 / p.tiles_y;
+
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane % MT, kk = lane / MT;
+
+    // ---- accumulators start at the bias of the lane's output channel ----
+    typename M::acc_t acc[WM][WN];
+#pragma unroll
+    for (int n = 0; n < WN; ++n) {
+        const float b = p.bias[nblk * C::BN + n * MT + li];
+#pragma unroll
+        for (int t = 0; t < WM; ++t)
+#pragma unroll
+            for (int r = 0; r < M::NREG; ++r) acc[t][n][r] = b;
+    }
+
+    // ---- per-lane LDS read bases of the wave's M-tiles ----
+    int abase[WM];
+#pragma unroll
+    for (int t = 0; t < WM; ++t) {
+        const int m = wave * WM + t;
+        const int row = m / C::XT, xt = m % C::XT;
+        abase[t] = ((row * G::LS) * G::COLS_L + (xt * MT + li)) * G::CKP + 4 * kk;
+    }
+
+    const int ksteps_total = p.cin_pad / KS;
+    const long long ntile_stride = (long long)TAPS * ksteps_total * 256;
+    const float *wlane = p.wpk + (long long)(nblk * WN) * ntile_stride + lane * 4;
+
+    const int pad_y = KH / 2, pad_x = KW / 2;
+    const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
+    const float *in_img = p.in + (long long)img * p.in_sn;
+
+    for (int c0 = 0; c0 < p.cin_pad; c0 += CK) {
+        __syncthreads();
+        // ---- stage the input footprint of this channel chunk ----
+        {
+            constexpr int C4 = CK / 4;
+            constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
+            for (int idx = threadIdx.x; idx < ITEMS; idx += 256) {
+                const int c4 = idx % C4;
+                const int pc = idx / C4;
+                const int col = pc % G::COLS_IN, row = pc / G::COLS_IN;
+                const int iy = G::POINT ? (oy0 + row) * S : iy0 + row;
+                const int ix = G::POINT ? (ox0 + col) * S : ix0 + col;
+                const int ch = c0 + c4 * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin) {
+                    const float *src = in_img + (long long)iy * p.in_sh + (long long)ix * p.in_sw + ch;
+                    if (p.vec4) {
+                        v = *reinterpret_cast<const f32x4 *>(src);
+                    } else {
+                        v.x = src[0];
+                        if (ch + 1 < p.Cin) v.y = src[1];
+                        if (ch + 2 < p.Cin) v.z = src[2];
+                        if (ch + 3 < p.Cin) v.w = src[3];
+                    }
+                    if (p.in_xform == VC_IN_SQUARE) v = v * v;
+                }
+                const int pos = (G::LS == 2) ? ((col & 1) * G::HALF + (col >> 1)) : col;
+                *reinterpret_cast<f32x4 *>(&lds[(row * G::COLS_L + pos) * G::CKP + c4 * 4]) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- contraction over taps x k-steps of this chunk ----
+        const float *wchunk = wlane + (long long)(c0 / KS) * 256;
+#pragma unroll 1
+        for (int ky = 0; ky < KH; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const int tap = ky * KW + kx;
+                const int tapoff = (G::LS == 2)
+                                       ? (ky * G::COLS_L + (kx & 1) * G::HALF + (kx >> 1)) * G::CKP
+                                       : (ky * G::COLS_L + kx) * G::CKP;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    f32x4 b[WN], a[WM];
+#pragma unroll
+                    for (int n = 0; n < WN; ++n)
+                        b[n] = *reinterpret_cast<const f32x4 *>(
+                            wchunk + n * ntile_stride + ((long long)tap * ksteps_total + ks) * 256);
+#pragma unroll
+                    for (int t = 0; t < WM; ++t)
+                        a[t] = *reinterpret_cast<const f32x4 *>(&lds[abase[t] + tapoff + ks * KS]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < WM; ++t)
+#pragma unroll
+                            for (int n = 0; n < WN; ++n) acc[t][n] = M::run(a[t][e], b[n][e], acc[t][n]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: (GDN) -> activation -> channel gain -> residual -> store (plain / pixel-shuffle) ----
+    static_for<0, WM>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int m = wave * WM + t;
+        const int oy = oy0 + m / C::XT;
+        const int xbase = ox0 + (m % C::XT) * MT;
+        static_for<0, WN>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            const int co = nblk * C::BN + n * MT + li;
+            const bool co_ok = (co < p.Cout) && (oy < p.Ho);
+            const float gain = (p.chscale && co_ok) ? p.chscale[co] : 1.0f;
+            const int cps = p.Cout >> 2;
+            const int pos = (p.out_mode == VC_OUT_PLAIN) ? 0 : co / cps;
+            const int cch = (p.out_mode == VC_OUT_PLAIN) ? co : co - pos * cps;
+            const int sc = (p.out_mode == VC_OUT_PLAIN) ? 1 : 2;
+            const int yy = sc * oy + (pos >> 1);
+            const long long out_row = (long long)img * p.out_sn + (long long)yy * p.out_sh + cch;
+            const long long res_row = (long long)img * p.res_sn + (long long)yy * p.res_sh + cch;
+            const long long mul_row = (long long)img * p.mul_sn + (long long)oy * p.mul_sh + co;
+#pragma unroll
+            for (int r = 0; r < M::NREG; ++r) {
+                const int ox = xbase + M::row(r, lane);
+                float v = acc[t][n][r];
+                if (co_ok && ox < p.Wo) {
+                    if (p.epi != VC_EPI_NONE) {
+                        const float x = p.mul[mul_row + (long long)ox * p.mul_sw];
+                        // IEEE sqrt and divide, like the CPU path's x * rsqrt(norm)
+                        v = (p.epi == VC_EPI_GDN) ? x * (1.0f / sqrtf(v)) : x * sqrtf(v);
+                    }
+                    v = apply_act(v, p.act, p.slope) * gain;
+                    const int xx = sc * ox + (pos & 1);
+                    if (p.res) v += p.res[res_row + (long long)xx * p.res_sw];
+                    p.out[out_row + (long long)xx * p.out_sw] = v;
+                }
+            }
+        });
+    });
+}
+
+template <int KH, int KW, int S, int CK, class C> int launch_conv(hipStream_t st, const ConvArgs &a)
+{
+    typedef ConvGeom<KH, KW, S, CK, C> G;
+    hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, S, CK, C>), dim3(a.total_blocks), dim3(256),
+                       G::LDS_FLOATS * sizeof(float), st, a);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
+}
+
+// one translation unit per kernel size (parallel build); each exports a dispatcher over the tile configs
+int conv_dispatch_k1(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
+int conv_dispatch_k3(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
+int conv_dispatch_k5(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
+int conv_dispatch_k7(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);

@@ -1,0 +1,255 @@
+// Entropy-model kernels: fused quantise + likelihood + (-log2) + reduction, and the symboliser /
+// de-quantiser that sit either side of the host range coder.
+//
+//   factorised prior  (CompressAI EntropyBottleneck): p = |sigmoid(s*u) - sigmoid(s*l)| with
+//                     u,l = logistic-CDF logits of z_hat +- 1/2 through a per-channel 1-3-3-3-3-1 MLP
+//   Gaussian conditional (GaussianConditional): p = Phi((.5-|v|)/s) - Phi((-.5-|v|)/s), Phi via erfc
+//
+// Both are HBM-bound streaming kernels (one read of each operand, one write of the quantised tensor);
+// the bit count is reduced wavefront -> workgroup -> one double per workgroup (deterministic), and
+// vc_bits_reduce folds the partials.  Symbols/indexes are written in the (n,c,y,x) order the range
+// coder consumes (CompressAI flattens NCHW tensors).
+#include "common.h"
+
+#define ENT_BLOCK 256
+#define ENT_SLOTS 1024
+
+extern "C" int vc_bits_slots(void) { return ENT_SLOTS; }
+
+__device__ __forceinline__ double block_sum(double v, double *sm)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < ENT_BLOCK / 64; ++w) r += sm[w];
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// logits of the cumulative at x for one channel (params: see VC_EB_PARAMS_PER_CHANNEL in vc_hip.h)
+__device__ __forceinline__ float eb_logits(const float *__restrict__ q, float x)
+{
+    float l[3], m[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float t = q[i] * x + q[3 + i];
+        l[i] = t + q[6 + i] * tanhf(t);
+    }
+    const float *r = q + 9;
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float t = r[3 * i] * l[0];
+            t += r[3 * i + 1] * l[1];
+            t += r[3 * i + 2] * l[2];
+            t += r[9 + i];
+            m[i] = t + r[12 + i] * tanhf(t);
+        }
+        l[0] = m[0]; l[1] = m[1]; l[2] = m[2];
+        r += 15;
+    }
+    float t = r[0] * l[0];
+    t += r[1] * l[1];
+    t += r[2] * l[2];
+    return t + r[3];
+}
+
+__global__ void __launch_bounds__(ENT_BLOCK) k_eb_forward(vc_view z, const float *__restrict__ params,
+                                                          const float *__restrict__ in_gain,
+                                                          const float *__restrict__ out_gain, vc_view zh,
+                                                          int32_t *__restrict__ symbols, double *__restrict__ partial)
+{
+    __shared__ double sm[ENT_BLOCK / 64];
+    double bits = 0.0;
+    const long long total = (long long)z.n * z.h * z.w * z.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % z.c);
+        long long t = i / z.c;
+        const int x = (int)(t % z.w); t /= z.w;
+        const int y = (int)(t % z.h);
+        const int n = (int)(t / z.h);
+        const float *q = params + (long long)c * VC_EB_PARAMS_PER_CHANNEL;
+        const float med = q[58];
+        float v = z.p[view_off(z, n, y, x) + c];
+        if (in_gain) v *= in_gain[c];
+        const float sym = rintf(v - med);             // torch.round: half to even
+        const float zq = sym + med;
+        const float lower = eb_logits(q, zq - 0.5f), upper = eb_logits(q, zq + 0.5f);
+        const float sum = lower + upper;
+        const float sg = sum > 0.0f ? -1.0f : (sum < 0.0f ? 1.0f : 0.0f);
+        float lik = fabsf(sigmoidf_(sg * upper) - sigmoidf_(sg * lower));
+        lik = fmaxf(lik, 1e-9f);
+        bits -= (double)log2f(lik);
+        if (zh.p) zh.p[view_off(zh, n, y, x) + c] = out_gain ? zq * out_gain[c] : zq;
+        if (symbols) symbols[(((long long)n * z.c + c) * z.h + y) * z.w + x] = (int32_t)sym;
+    }
+    const double r = block_sum(bits, sm);
+    if (threadIdx.x == 0 && partial) partial[blockIdx.x] = r;
+}
+
+extern "C" int vc_eb_forward(vc_stream s, vc_view z, const float *params, const float *in_gain, const float *out_gain,
+                             vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots)
+{
+    if (!z.p || !params) return VC_EINVAL;
+    if (bits_partial && bits_slots != ENT_SLOTS) return VC_EINVAL;
+    hipLaunchKernelGGL(k_eb_forward, dim3(ENT_SLOTS), dim3(ENT_BLOCK), 0, as_stream(s), z, params, in_gain, out_gain,
+                       z_hat, symbols, bits_partial);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_eb_dequant(const int32_t *__restrict__ symbols, const float *__restrict__ params,
+                             const float *__restrict__ out_gain, vc_view zh)
+{
+    const long long total = (long long)zh.n * zh.h * zh.w * zh.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % zh.c);
+        long long t = i / zh.c;
+        const int x = (int)(t % zh.w); t /= zh.w;
+        const int y = (int)(t % zh.h);
+        const int n = (int)(t / zh.h);
+        const float med = params[(long long)c * VC_EB_PARAMS_PER_CHANNEL + 58];
+        const float v = (float)symbols[(((long long)n * zh.c + c) * zh.h + y) * zh.w + x] + med;
+        zh.p[view_off(zh, n, y, x) + c] = out_gain ? v * out_gain[c] : v;
+    }
+}
+
+extern "C" int vc_eb_dequant(vc_stream s, const int32_t *symbols, const float *params, const float *out_gain, vc_view z_hat)
+{
+    if (!symbols || !params || !z_hat.p) return VC_EINVAL;
+    const long long total = (long long)z_hat.n * z_hat.h * z_hat.w * z_hat.c;
+    hipLaunchKernelGGL(k_eb_dequant, dim3(ew_grid(total, ENT_BLOCK)), dim3(ENT_BLOCK), 0, as_stream(s), symbols, params, out_gain, z_hat);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__device__ __forceinline__ int scale_index(float s, const float *__restrict__ table, int n_scales)
+{
+    // build_indexes: (n_scales-1) - #{t in table[:-1] : s <= t}; table is ascending, so count from the top
+    int idx = n_scales - 1;
+    for (int k = 0; k < n_scales - 1; ++k) idx -= (s <= table[k]) ? 1 : 0;
+    return idx;
+}
+
+__global__ void __launch_bounds__(ENT_BLOCK) k_gc_forward(vc_view yv, vc_view sc, vc_view mu, const float *__restrict__ in_gain,
+                                                          const float *__restrict__ out_gain, vc_view yh,
+                                                          double *__restrict__ partial, const float *__restrict__ sym_src,
+                                                          int32_t *__restrict__ symbols, int32_t *__restrict__ indexes,
+                                                          const float *__restrict__ table, int n_scales)
+{
+    __shared__ double sm[ENT_BLOCK / 64];
+    double bits = 0.0;
+    const float kc = -0.70710678118654752440f;  // float(-(2 ** -0.5))
+    const long long total = (long long)yv.n * yv.h * yv.w * yv.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % yv.c);
+        long long t = i / yv.c;
+        const int x = (int)(t % yv.w); t /= yv.w;
+        const int y = (int)(t % yv.h);
+        const int n = (int)(t / yv.h);
+        const long long oy = view_off(yv, n, y, x) + c;
+        float v = yv.p[oy];
+        if (in_gain) v *= in_gain[c];
+        const float m = mu.p[view_off(mu, n, y, x) + c];
+        float s = sc.p[view_off(sc, n, y, x) + c];
+        s = fmaxf(s, 0.11f);                          // lower_bound_scale
+        const float q = rintf(v - m);
+        const float yq = q + m;
+        const float a = fabsf(yq - m);                // the reference subtracts the mean again
+        const float upper = 0.5f * erfcf(kc * ((0.5f - a) / s));
+        const float lower = 0.5f * erfcf(kc * ((-0.5f - a) / s));
+        const float lik = fmaxf(upper - lower, 1e-9f);
+        bits -= (double)log2f(lik);
+        if (yh.p) yh.p[view_off(yh, n, y, x) + c] = out_gain ? yq * out_gain[c] : yq;
+        if (symbols) {
+            const long long o = (((long long)n * yv.c + c) * yv.h + y) * yv.w + x;
+            symbols[o] = sym_src ? (int32_t)rintf(sym_src[oy] - m) : (int32_t)q;
+            indexes[o] = scale_index(s, table, n_scales);
+        }
+    }
+    const double r = block_sum(bits, sm);
+    if (threadIdx.x == 0 && partial) partial[blockIdx.x] = r;
+}
+
+extern "C" int vc_gc_forward(vc_stream s, vc_view y, vc_view scales, vc_view means, const float *in_gain,
+                             const float *out_gain, vc_view y_hat, double *bits_partial, int bits_slots,
+                             const float *sym_src_p, int32_t *symbols, int32_t *indexes, const float *scale_table,
+                             int n_scales)
+{
+    if (!y.p || !scales.p || !means.p) return VC_EINVAL;
+    if (bits_partial && bits_slots != ENT_SLOTS) return VC_EINVAL;
+    if (symbols && (!indexes || !scale_table || n_scales < 2)) return VC_EINVAL;
+    hipLaunchKernelGGL(k_gc_forward, dim3(ENT_SLOTS), dim3(ENT_BLOCK), 0, as_stream(s), y, scales, means, in_gain, out_gain,
+                       y_hat, bits_partial, sym_src_p, symbols, indexes, scale_table, n_scales);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_gc_indexes(vc_view sc, const float *__restrict__ table, int n_scales, int32_t *__restrict__ indexes)
+{
+    const long long total = (long long)sc.n * sc.h * sc.w * sc.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % sc.c);
+        long long t = i / sc.c;
+        const int x = (int)(t % sc.w); t /= sc.w;
+        const int y = (int)(t % sc.h);
+        const int n = (int)(t / sc.h);
+        const float s = fmaxf(sc.p[view_off(sc, n, y, x) + c], 0.11f);
+        indexes[(((long long)n * sc.c + c) * sc.h + y) * sc.w + x] = scale_index(s, table, n_scales);
+    }
+}
+
+extern "C" int vc_gc_indexes(vc_stream s, vc_view scales, const float *scale_table, int n_scales, int32_t *indexes)
+{
+    if (!scales.p || !scale_table || !indexes || n_scales < 2) return VC_EINVAL;
+    const long long total = (long long)scales.n * scales.h * scales.w * scales.c;
+    hipLaunchKernelGGL(k_gc_indexes, dim3(ew_grid(total, ENT_BLOCK)), dim3(ENT_BLOCK), 0, as_stream(s), scales, scale_table, n_scales, indexes);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_gc_dequant(const int32_t *__restrict__ symbols, vc_view mu, const float *__restrict__ out_gain, vc_view yh)
+{
+    const long long total = (long long)yh.n * yh.h * yh.w * yh.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % yh.c);
+        long long t = i / yh.c;
+        const int x = (int)(t % yh.w); t /= yh.w;
+        const int y = (int)(t % yh.h);
+        const int n = (int)(t / yh.h);
+        const float v = (float)symbols[(((long long)n * yh.c + c) * yh.h + y) * yh.w + x] + mu.p[view_off(mu, n, y, x) + c];
+        yh.p[view_off(yh, n, y, x) + c] = out_gain ? v * out_gain[c] : v;
+    }
+}
+
+extern "C" int vc_gc_dequant(vc_stream s, const int32_t *symbols, vc_view means, const float *out_gain, vc_view y_hat)
+{
+    if (!symbols || !means.p || !y_hat.p) return VC_EINVAL;
+    const long long total = (long long)y_hat.n * y_hat.h * y_hat.w * y_hat.c;
+    hipLaunchKernelGGL(k_gc_dequant, dim3(ew_grid(total, ENT_BLOCK)), dim3(ENT_BLOCK), 0, as_stream(s), symbols, means, out_gain, y_hat);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_bits_reduce(const double *__restrict__ partial, int slots, double *__restrict__ out)
+{
+    __shared__ double sm[ENT_BLOCK / 64];
+    double v = 0.0;
+    for (int j = threadIdx.x; j < slots; j += blockDim.x) v += partial[(long long)blockIdx.x * slots + j];
+    const double r = block_sum(v, sm);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
+extern "C" int vc_bits_reduce(vc_stream s, const double *partial, int slots, int count, double *out)
+{
+    if (!partial || !out || slots < 1 || count < 1) return VC_EINVAL;
+    hipLaunchKernelGGL(k_bits_reduce, dim3(count), dim3(ENT_BLOCK), 0, as_stream(s), partial, slots, out);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}

@@ -1,0 +1,458 @@
+// HBM-bound kernels of the hot path: layout conversion, pooling, bilinear resampling, warping,
+// blending.  All tensors are fp32 channels-last views (vc_view); channel is the fastest thread index
+// so that a wave's accesses are contiguous.  Arithmetic follows the PyTorch operators the reference
+// calls (same formulas, same association where it is documented) -- see include/vc_hip.h for the
+// reference call sites each entry point replaces.
+#include "common.h"
+
+#define EW_BLOCK 256
+
+// ------------------------------------------------------------------------------------------------
+// layout conversion
+// ------------------------------------------------------------------------------------------------
+__global__ void k_nchw_to_nhwc(const float *__restrict__ src, vc_view d)
+{
+    const long long total = (long long)d.n * d.h * d.w * d.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d.c);
+        long long t = i / d.c;
+        const int x = (int)(t % d.w); t /= d.w;
+        const int y = (int)(t % d.h);
+        const int n = (int)(t / d.h);
+        d.p[view_off(d, n, y, x) + c] = src[(((long long)n * d.c + c) * d.h + y) * d.w + x];
+    }
+}
+
+__global__ void k_nhwc_to_nchw(vc_view s, float *__restrict__ dst)
+{
+    const long long total = (long long)s.n * s.h * s.w * s.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % s.w);
+        long long t = i / s.w;
+        const int y = (int)(t % s.h); t /= s.h;
+        const int c = (int)(t % s.c);
+        const int n = (int)(t / s.c);
+        dst[i] = s.p[view_off(s, n, y, x) + c];
+    }
+}
+
+extern "C" int vc_nchw_to_nhwc(vc_stream s, const float *src, vc_view dst)
+{
+    if (!src || !dst.p) return VC_EINVAL;
+    const long long total = (long long)dst.n * dst.h * dst.w * dst.c;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), src, dst);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+extern "C" int vc_nhwc_to_nchw(vc_stream s, vc_view src, float *dst)
+{
+    if (!src.p || !dst) return VC_EINVAL;
+    const long long total = (long long)src.n * src.h * src.w * src.c;
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), src, dst);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling
+// ------------------------------------------------------------------------------------------------
+__global__ void k_avgpool_reflectpad(vc_view in, vc_view out, int k, float scale)
+{
+    const int hp = in.h / k, wp = in.w / k;  // pooled size before padding
+    const float inv = 1.0f / (float)(k * k);
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        const int py = y < hp ? y : 2 * (hp - 1) - y;  // ReflectionPad2d bottom/right
+        const int px = x < wp ? x : 2 * (wp - 1) - x;
+        float sum = 0.0f;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) sum += in.p[view_off(in, n, py * k + dy, px * k + dx) + c];
+        out.p[view_off(out, n, y, x) + c] = sum * inv * scale;
+    }
+}
+
+extern "C" int vc_avgpool_reflectpad(vc_stream s, vc_view in, vc_view out, int k, float scale)
+{
+    if (!in.p || !out.p || k < 1 || in.c != out.c || in.n != out.n) return VC_EINVAL;
+    const int hp = in.h / k, wp = in.w / k;
+    if (out.h < hp || out.w < wp || out.h - hp >= hp || out.w - wp >= wp) return VC_EINVAL;  // reflect needs pad < size
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_avgpool_reflectpad, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out, k, scale);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_maxpool2(vc_view in, vc_view out)
+{
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        const float *p = in.p + view_off(in, n, 2 * y, 2 * x) + c;
+        const float a = fmaxf(p[0], p[in.sw]);
+        const float b = fmaxf(p[in.sh], p[in.sh + in.sw]);
+        out.p[view_off(out, n, y, x) + c] = fmaxf(a, b);
+    }
+}
+
+extern "C" int vc_maxpool2(vc_stream s, vc_view in, vc_view out)
+{
+    if (!in.p || !out.p || in.c != out.c || in.n != out.n || out.h != in.h / 2 || out.w != in.w / 2) return VC_EINVAL;
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_maxpool2, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear up-sampling (ATen upsample_bilinear2d source-index rule)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilinear_src(int dst, int in_size, int out_size, int factor, int align_corners,
+                                             int &i0, int &i1, float &l0, float &l1)
+{
+    float src;
+    if (align_corners) {
+        const float sc = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
+        src = sc * (float)dst;
+    } else {
+        const float sc = 1.0f / (float)factor;
+        src = sc * ((float)dst + 0.5f) - 0.5f;
+        if (src < 0.0f) src = 0.0f;
+    }
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ void k_upsample_bilinear(vc_view in, vc_view out, int factor, int align_corners, float scale)
+{
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        bilinear_src(y, in.h, out.h, factor, align_corners, y0, y1, ly0, ly1);
+        bilinear_src(x, in.w, out.w, factor, align_corners, x0, x1, lx0, lx1);
+        const float *b = in.p + (long long)n * in.sn + c;
+        const float v00 = b[(long long)y0 * in.sh + (long long)x0 * in.sw], v01 = b[(long long)y0 * in.sh + (long long)x1 * in.sw];
+        const float v10 = b[(long long)y1 * in.sh + (long long)x0 * in.sw], v11 = b[(long long)y1 * in.sh + (long long)x1 * in.sw];
+        const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        out.p[view_off(out, n, y, x) + c] = v * scale;
+    }
+}
+
+extern "C" int vc_upsample_bilinear(vc_stream s, vc_view in, vc_view out, int factor, int align_corners, float scale)
+{
+    if (!in.p || !out.p || factor < 1 || in.c != out.c || in.n != out.n) return VC_EINVAL;
+    if (out.h != in.h * factor || out.w != in.w * factor) return VC_EINVAL;
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_upsample_bilinear, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out,
+                       factor, align_corners, scale);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = alpha*a + beta*b
+// ------------------------------------------------------------------------------------------------
+__global__ void k_axpby(vc_view a, vc_view b, vc_view out, float alpha, float beta)
+{
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        float v = alpha * a.p[view_off(a, n, y, x) + c];
+        if (b.p) v += beta * b.p[view_off(b, n, y, x) + c];
+        out.p[view_off(out, n, y, x) + c] = v;
+    }
+}
+
+extern "C" int vc_axpby(vc_stream s, vc_view a, vc_view b, vc_view out, float alpha, float beta)
+{
+    if (!a.p || !out.p) return VC_EINVAL;
+    if (a.h < out.h || a.w < out.w || a.c < out.c || a.n != out.n) return VC_EINVAL;
+    if (b.p && (b.h < out.h || b.w < out.w || b.c < out.c || b.n != out.n)) return VC_EINVAL;
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_axpby, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, b, out, alpha, beta);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_channel_scale(vc_view a, const float *__restrict__ gain, vc_view out)
+{
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        out.p[view_off(out, n, y, x) + c] = gain[c] * a.p[view_off(a, n, y, x) + c];
+    }
+}
+
+extern "C" int vc_channel_scale(vc_stream s, vc_view a, const float *gain, vc_view out)
+{
+    if (!a.p || !gain || !out.p || a.c < out.c || a.h < out.h || a.w < out.w || a.n != out.n) return VC_EINVAL;
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_channel_scale, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, gain, out);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// warping: torch.grid_sample(bilinear, align_corners=False) behind the reference's two grid recipes
+// ------------------------------------------------------------------------------------------------
+// torch.linspace(start, end, steps)[i] in fp32 (symmetric evaluation from both ends)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i)
+{
+    if (steps == 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+// normalised grid coordinate of output pixel `i` displaced by `d` pixels
+__device__ __forceinline__ float grid_coord(int convention, int i, float d, int size_flow, int size_img)
+{
+    if (convention == VC_WARP_W1) {
+        const float inv = 1.0f / (float)size_flow;
+        const float g = linspace_at(-1.0f + inv, 1.0f - inv, size_flow, i);
+        return g + d / (((float)size_img - 1.0f) / 2.0f);
+    }
+    const float x = (float)i + d;                      // W2: b_model.py:104-109
+    return 2.0f * (x / (float)size_img - 0.5f);
+}
+
+__device__ __forceinline__ float sample_bilinear(const float *img, long long sh, long long sw, int H, int W,
+                                                 float gx, float gy, bool border)
+{
+    float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;  // grid_sampler_unnormalize, align_corners=False
+    float iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    if (border) {
+        ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));
+        iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+    }
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float w = ix - xw, e = 1.0f - w, n = iy - yn, s_ = 1.0f - n;
+    const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
+    const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+    const float nw = (x0ok && y0ok) ? img[(long long)y0 * sh + (long long)x0 * sw] : 0.0f;
+    const float ne = (x1ok && y0ok) ? img[(long long)y0 * sh + (long long)x1 * sw] : 0.0f;
+    const float sw_ = (x0ok && y1ok) ? img[(long long)y1 * sh + (long long)x0 * sw] : 0.0f;
+    const float se = (x1ok && y1ok) ? img[(long long)y1 * sh + (long long)x1 * sw] : 0.0f;
+    return nw * (s_ * e) + ne * (s_ * w) + sw_ * (n * e) + se * (n * w);
+}
+
+__global__ void k_warp(int convention, vc_view img, vc_view flow, vc_view out)
+{
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        const float *f = flow.p + view_off(flow, n, y, x);
+        const float gx = grid_coord(convention, x, f[0], flow.w, img.w);
+        const float gy = grid_coord(convention, y, f[1], flow.h, img.h);
+        out.p[view_off(out, n, y, x) + c] =
+            sample_bilinear(img.p + (long long)n * img.sn + c, img.sh, img.sw, img.h, img.w, gx, gy, convention == VC_WARP_W1);
+    }
+}
+
+extern "C" int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, vc_view out)
+{
+    if (!img.p || !flow.p || !out.p) return VC_EINVAL;
+    if (convention != VC_WARP_W1 && convention != VC_WARP_W2) return VC_EINVAL;
+    if (flow.c < 2 || out.c > img.c || out.h != flow.h || out.w != flow.w || img.n != out.n || flow.n != out.n) return VC_EINVAL;
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_warp, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SPyNet glue
+// ------------------------------------------------------------------------------------------------
+__global__ void k_spynet_preprocess(const float *__restrict__ src, vc_view d)
+{
+    const long long total = (long long)d.n * d.h * d.w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % d.w);
+        long long t = i / d.w;
+        const int y = (int)(t % d.h);
+        const int n = (int)(t / d.h);
+        const long long plane = (long long)d.h * d.w;
+        const float *s0 = src + (long long)n * 3 * plane + (long long)y * d.w + x;
+        // flow.py:40-44: input channel 0 takes the "blue" statistics and is emitted LAST
+        const float c0 = (s0[0] - 0.406f) / 0.225f;
+        const float c1 = (s0[plane] - 0.456f) / 0.224f;
+        const float c2 = (s0[2 * plane] - 0.485f) / 0.229f;
+        float *o = d.p + view_off(d, n, y, x);
+        o[0] = c2; o[1] = c1; o[2] = c0;
+    }
+}
+
+extern "C" int vc_spynet_preprocess(vc_stream s, const float *src, vc_view dst)
+{
+    if (!src || !dst.p || dst.c != 3) return VC_EINVAL;
+    const long long total = (long long)dst.n * dst.h * dst.w;
+    hipLaunchKernelGGL(k_spynet_preprocess, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), src, dst);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_spynet_level_input(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
+{
+    const long long total = (long long)feat.n * feat.h * feat.w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % feat.w);
+        long long t = i / feat.w;
+        const int y = (int)(t % feat.h);
+        const int n = (int)(t / feat.h);
+        float u = 0.0f, v = 0.0f;
+        if (fc.p) {
+            // F.interpolate(x2, bilinear, align_corners=True) * 2, then replicate-pad one row/col when
+            // the level is odd-sized (flow.py:93-96): clamp the destination index into the x2 grid.
+            const int uh = 2 * fc.h, uw = 2 * fc.w;
+            const int yy = y < uh ? y : uh - 1, xx = x < uw ? x : uw - 1;
+            int y0, y1, x0, x1;
+            float ly0, ly1, lx0, lx1;
+            bilinear_src(yy, fc.h, uh, 2, 1, y0, y1, ly0, ly1);
+            bilinear_src(xx, fc.w, uw, 2, 1, x0, x1, lx0, lx1);
+            const float *b = fc.p + (long long)n * fc.sn;
+            const float *p00 = b + (long long)y0 * fc.sh + (long long)x0 * fc.sw, *p01 = b + (long long)y0 * fc.sh + (long long)x1 * fc.sw;
+            const float *p10 = b + (long long)y1 * fc.sh + (long long)x0 * fc.sw, *p11 = b + (long long)y1 * fc.sh + (long long)x1 * fc.sw;
+            u = (ly0 * (lx0 * p00[0] + lx1 * p01[0]) + ly1 * (lx0 * p10[0] + lx1 * p11[0])) * 2.0f;
+            v = (ly0 * (lx0 * p00[1] + lx1 * p01[1]) + ly1 * (lx0 * p10[1] + lx1 * p11[1])) * 2.0f;
+        }
+        const float gx = grid_coord(VC_WARP_W1, x, u, feat.w, second.w);
+        const float gy = grid_coord(VC_WARP_W1, y, v, feat.h, second.h);
+        const float *f1 = first.p + view_off(first, n, y, x);
+        const float *s2 = second.p + (long long)n * second.sn;
+        float *o = feat.p + view_off(feat, n, y, x);
+        o[0] = f1[0]; o[1] = f1[1]; o[2] = f1[2];
+        o[3] = sample_bilinear(s2 + 0, second.sh, second.sw, second.h, second.w, gx, gy, true);
+        o[4] = sample_bilinear(s2 + 1, second.sh, second.sw, second.h, second.w, gx, gy, true);
+        o[5] = sample_bilinear(s2 + 2, second.sh, second.sw, second.h, second.w, gx, gy, true);
+        o[6] = u; o[7] = v;
+        float *q = up.p + view_off(up, n, y, x);
+        q[0] = u; q[1] = v;
+    }
+}
+
+extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
+{
+    if (!first.p || !second.p || !feat.p || !up.p) return VC_EINVAL;
+    if (first.c != 3 || second.c != 3 || feat.c != 8 || up.c != 2) return VC_EINVAL;
+    if (first.h != feat.h || first.w != feat.w || second.h != feat.h || second.w != feat.w) return VC_EINVAL;
+    if (up.h != feat.h || up.w != feat.w) return VC_EINVAL;
+    if (fc.p && (fc.c != 2 || (2 * fc.h != feat.h && 2 * fc.h + 1 != feat.h) || (2 * fc.w != feat.w && 2 * fc.w + 1 != feat.w)))
+        return VC_EINVAL;
+    const long long total = (long long)feat.n * feat.h * feat.w;
+    hipLaunchKernelGGL(k_spynet_level_input, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
+                       fc, feat, up);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// blending
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lhbdc_blend(vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid)
+{
+    const long long total = (long long)pred.n * pred.h * pred.w * 3;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        long long t = i / 3;
+        const int x = (int)(t % pred.w); t /= pred.w;
+        const int y = (int)(t % pred.h);
+        const int n = (int)(t / pred.h);
+        const float m = mask.p[view_off(mask, n, y, x)];
+        const float *f = fwbw.p + view_off(fwbw, n, y, x);
+        const float pv = m * f[c] + (1.0f - m) * f[3 + c];   // m.py:65
+        pred.p[view_off(pred, n, y, x) + c] = pv;
+        if (resid.p) resid.p[view_off(resid, n, y, x) + c] = cur.p[view_off(cur, n, y, x) + c] - pv;
+    }
+}
+
+extern "C" int vc_lhbdc_blend(vc_stream s, vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid)
+{
+    if (!fwbw.p || !mask.p || !pred.p || fwbw.c < 6 || pred.c != 3) return VC_EINVAL;
+    if (resid.p && !cur.p) return VC_EINVAL;
+    const long long total = (long long)pred.n * pred.h * pred.w * 3;
+    hipLaunchKernelGGL(k_lhbdc_blend, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), fwbw, mask, cur, pred, resid);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_flex_blend(vc_view xb, vc_view xa, vc_view mask, vc_view cur, vc_view pred, vc_view resid)
+{
+    const long long total = (long long)pred.n * pred.h * pred.w * 3;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        long long t = i / 3;
+        const int x = (int)(t % pred.w); t /= pred.w;
+        const int y = (int)(t % pred.h);
+        const int n = (int)(t / pred.h);
+        const float *m = mask.p + view_off(mask, n, y, x);
+        const float w1 = 0.5f * m[0], w2 = 0.5f * m[1];    // b_model.py:70-71
+        const float pv = (w1 * xb.p[view_off(xb, n, y, x) + c] + w2 * xa.p[view_off(xa, n, y, x) + c]) / (w1 + w2 + 1e-8f);
+        pred.p[view_off(pred, n, y, x) + c] = pv;
+        if (resid.p) resid.p[view_off(resid, n, y, x) + c] = cur.p[view_off(cur, n, y, x) + c] - pv;
+    }
+}
+
+extern "C" int vc_flex_blend(vc_stream s, vc_view xb, vc_view xa, vc_view mask, vc_view cur, vc_view pred, vc_view resid)
+{
+    if (!xb.p || !xa.p || !mask.p || !pred.p || mask.c < 2 || pred.c != 3) return VC_EINVAL;
+    if (resid.p && !cur.p) return VC_EINVAL;
+    const long long total = (long long)pred.n * pred.h * pred.w * 3;
+    hipLaunchKernelGGL(k_flex_blend, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), xb, xa, mask, cur, pred, resid);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+__global__ void k_flex_motion_split(vc_view f4, vc_view ft0, vc_view ft1, float t)
+{
+    const long long total = (long long)f4.n * f4.h * f4.w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % f4.w);
+        long long q = i / f4.w;
+        const int y = (int)(q % f4.h);
+        const int n = (int)(q / f4.h);
+        const float *f = f4.p + view_off(f4, n, y, x);
+        float *a = ft0.p + view_off(ft0, n, y, x), *b = ft1.p + view_off(ft1, n, y, x);
+        // b_model.py:39-40 with the same association:  -(1-t)*t*F01 + t*t*F10 ;  (1-t)*(1-t)*F01 - t*(1-t)*F10
+        const float k0 = -(1.0f - t) * t, k1 = t * t, k2 = (1.0f - t) * (1.0f - t), k3 = t * (1.0f - t);
+        a[0] = k0 * f[0] + k1 * f[2]; a[1] = k0 * f[1] + k1 * f[3];
+        b[0] = k2 * f[0] - k3 * f[2]; b[1] = k2 * f[1] - k3 * f[3];
+    }
+}
+
+extern "C" int vc_flex_motion_split(vc_stream s, vc_view f4, vc_view ft0, vc_view ft1, float t)
+{
+    if (!f4.p || !ft0.p || !ft1.p || f4.c < 4) return VC_EINVAL;
+    const long long total = (long long)f4.n * f4.h * f4.w;
+    hipLaunchKernelGGL(k_flex_motion_split, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), f4, ft0, ft1, t);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}

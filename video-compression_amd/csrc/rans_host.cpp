@@ -1,0 +1,191 @@
+// Host range coder of the product: rans64 (32-bit word renormalisation, L = 2^31), 16-bit table
+// probabilities, 4-bit bypass escape -- the bitstream format of CompressAI's ans module that the
+// reference reaches through EntropyModel.compress/decompress (LHBDC/model/layers.py:97-112).
+//
+// The state machine is inherently serial, so it runs on a host core while the GPU produces the next
+// frame's symbols.  Unlike the queue-then-flush formulation, the encoder walks the symbols once,
+// backwards, expanding escapes in reverse on the fly and writing 32-bit words from the end of the
+// caller's buffer -- no intermediate symbol queue, no allocation.
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#include "vc_hip.h"
+
+namespace {
+constexpr uint32_t kProbBits = 16;
+constexpr uint32_t kBypassBits = 4;
+constexpr uint32_t kBypassMax = (1u << kBypassBits) - 1u;
+constexpr uint64_t kLow = 1ull << 31;
+
+struct Encoder {
+    uint64_t x = kLow;
+    uint32_t *p;      // next free word (grows downwards)
+    uint32_t *floor;  // lowest legal address
+    bool overflow = false;
+
+    inline void emit()
+    {
+        if (p == floor) { overflow = true; return; }
+        *--p = static_cast<uint32_t>(x);
+        x >>= 32;
+    }
+    inline void put(uint32_t start, uint32_t range)
+    {
+        const uint64_t lim = ((kLow >> kProbBits) << 32) * range;
+        if (x >= lim) emit();
+        x = ((x / range) << kProbBits) + (x % range) + start;
+    }
+    inline void put_nibble(uint32_t v)
+    {
+        const uint64_t lim = ((kLow >> 16) << 32) * static_cast<uint64_t>(1u << (16 - kBypassBits));
+        if (x >= lim) emit();
+        x = (x << kBypassBits) | v;
+    }
+};
+}  // namespace
+
+extern "C" size_t vc_rans_bound(size_t count) { return 4 * (2 * count + 4); }
+
+extern "C" long long vc_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes, size_t count,
+                                                 const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                                 const int32_t *offsets, uint8_t *out, size_t out_cap)
+{
+    if ((count && (!symbols || !indexes)) || !cdfs || !cdf_sizes || !offsets || !out || out_cap < 8) return VC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(out) % 4) return VC_EINVAL;
+    const size_t cap_words = out_cap / 4;
+    uint32_t *base = reinterpret_cast<uint32_t *>(out);
+    Encoder enc;
+    enc.p = base + cap_words;
+    enc.floor = base + 2;  // keep room for the final flush
+    for (size_t i = count; i-- > 0;) {
+        const int32_t t = indexes[i];
+        const int32_t *cdf = cdfs + static_cast<size_t>(t) * cdf_stride;
+        const int32_t escape = cdf_sizes[t] - 2;
+        int32_t v = symbols[i] - offsets[t];
+        if (v >= 0 && v < escape) {
+            enc.put(static_cast<uint32_t>(cdf[v]), static_cast<uint32_t>(cdf[v + 1] - cdf[v]));
+            continue;
+        }
+        // out-of-table value: sign/magnitude folded into `raw`, sent as nibbles after the escape bin
+        const uint32_t raw = v < 0 ? static_cast<uint32_t>(-2 * v - 1) : static_cast<uint32_t>(2 * (v - escape));
+        int32_t nibbles = 0;
+        while (nibbles < 8 && (raw >> (nibbles * kBypassBits)) != 0) ++nibbles;
+        for (int32_t j = nibbles - 1; j >= 0; --j) enc.put_nibble((raw >> (j * kBypassBits)) & kBypassMax);
+        // nibble count in base-15 "unary" chunks; forward order is 15,15,...,rest -> reverse: rest first
+        enc.put_nibble(static_cast<uint32_t>(nibbles) % kBypassMax);
+        for (int32_t c = nibbles / static_cast<int32_t>(kBypassMax); c > 0; --c) enc.put_nibble(kBypassMax);
+        enc.put(static_cast<uint32_t>(cdf[escape]), static_cast<uint32_t>(cdf[escape + 1] - cdf[escape]));
+    }
+    if (enc.overflow) return VC_ENOMEM;
+    enc.p -= 2;
+    enc.p[0] = static_cast<uint32_t>(enc.x);
+    enc.p[1] = static_cast<uint32_t>(enc.x >> 32);
+    const size_t nbytes = static_cast<size_t>((base + cap_words) - enc.p) * 4;
+    std::memmove(out, enc.p, nbytes);
+    return static_cast<long long>(nbytes);
+}
+
+extern "C" int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, const int32_t *indexes, size_t count,
+                                           const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                           const int32_t *offsets, int32_t *out)
+{
+    if (!data || nbytes < 8 || (nbytes % 4) || (count && (!indexes || !out)) || !cdfs || !cdf_sizes || !offsets) return VC_EINVAL;
+    const size_t nwords = nbytes / 4;
+    size_t pos = 0;
+    auto next_word = [&](uint32_t &w) -> bool {
+        if (pos >= nwords) return false;
+        std::memcpy(&w, data + 4 * pos, 4);
+        ++pos;
+        return true;
+    };
+    uint32_t lo, hi;
+    next_word(lo);
+    next_word(hi);
+    uint64_t x = static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+    bool bad = false;
+    auto refill = [&]() {
+        if (x < kLow) {
+            uint32_t w = 0;
+            if (!next_word(w)) bad = true;
+            x = (x << 32) | w;
+        }
+    };
+    auto nibble = [&]() -> int32_t {
+        const int32_t v = static_cast<int32_t>(x & kBypassMax);
+        x >>= kBypassBits;
+        refill();
+        return v;
+    };
+    for (size_t i = 0; i < count; ++i) {
+        const int32_t t = indexes[i];
+        const int32_t *cdf = cdfs + static_cast<size_t>(t) * cdf_stride;
+        const int32_t n = cdf_sizes[t], escape = n - 2;
+        const uint32_t cum = static_cast<uint32_t>(x & 0xFFFFu);
+        // tables are short for the frequent (small-scale) contexts: linear scan like the format's reference
+        // decoder, switched to bisection for the long ones
+        int32_t sidx;
+        if (n <= 32) {
+            int32_t j = 1;
+            while (j < n && static_cast<uint32_t>(cdf[j]) <= cum) ++j;
+            sidx = j - 1;
+        } else {
+            int32_t lo_i = 0, hi_i = n - 1;  // invariant: cdf[lo_i] <= cum < cdf[hi_i]
+            while (hi_i - lo_i > 1) {
+                const int32_t mid = (lo_i + hi_i) >> 1;
+                if (static_cast<uint32_t>(cdf[mid]) <= cum) lo_i = mid; else hi_i = mid;
+            }
+            sidx = lo_i;
+        }
+        const uint32_t start = static_cast<uint32_t>(cdf[sidx]);
+        const uint32_t range = static_cast<uint32_t>(cdf[sidx + 1]) - start;
+        x = static_cast<uint64_t>(range) * (x >> kProbBits) + (x & 0xFFFFu) - start;
+        refill();
+        int32_t v = sidx;
+        if (v == escape) {
+            int32_t got = nibble(), nibbles = got;
+            while (got == static_cast<int32_t>(kBypassMax)) {
+                got = nibble();
+                nibbles += got;
+                if (bad) break;
+            }
+            if (nibbles > 8) return VC_EDATA;
+            int32_t raw = 0;
+            for (int32_t k = 0; k < nibbles; ++k) raw |= nibble() << (k * kBypassBits);
+            v = static_cast<int32_t>(static_cast<uint32_t>(raw) >> 1);
+            if (raw & 1) v = -v - 1; else v += escape;
+        }
+        if (bad) return VC_EDATA;
+        out[i] = v + offsets[t];
+    }
+    return VC_OK;
+}
+
+extern "C" int vc_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf)
+{
+    if (!pmf || !cdf || n < 1 || precision != 16) return VC_EINVAL;
+    const uint32_t one = 1u << precision;
+    std::vector<uint32_t> freq(static_cast<size_t>(n) + 1, 0u);
+    for (int i = 0; i < n; ++i) freq[i + 1] = static_cast<uint32_t>(std::round(pmf[i] * static_cast<float>(one)));
+    const uint32_t total = std::accumulate(freq.begin(), freq.end(), 0u);
+    if (total == 0) return VC_EDATA;
+    for (auto &f : freq) f = static_cast<uint32_t>((static_cast<uint64_t>(one) * f) / total);
+    std::partial_sum(freq.begin(), freq.end(), cdf);
+    cdf[n] = one;
+    for (int i = 0; i < n; ++i) {
+        if (cdf[i] != cdf[i + 1]) continue;
+        uint32_t best = ~0u;
+        int donor = -1;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t f = cdf[j + 1] - cdf[j];
+            if (f > 1 && f < best) { best = f; donor = j; }
+        }
+        if (donor < 0) return VC_EDATA;
+        if (donor < i) for (int j = donor + 1; j <= i; ++j) --cdf[j];
+        else for (int j = i + 1; j <= donor; ++j) ++cdf[j];
+    }
+    return VC_OK;
+}
+
+extern "C" const char *vc_version(void) { return "vc_hip 0.1 (round 1)"; }
+extern "C" const char *vc_target_arch(void) { return "gfx950"; }

@@ -1,0 +1,315 @@
+"""ctypes binding of libvc_hip.so (C ABI declared in include/vc_hip.h).
+
+This is the only door to the compute path: there is NO CPU fallback.  If the library is missing the
+import of any model module fails loudly with instructions to build it.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libvc_hip.so")
+
+VC_OK = 0
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+EPI_NONE, EPI_GDN, EPI_IGDN = 0, 1, 2
+IN_NONE, IN_SQUARE = 0, 1
+OUT_PLAIN, OUT_PIXELSHUFFLE2 = 0, 1
+WARP_W1, WARP_W2 = 1, 2
+EB_PARAMS_PER_CHANNEL = 60
+
+_ERR = {-1: "VC_EINVAL (bad argument / unsupported shape)", -2: "VC_ELAUNCH (HIP launch failure)",
+        -3: "VC_ENOMEM", -4: "VC_EDATA (corrupt bitstream / degenerate pmf)"}
+
+
+class VcError(RuntimeError):
+    pass
+
+
+class View(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("n", ctypes.c_int), ("h", ctypes.c_int), ("w", ctypes.c_int),
+                ("c", ctypes.c_int), ("sn", ctypes.c_longlong), ("sh", ctypes.c_longlong),
+                ("sw", ctypes.c_longlong)]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [("inp", View), ("out", View), ("wpk", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("res", ctypes.c_void_p), ("res_sn", ctypes.c_longlong), ("res_sh", ctypes.c_longlong),
+                ("res_sw", ctypes.c_longlong),
+                ("mul", ctypes.c_void_p), ("mul_sn", ctypes.c_longlong), ("mul_sh", ctypes.c_longlong),
+                ("mul_sw", ctypes.c_longlong),
+                ("chscale", ctypes.c_void_p),
+                ("kh", ctypes.c_int), ("kw", ctypes.c_int), ("stride", ctypes.c_int),
+                ("act", ctypes.c_int), ("slope", ctypes.c_float),
+                ("epi", ctypes.c_int), ("in_xform", ctypes.c_int), ("out_mode", ctypes.c_int),
+                ("cfg", ctypes.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libvc_hip.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VcError(
+            f"{LIB_PATH} not found: the HIP extension is the only compute path (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C video-compression_amd/csrc`.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf, cll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+    sz = ctypes.c_size_t
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("vc_version", ctypes.c_char_p)
+    sig("vc_target_arch", ctypes.c_char_p)
+    sig("vc_conv_select_cfg", ci, ci, ci, ci, ci)
+    sig("vc_conv_chunk", ci, ci, ci, ci, ci)
+    sig("vc_conv_packed_weight_floats", sz, ci, ci, ci, ci, ci, ci)
+    sig("vc_conv_packed_bias_floats", sz, ci, ci)
+    sig("vc_conv_pack_weights", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp)
+    sig("vc_conv2d_nhwc", ci, vp, ctypes.POINTER(ConvDesc))
+    sig("vc_nchw_to_nhwc", ci, vp, vp, View)
+    sig("vc_nhwc_to_nchw", ci, vp, View, vp)
+    sig("vc_avgpool_reflectpad", ci, vp, View, View, ci, cf)
+    sig("vc_maxpool2", ci, vp, View, View)
+    sig("vc_upsample_bilinear", ci, vp, View, View, ci, ci, cf)
+    sig("vc_axpby", ci, vp, View, View, View, cf, cf)
+    sig("vc_channel_scale", ci, vp, View, vp, View)
+    sig("vc_warp", ci, vp, ci, View, View, View)
+    sig("vc_spynet_preprocess", ci, vp, vp, View)
+    sig("vc_spynet_level_input", ci, vp, View, View, View, View, View)
+    sig("vc_lhbdc_blend", ci, vp, View, View, View, View, View)
+    sig("vc_flex_blend", ci, vp, View, View, View, View, View, View)
+    sig("vc_flex_motion_split", ci, vp, View, View, View, cf)
+    sig("vc_eb_forward", ci, vp, View, vp, vp, vp, View, vp, vp, ci)
+    sig("vc_eb_dequant", ci, vp, vp, vp, vp, View)
+    sig("vc_gc_forward", ci, vp, View, View, View, vp, vp, View, vp, ci, vp, vp, vp, vp, ci)
+    sig("vc_gc_indexes", ci, vp, View, vp, ci, vp)
+    sig("vc_gc_dequant", ci, vp, vp, View, vp, View)
+    sig("vc_bits_reduce", ci, vp, vp, ci, ci, vp)
+    sig("vc_bits_slots", ci)
+    sig("vc_pmf_to_quantized_cdf", ci, vp, ci, ci, vp)
+    sig("vc_rans_bound", sz, sz)
+    sig("vc_rans_encode_with_indexes", cll, vp, vp, sz, vp, ci, vp, vp, vp, sz)
+    sig("vc_rans_decode_with_indexes", ci, vp, sz, vp, sz, vp, ci, vp, vp, vp)
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "vc_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
+    "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
+    "vc_nhwc_to_nchw", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_channel_scale", "vc_warp",
+    "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
+    "vc_flex_motion_split", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
+    "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
+    "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes",
+]
+
+
+def check(rc, what):
+    if rc != VC_OK:
+        raise VcError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def stream():
+    """The HIP stream torch is currently enqueuing on (so torch allocations and our kernels order)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------
+# device tensors: channels-last fp32 buffers addressed through views
+# ------------------------------------------------------------------------------------------------
+class T:
+    """A [n,h,w,c] fp32 channels-last window into a torch buffer (channel slice / crop = new T)."""
+
+    __slots__ = ("buf", "n", "h", "w", "c", "sn", "sh", "sw", "off")
+
+    def __init__(self, buf, n, h, w, c, sn, sh, sw, off=0):
+        self.buf, self.n, self.h, self.w, self.c = buf, n, h, w, c
+        self.sn, self.sh, self.sw, self.off = sn, sh, sw, off
+
+    @staticmethod
+    def empty(n, h, w, c, device):
+        buf = torch.empty(n * h * w * c, dtype=torch.float32, device=device)
+        return T(buf, n, h, w, c, h * w * c, w * c, c)
+
+    def channels(self, c0, c1):
+        return T(self.buf, self.n, self.h, self.w, c1 - c0, self.sn, self.sh, self.sw, self.off + c0)
+
+    def crop(self, h, w):
+        return T(self.buf, self.n, h, w, self.c, self.sn, self.sh, self.sw, self.off)
+
+    def images(self, n0, n1):
+        return T(self.buf, n1 - n0, self.h, self.w, self.c, self.sn, self.sh, self.sw, self.off + n0 * self.sn)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + 4 * self.off
+
+    def view(self):
+        return View(self.ptr, self.n, self.h, self.w, self.c, self.sn, self.sh, self.sw)
+
+    def to_nchw(self):
+        """Debug/inspection helper (torch indexing, not on the hot path)."""
+        full = self.buf[self.off:]
+        return torch.as_strided(full, (self.n, self.c, self.h, self.w), (self.sn, 1, self.sh, self.sw)).contiguous()
+
+
+NULL_VIEW = View(None, 0, 0, 0, 0, 0, 0, 0)
+
+
+def nchw_to_nhwc(x):
+    x = x.contiguous().float()
+    n, c, h, w = x.shape
+    out = T.empty(n, h, w, c, x.device)
+    check(lib().vc_nchw_to_nhwc(stream(), x.data_ptr(), out.view()), "vc_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(t):
+    out = torch.empty((t.n, t.c, t.h, t.w), dtype=torch.float32, device=t.buf.device)
+    check(lib().vc_nhwc_to_nchw(stream(), t.view(), out.data_ptr()), "vc_nhwc_to_nchw")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution
+# ------------------------------------------------------------------------------------------------
+class PackedConv:
+    """Weights of one nn.Conv2d re-laid out for the MFMA kernel (done once per model load)."""
+
+    def __init__(self, weight, bias, stride=1, pixelshuffle=False, device=None):
+        L = lib()
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        cout, cin, kh, kw = w.shape
+        self.cout, self.cin, self.k, self.stride, self.ps = cout, cin, kh, stride, bool(pixelshuffle)
+        self.cfg = L.vc_conv_select_cfg(cout, cin, kh, stride)
+        nw = L.vc_conv_packed_weight_floats(self.cfg, cout, cin, kh, kw, stride)
+        nb = L.vc_conv_packed_bias_floats(self.cfg, cout)
+        if nw == 0:
+            raise VcError(f"unsupported convolution {cout}x{cin}x{kh}x{kw} stride {stride}")
+        wpk = np.empty(nw, dtype=np.float32)
+        bpk = np.empty(nb, dtype=np.float32)
+        wnp = w.numpy()
+        bnp = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous().numpy()
+        check(L.vc_conv_pack_weights(wnp.ctypes.data, None if bnp is None else bnp.ctypes.data, cout, cin, kh, kw,
+                                     stride, self.cfg, int(self.ps), wpk.ctypes.data, bpk.ctypes.data),
+              "vc_conv_pack_weights")
+        self.wpk = torch.from_numpy(wpk).to(device)
+        self.bias = torch.from_numpy(bpk).to(device)
+
+    def out_shape(self, h, w):
+        k, s = self.k, self.stride
+        ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+        return (2 * ho, 2 * wo, self.cout // 4) if self.ps else (ho, wo, self.cout)
+
+    def __call__(self, x, out=None, act=ACT_NONE, slope=0.01, res=None, epi=EPI_NONE, mul=None,
+                 in_xform=IN_NONE, chscale=None):
+        ho, wo, co = self.out_shape(x.h, x.w)
+        if out is None:
+            out = T.empty(x.n, ho, wo, co, x.buf.device)
+        d = ConvDesc()
+        d.inp, d.out = x.view(), out.view()
+        d.wpk, d.bias = self.wpk.data_ptr(), self.bias.data_ptr()
+        if res is not None:
+            d.res, d.res_sn, d.res_sh, d.res_sw = res.ptr, res.sn, res.sh, res.sw
+        if mul is not None:
+            d.mul, d.mul_sn, d.mul_sh, d.mul_sw = mul.ptr, mul.sn, mul.sh, mul.sw
+        if chscale is not None:
+            d.chscale = chscale.data_ptr()
+        d.kh = d.kw = self.k
+        d.stride = self.stride
+        d.act, d.slope = act, slope
+        d.epi, d.in_xform = epi, in_xform
+        d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
+        d.cfg = self.cfg
+        check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# thin wrappers
+# ------------------------------------------------------------------------------------------------
+def avgpool_reflectpad(x, k, scale=1.0, out_h=None, out_w=None):
+    hp, wp = x.h // k, x.w // k
+    out = T.empty(x.n, out_h or hp, out_w or wp, x.c, x.buf.device)
+    check(lib().vc_avgpool_reflectpad(stream(), x.view(), out.view(), k, scale), "vc_avgpool_reflectpad")
+    return out
+
+
+def maxpool2(x):
+    out = T.empty(x.n, x.h // 2, x.w // 2, x.c, x.buf.device)
+    check(lib().vc_maxpool2(stream(), x.view(), out.view()), "vc_maxpool2")
+    return out
+
+
+def upsample_bilinear(x, factor, align_corners=False, scale=1.0, out=None):
+    if out is None:
+        out = T.empty(x.n, x.h * factor, x.w * factor, x.c, x.buf.device)
+    check(lib().vc_upsample_bilinear(stream(), x.view(), out.view(), factor, int(align_corners), scale),
+          "vc_upsample_bilinear")
+    return out
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out=None):
+    if out is None:
+        out = T.empty(a.n, a.h, a.w, a.c, a.buf.device)
+    check(lib().vc_axpby(stream(), a.view(), b.view() if b is not None else NULL_VIEW, out.view(), alpha, beta),
+          "vc_axpby")
+    return out
+
+
+def warp(convention, img, flow, out=None):
+    if out is None:
+        out = T.empty(img.n, flow.h, flow.w, img.c, img.buf.device)
+    check(lib().vc_warp(stream(), convention, img.view(), flow.view(), out.view()), "vc_warp")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# host range coder
+# ------------------------------------------------------------------------------------------------
+def pmf_to_quantized_cdf(pmf, precision=16):
+    p = np.ascontiguousarray(np.asarray(pmf, dtype=np.float32))
+    cdf = np.empty(p.size + 1, dtype=np.uint32)
+    check(lib().vc_pmf_to_quantized_cdf(p.ctypes.data, p.size, precision, cdf.ctypes.data), "vc_pmf_to_quantized_cdf")
+    return cdf
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def rans_encode(symbols, indexes, cdfs, cdf_sizes, offsets):
+    sym, idx = _i32(symbols).reshape(-1), _i32(indexes).reshape(-1)
+    cdfs = _i32(cdfs)
+    sizes, offs = _i32(cdf_sizes).reshape(-1), _i32(offsets).reshape(-1)
+    cap = lib().vc_rans_bound(sym.size)
+    out = np.empty(cap // 4, dtype=np.uint32)
+    n = lib().vc_rans_encode_with_indexes(sym.ctypes.data, idx.ctypes.data, sym.size, cdfs.ctypes.data,
+                                          cdfs.shape[1], sizes.ctypes.data, offs.ctypes.data, out.ctypes.data, cap)
+    if n < 0:
+        check(int(n), "vc_rans_encode_with_indexes")
+    return out.view(np.uint8)[:n].tobytes()
+
+
+def rans_decode(data, indexes, cdfs, cdf_sizes, offsets):
+    idx = _i32(indexes).reshape(-1)
+    cdfs = _i32(cdfs)
+    sizes, offs = _i32(cdf_sizes).reshape(-1), _i32(offsets).reshape(-1)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(idx.size, dtype=np.int32)
+    check(lib().vc_rans_decode_with_indexes(buf.ctypes.data, buf.size, idx.ctypes.data, idx.size, cdfs.ctypes.data,
+                                            cdfs.shape[1], sizes.ctypes.data, offs.ctypes.data, out.ctypes.data),
+          "vc_rans_decode_with_indexes")
+    return out

@@ -1,0 +1,518 @@
+"""Building blocks of the hyperprior codecs, executed on MI355X through libvc_hip.so.
+
+Host-side mirror of the CompressAI 1.1.8 module surface the reference builds on
+(``compressai.layers`` / ``entropy_models`` / ``models.MeanScaleHyperprior``; call sites
+LHBDC/model/layers.py:6-17,43-191 and Flex-Rate.../b_model/layers.py:76-305).  Every class keeps the
+attribute names of the original so that ``state_dict`` keys are identical and reference checkpoints load
+with ``strict=True``; the modules only HOLD parameters -- compute goes through the HIP kernels
+(``.run(T) -> T``), never through torch operators.
+"""
+import math
+
+import numpy as np
+import scipy.stats
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+from .hip import T
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter holders with CompressAI-compatible names
+# ------------------------------------------------------------------------------------------------
+class LowerBound(nn.Module):
+    def __init__(self, bound):
+        super().__init__()
+        self.register_buffer("bound", torch.Tensor([float(bound)]))
+
+
+class NonNegativeParametrizer(nn.Module):
+    def __init__(self, minimum=0.0, reparam_offset=2 ** -18):
+        super().__init__()
+        pedestal = float(reparam_offset) ** 2
+        self.register_buffer("pedestal", torch.Tensor([pedestal]))
+        self.lower_bound = LowerBound((float(minimum) + pedestal) ** 0.5)
+
+    def init(self, x):
+        return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
+
+    def resolve(self, p):
+        """effective (non-negative) parameter: max(p, bound)^2 - pedestal"""
+        return torch.max(p, self.lower_bound.bound) ** 2 - self.pedestal
+
+
+class _Prepared(nn.Module):
+    """Caches device-side packed weights; dropped whenever parameters are (re)loaded or moved."""
+
+    def __init__(self):
+        super().__init__()
+        self._packed = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._packed = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+
+def _dev(module):
+    return next(module.parameters()).device
+
+
+def pack_conv(conv, pixelshuffle=False):
+    return hip.PackedConv(conv.weight, conv.bias, stride=conv.stride[0], pixelshuffle=pixelshuffle,
+                          device=conv.weight.device)
+
+
+class GDN(_Prepared):
+    """y = x * rsqrt(beta + gamma @ x^2)  (inverse: * sqrt) as ONE 1x1 MFMA contraction on x^2 with the
+    normalisation, the multiply and the block's residual add fused into the epilogue."""
+
+    def __init__(self, in_channels, inverse=False, beta_min=1e-6, gamma_init=0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_reparam = NonNegativeParametrizer(minimum=beta_min)
+        self.beta = nn.Parameter(self.beta_reparam.init(torch.ones(in_channels)))
+        self.gamma_reparam = NonNegativeParametrizer()
+        self.gamma = nn.Parameter(self.gamma_reparam.init(gamma_init * torch.eye(in_channels)))
+
+    def run(self, x, res=None, out=None):
+        if self._packed is None:
+            with torch.no_grad():
+                c = self.beta.numel()
+                beta = self.beta_reparam.resolve(self.beta)
+                gamma = self.gamma_reparam.resolve(self.gamma).reshape(c, c, 1, 1)
+            self._packed = hip.PackedConv(gamma, beta, device=self.beta.device)
+        return self._packed(x, out=out, epi=hip.EPI_IGDN if self.inverse else hip.EPI_GDN, mul=x,
+                            in_xform=hip.IN_SQUARE, res=res)
+
+
+def conv3x3(in_ch, out_ch, stride=1):
+    return nn.Conv2d(in_ch, out_ch, kernel_size=3, stride=stride, padding=1)
+
+
+def conv1x1(in_ch, out_ch, stride=1):
+    return nn.Conv2d(in_ch, out_ch, kernel_size=1, stride=stride)
+
+
+def subpel_conv3x3(in_ch, out_ch, r=1):
+    return nn.Sequential(nn.Conv2d(in_ch, out_ch * r ** 2, kernel_size=3, padding=1), nn.PixelShuffle(r))
+
+
+class ResidualBlockWithStride(_Prepared):
+    def __init__(self, in_ch, out_ch, stride=2):
+        super().__init__()
+        self.conv1 = conv3x3(in_ch, out_ch, stride=stride)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv2 = conv3x3(out_ch, out_ch)
+        self.gdn = GDN(out_ch)
+        self.skip = conv1x1(in_ch, out_ch, stride=stride) if (stride != 1 or in_ch != out_ch) else None
+
+    def run(self, x):
+        if self._packed is None:
+            self._packed = (pack_conv(self.conv1), pack_conv(self.conv2),
+                            pack_conv(self.skip) if self.skip is not None else None)
+        c1, c2, sk = self._packed
+        t = c1(x, act=hip.ACT_LRELU, slope=0.01)
+        u = c2(t)
+        identity = x if sk is None else sk(x)
+        return self.gdn.run(u, res=identity)
+
+
+class ResidualBlockUpsample(_Prepared):
+    def __init__(self, in_ch, out_ch, upsample=2):
+        super().__init__()
+        self.subpel_conv = subpel_conv3x3(in_ch, out_ch, upsample)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv = conv3x3(out_ch, out_ch)
+        self.igdn = GDN(out_ch, inverse=True)
+        self.upsample = subpel_conv3x3(in_ch, out_ch, upsample)
+
+    def run(self, x):
+        if self._packed is None:
+            self._packed = (pack_conv(self.subpel_conv[0], pixelshuffle=True), pack_conv(self.conv),
+                            pack_conv(self.upsample[0], pixelshuffle=True))
+        sp, cv, up = self._packed
+        t = sp(x, act=hip.ACT_LRELU, slope=0.01)   # LeakyReLU commutes with the pixel shuffle
+        u = cv(t)
+        identity = up(x)
+        return self.igdn.run(u, res=identity)
+
+
+class ResidualBlock(_Prepared):
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv1 = conv3x3(in_ch, out_ch)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv2 = conv3x3(out_ch, out_ch)
+        self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
+
+    def run(self, x):
+        if self._packed is None:
+            self._packed = (pack_conv(self.conv1), pack_conv(self.conv2),
+                            pack_conv(self.skip) if self.skip is not None else None)
+        c1, c2, sk = self._packed
+        t = c1(x, act=hip.ACT_LRELU, slope=0.01)
+        identity = x if sk is None else sk(x)
+        return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity)
+
+
+def run_sequential(seq, x, cache, final_chscale=None):
+    """Execute an nn.Sequential of {Conv2d, subpel Sequential, LeakyReLU, Residual*} on the HIP path.
+    A LeakyReLU following a convolution is fused into that convolution's epilogue."""
+    mods = list(seq)
+    if cache.get("seq") is None:
+        cache["seq"] = {}
+    packed = cache["seq"]
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        last = i == len(mods) - 1
+        if isinstance(m, (ResidualBlock, ResidualBlockWithStride, ResidualBlockUpsample)):
+            x = m.run(x)
+            i += 1
+            continue
+        is_subpel = isinstance(m, nn.Sequential)
+        conv = m[0] if is_subpel else m
+        if not isinstance(conv, nn.Conv2d):
+            raise hip.VcError(f"unsupported layer in sequential: {type(m).__name__}")
+        key = id(conv)
+        if key not in packed:
+            packed[key] = pack_conv(conv, pixelshuffle=is_subpel)
+        act, slope = hip.ACT_NONE, 0.0
+        if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+            act, slope = hip.ACT_LRELU, mods[i + 1].negative_slope
+            i += 1
+            last = i == len(mods) - 1
+        x = packed[key](x, act=act, slope=slope, chscale=final_chscale if last else None)
+        i += 1
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# entropy models
+# ------------------------------------------------------------------------------------------------
+class EntropyModel(_Prepared):
+    def __init__(self, likelihood_bound=1e-9, entropy_coder_precision=16):
+        super().__init__()
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        self.use_likelihood_bound = likelihood_bound > 0
+        if self.use_likelihood_bound:
+            self.likelihood_lower_bound = LowerBound(likelihood_bound)
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+
+    def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
+        cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
+        for i, p in enumerate(pmf):
+            prob = torch.cat((p[: pmf_length[i]], tail_mass[i]), dim=0)
+            q = hip.pmf_to_quantized_cdf(prob.numpy(), self.entropy_coder_precision)
+            cdf[i, : q.size] = torch.from_numpy(q.astype(np.int32))
+        return cdf
+
+    def tables(self):
+        """host copies (numpy int32) of cdf / cdf_length / offset for the range coder"""
+        if self._offset.numel() == 0:
+            raise hip.VcError("entropy tables are empty: call update(force=True) after loading weights")
+        return (self._quantized_cdf.cpu().numpy().astype(np.int32), self._cdf_length.cpu().numpy().astype(np.int32),
+                self._offset.cpu().numpy().astype(np.int32))
+
+
+class EntropyBottleneck(EntropyModel):
+    def __init__(self, channels, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3), **kwargs):
+        super().__init__(**kwargs)
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        if self.filters != (3, 3, 3, 3):
+            raise hip.VcError("the fused factorised-prior kernel is specialised for filters=(3,3,3,3)")
+        widths = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / widths[i + 1]))
+            self.register_parameter(f"_matrix{i:d}", nn.Parameter(torch.full((channels, widths[i + 1], widths[i]), float(init))))
+            self.register_parameter(f"_bias{i:d}", nn.Parameter(torch.empty(channels, widths[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < len(self.filters):
+                self.register_parameter(f"_factor{i:d}", nn.Parameter(torch.zeros(channels, widths[i + 1], 1)))
+        self.quantiles = nn.Parameter(torch.Tensor([-self.init_scale, 0, self.init_scale]).repeat(channels, 1, 1))
+        target = np.log(2 / self.tail_mass - 1)
+        self.register_buffer("target", torch.Tensor([-target, 0, target]))
+
+    # -- host-side table construction (once per model load; CompressAI EntropyBottleneck.update) ----
+    def _logits_cumulative_host(self, inputs):
+        logits = inputs
+        for i in range(len(self.filters) + 1):
+            logits = torch.matmul(F.softplus(getattr(self, f"_matrix{i:d}").detach().cpu()), logits)
+            logits = logits + getattr(self, f"_bias{i:d}").detach().cpu()
+            if i < len(self.filters):
+                logits = logits + torch.tanh(getattr(self, f"_factor{i:d}").detach().cpu()) * torch.tanh(logits)
+        return logits
+
+    @torch.no_grad()
+    def update(self, force=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.quantiles.device
+        q = self.quantiles.detach().cpu()
+        medians = q[:, 0, 1]
+        minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+        pmf_start = medians - minima
+        pmf_length = maxima + minima + 1
+        max_length = int(pmf_length.max().item())
+        samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+        lower = self._logits_cumulative_host(samples - 0.5)
+        upper = self._logits_cumulative_host(samples + 0.5)
+        sign = -torch.sign(lower + upper)
+        pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+        tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
+        self._cdf_length = (pmf_length + 2).int().to(dev)
+        self._offset = (-minima).int().to(dev)
+        return True
+
+    def device_params(self):
+        """[C,60] fp32: softplus/tanh pre-resolved MLP + median, layout of VC_EB_PARAMS_PER_CHANNEL."""
+        if self._packed is None:
+            with torch.no_grad():
+                c = self.channels
+                parts = []
+                for i in range(5):
+                    parts.append(F.softplus(getattr(self, f"_matrix{i:d}").detach().cpu()).reshape(c, -1))
+                    parts.append(getattr(self, f"_bias{i:d}").detach().cpu().reshape(c, -1))
+                    if i < 4:
+                        parts.append(torch.tanh(getattr(self, f"_factor{i:d}").detach().cpu()).reshape(c, -1))
+                parts.append(self.quantiles.detach().cpu()[:, 0, 1].reshape(c, 1))
+                parts.append(torch.zeros(c, 1))
+                p = torch.cat(parts, dim=1).contiguous().float()
+                assert p.shape[1] == hip.EB_PARAMS_PER_CHANNEL
+            self._packed = p.to(self.quantiles.device)
+        return self._packed
+
+
+class GaussianConditional(EntropyModel):
+    def __init__(self, scale_table, scale_bound=0.11, tail_mass=1e-9, **kwargs):
+        super().__init__(**kwargs)
+        self.register_buffer("scale_table", torch.Tensor(tuple(float(s) for s in scale_table)) if scale_table else torch.Tensor())
+        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
+        self.tail_mass = float(tail_mass)
+        self.lower_bound_scale = LowerBound(scale_bound)
+
+    @torch.no_grad()
+    def update_scale_table(self, scale_table, force=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.scale_bound.device
+        self.scale_table = torch.Tensor(tuple(float(s) for s in scale_table)).to(dev)
+        self.update()
+        return True
+
+    @torch.no_grad()
+    def update(self):
+        dev = self.scale_bound.device
+        table = self.scale_table.detach().cpu()
+        multiplier = -scipy.stats.norm.ppf(self.tail_mass / 2)
+        pmf_center = torch.ceil(table * float(multiplier)).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = int(torch.max(pmf_length).item())
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+        scale = table.unsqueeze(1).float()
+        const = float(-(2 ** -0.5))
+        upper = 0.5 * torch.erfc(const * ((0.5 - samples) / scale))
+        lower = 0.5 * torch.erfc(const * ((-0.5 - samples) / scale))
+        pmf = upper - lower
+        tail_mass = 2 * lower[:, :1]
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
+        self._offset = (-pmf_center).int().to(dev)
+        self._cdf_length = (pmf_length + 2).int().to(dev)
+        self._packed = None
+
+
+def get_scale_table(lo=0.11, hi=256, levels=64):
+    return torch.exp(torch.linspace(math.log(lo), math.log(hi), levels))
+
+
+_CDF_BUFFERS = ("_quantized_cdf", "_offset", "_cdf_length")
+
+
+def _resize_registered_buffers(module, prefix, names, state_dict):
+    """CompressAI's load_state_dict override: size the CDF buffers like the checkpoint's (needed for
+    checkpoints saved after update(), as Flex loads them child by child -- test/utils.py:253-270)."""
+    for name in names:
+        key = f"{prefix}.{name}"
+        if key not in state_dict:
+            raise RuntimeError(f'missing key "{key}" in state_dict')
+        src = state_dict[key]
+        buf = getattr(module, name)
+        if buf.shape != src.shape:
+            setattr(module, name, torch.empty(src.shape, dtype=src.dtype, device=buf.device))
+
+
+# ------------------------------------------------------------------------------------------------
+# mean-scale hyperprior codec
+# ------------------------------------------------------------------------------------------------
+class BitCounter:
+    """Device-side accumulation of -log2(likelihood) sums: one row of workgroup partials per entropy
+    launch, folded by vc_bits_reduce; a single D2H copy at the very end of the frame."""
+
+    def __init__(self, device, max_rows=8):
+        self.slots = hip.lib().vc_bits_slots()
+        self.partial = torch.zeros(max_rows * self.slots, dtype=torch.float64, device=device)
+        self.out = torch.zeros(max_rows, dtype=torch.float64, device=device)
+        self.rows = 0
+
+    def next_row_ptr(self):
+        ptr = self.partial.data_ptr() + 8 * self.rows * self.slots
+        self.rows += 1
+        return ptr
+
+    def totals(self):
+        hip.check(hip.lib().vc_bits_reduce(hip.stream(), self.partial.data_ptr(), self.slots, self.rows,
+                                           self.out.data_ptr()), "vc_bits_reduce")
+        return self.out[: self.rows]
+
+
+class MeanScaleHyperprior(_Prepared):
+    """Holder + executor with the attribute names of compressai.models.MeanScaleHyperprior.
+    Sub-classes assign g_a, h_a, h_s, g_s (LHBDC/model/layers.py:48-91)."""
+
+    def __init__(self, N, M, **kwargs):
+        super().__init__()
+        self.entropy_bottleneck = EntropyBottleneck(N)
+        self.gaussian_conditional = GaussianConditional(None)
+        self.N, self.M = int(N), int(M)
+        self._cache = {"g_a": {}, "h_a": {}, "h_s": {}, "g_s": {}}
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._cache = {"g_a": {}, "h_a": {}, "h_s": {}, "g_s": {}}
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._cache = {"g_a": {}, "h_a": {}, "h_s": {}, "g_s": {}}
+        return super()._apply(fn, *a, **k)
+
+    # -- checkpoint behaviour of CompressAI ------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        _resize_registered_buffers(self.entropy_bottleneck, "entropy_bottleneck", _CDF_BUFFERS, state_dict)
+        _resize_registered_buffers(self.gaussian_conditional, "gaussian_conditional",
+                                   _CDF_BUFFERS + ("scale_table",), state_dict)
+        return super().load_state_dict(state_dict, strict=strict)
+
+    def update(self, scale_table=None, force=False):
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= self.entropy_bottleneck.update(force=force)
+        return updated
+
+    def aux_loss(self):
+        raise NotImplementedError("training is outside the inference hot path")
+
+    # -- HIP execution -----------------------------------------------------------------------------
+    def _gains(self, n, l):
+        """(gain, inv_gain, hyper_gain, hyper_inv_gain) device vectors or Nones (Flex overrides)."""
+        return None, None, None, None
+
+    def forward_t(self, x, bits, gains=(None, None, None, None)):
+        """x: T [n,h,w,c_in] -> x_hat T; appends two rows (y then z) to the BitCounter."""
+        g, ig, hg, hig = gains
+        L = hip.lib()
+        y = run_sequential(self.g_a, x, self._cache["g_a"], final_chscale=g)      # gained y when g is set
+        z = run_sequential(self.h_a, y, self._cache["h_a"])
+        z_hat = T.empty(z.n, z.h, z.w, z.c, z.buf.device)
+        row_y = bits.next_row_ptr()
+        row_z = bits.next_row_ptr()
+        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
+                                  None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
+                                  z_hat.view(), None, row_z, bits.slots), "vc_eb_forward")
+        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        m = self.M
+        scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
+        y_hat = T.empty(y.n, y.h, y.w, y.c, y.buf.device)
+        hip.check(L.vc_gc_forward(hip.stream(), y.view(), scales.view(), means.view(), None,
+                                  None if ig is None else ig.data_ptr(), y_hat.view(), row_y, bits.slots,
+                                  None, None, None, None, 0), "vc_gc_forward")
+        return run_sequential(self.g_s, y_hat, self._cache["g_s"])
+
+    def _scale_table_dev(self):
+        gc = self.gaussian_conditional
+        if gc._packed is None:
+            if gc.scale_table.numel() == 0:
+                raise hip.VcError("scale table is empty: call update(force=True) after loading weights")
+            gc._packed = gc.scale_table.detach().float().contiguous().to(gc.scale_bound.device)
+        return gc._packed
+
+    def compress_t(self, x, gains=(None, None, None, None), code_ungained_y=False):
+        """Analysis + symbolisation on the GPU, range coding on the host.  Returns (strings, (hz,wz))."""
+        g, ig, hg, hig = gains
+        L = hip.lib()
+        dev = x.buf.device
+        if g is not None and code_ungained_y:
+            y_raw = run_sequential(self.g_a, x, self._cache["g_a"])
+            y = T.empty(y_raw.n, y_raw.h, y_raw.w, y_raw.c, dev)
+            # scaled_y = gain * y  (Gain_Module.forward) -- needed by h_a; the un-gained y is what gets coded
+            hip.check(L.vc_channel_scale(hip.stream(), y_raw.view(), g.data_ptr(), y.view()), "vc_channel_scale")
+        else:
+            y_raw = None
+            y = run_sequential(self.g_a, x, self._cache["g_a"], final_chscale=g)
+        z = run_sequential(self.h_a, y, self._cache["h_a"])
+        z_hat = T.empty(z.n, z.h, z.w, z.c, dev)
+        z_sym = torch.empty(z.n * z.c * z.h * z.w, dtype=torch.int32, device=dev)
+        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
+                                  None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
+                                  z_hat.view(), z_sym.data_ptr(), None, 0), "vc_eb_forward")
+        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        m = self.M
+        scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
+        y_sym = torch.empty(y.n * y.c * y.h * y.w, dtype=torch.int32, device=dev)
+        y_idx = torch.empty_like(y_sym)
+        table = self._scale_table_dev()
+        hip.check(L.vc_gc_forward(hip.stream(), y.view(), scales.view(), means.view(), None, None, hip.NULL_VIEW,
+                                  None, 0, None if y_raw is None else y_raw.ptr, y_sym.data_ptr(), y_idx.data_ptr(),
+                                  table.data_ptr(), table.numel()), "vc_gc_forward")
+        # single D2H of the integer symbols, then the serial coder on the host
+        z_sym_h = z_sym.cpu().numpy().reshape(z.n, -1)
+        y_sym_h = y_sym.cpu().numpy().reshape(y.n, -1)
+        y_idx_h = y_idx.cpu().numpy().reshape(y.n, -1)
+        eb_cdf, eb_len, eb_off = self.entropy_bottleneck.tables()
+        gc_cdf, gc_len, gc_off = self.gaussian_conditional.tables()
+        z_index = np.repeat(np.arange(z.c, dtype=np.int32), z.h * z.w)
+        z_strings = [hip.rans_encode(z_sym_h[i], z_index, eb_cdf, eb_len, eb_off) for i in range(z.n)]
+        y_strings = [hip.rans_encode(y_sym_h[i], y_idx_h[i], gc_cdf, gc_len, gc_off) for i in range(y.n)]
+        return [y_strings, z_strings], (z.h, z.w)
+
+    def decompress_t(self, strings, shape, device, gains=(None, None, None, None)):
+        assert isinstance(strings, list) and len(strings) == 2
+        g, ig, hg, hig = gains
+        L = hip.lib()
+        n = len(strings[1])
+        hz, wz = int(shape[0]), int(shape[1])
+        c = self.N
+        eb_cdf, eb_len, eb_off = self.entropy_bottleneck.tables()
+        gc_cdf, gc_len, gc_off = self.gaussian_conditional.tables()
+        z_index = np.repeat(np.arange(c, dtype=np.int32), hz * wz)
+        z_sym = np.stack([hip.rans_decode(strings[1][i], z_index, eb_cdf, eb_len, eb_off) for i in range(n)])
+        z_sym_d = torch.from_numpy(z_sym).to(device)
+        z_hat = T.empty(n, hz, wz, c, device)
+        hip.check(L.vc_eb_dequant(hip.stream(), z_sym_d.data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
+                                  None if hig is None else hig.data_ptr(), z_hat.view()), "vc_eb_dequant")
+        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        m = self.M
+        scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
+        idx_d = torch.empty(n * m * gp.h * gp.w, dtype=torch.int32, device=device)
+        table = self._scale_table_dev()
+        hip.check(L.vc_gc_indexes(hip.stream(), scales.view(), table.data_ptr(), table.numel(), idx_d.data_ptr()),
+                  "vc_gc_indexes")
+        idx_h = idx_d.cpu().numpy().reshape(n, -1)
+        y_sym = np.stack([hip.rans_decode(strings[0][i], idx_h[i], gc_cdf, gc_len, gc_off) for i in range(n)])
+        y_sym_d = torch.from_numpy(y_sym).to(device)
+        y_hat = T.empty(n, gp.h, gp.w, m, device)
+        hip.check(L.vc_gc_dequant(hip.stream(), y_sym_d.data_ptr(), means.view(), None if ig is None else ig.data_ptr(),
+                                  y_hat.view()), "vc_gc_dequant")
+        return run_sequential(self.g_s, y_hat, self._cache["g_s"])
