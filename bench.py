@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- B-frame throughput of the LHBDC hot path on MI355X (BASELINE.json configs[1]).
+
+One "step" = one GOP-8 of a synthetic 1080p video (SURVEY.md 8(d) Config 2): the 7 B-frames coded in
+hierarchical order through Model.forward (flow -> warp -> mask/blend -> residual analysis -> hyperprior
+-> likelihood/bit count -> synthesis), inputs resident in HBM, seeded random weights of the reference
+architecture (pretrained weights and UVG are not available offline).  I-frames are the reference's
+third-party mbt2018_mean codec -- outside the per-B-frame path -- so the boundary frames of each GOP
+are taken as already decoded.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1: launched by torch.distributed.run, one rank per GPU; GOPs shard across ranks (weak scaling, no
+data-path collective), the per-frame R-D records are gathered over RCCL at the end.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
+
+H, W = 1080, 1920
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_gop(seed, gop_index, device):
+    """Config 2: band-limited noise texture (Gaussian sigma=3 px) + global translation (1.5,0.75) px per
+    frame + 2 % additive noise, quantised to uint8, then /255 and reflection-padded to 1088x1920."""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    margin = 32
+    tex = rng.random((3, H + 2 * margin, W + 2 * margin)).astype(np.float32)
+    tex = np.stack([ndimage.gaussian_filter(c, 3.0) for c in tex])
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    frames = []
+    for t in range(9):
+        tt = gop_index * 8 + t
+        dx, dy = 1.5 * (tt % 16), 0.75 * (tt % 16)
+        shifted = np.stack([ndimage.shift(c, (dy, dx), order=1, mode="nearest") for c in tex])
+        f = shifted[:, margin:margin + H, margin:margin + W]
+        noise = np.random.default_rng(seed + 1 + tt).standard_normal(f.shape).astype(np.float32) * 0.02
+        u8 = np.clip(np.round((f + noise) * 255.0), 0, 255).astype(np.uint8)
+        x = torch.from_numpy(u8.astype(np.float32) / 255.0)[None]
+        x = torch.nn.functional.pad(x, (0, (64 - W % 64) % 64, 0, (64 - H % 64) % 64), mode="reflect")
+        frames.append(x.to(device))
+    return frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", default=None, help="write the per-kernel event timing table here (json)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from vcamd import gop as vgop
+    from vcamd import hip, lhbdc
+    from vcamd.seeding import seeded_state_dict
+
+    model = lhbdc.Model()
+    sd = seeded_state_dict(model.state_dict(), seed=1234)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+
+    # every rank codes its own GOP (GOP index = rank): weak scaling, per-GPU work fixed
+    frames = synthetic_gop(1234, rank, dev)
+    records = []
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(keep):
+        vgop.code_gop_lhbdc(model, frames, frames[0], frames[8], H, W, records if keep else None,
+                            video=0, gop_index=rank)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i == args.steps - 1)
+        rows = vgop.gather_records(records, dev)      # the only exchange: final R-D gather (RCCL)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    b_frames = 7 * args.steps * world
+    result = {
+        "metric": "B-frames/s, LHBDC 1080p GOP-8 (frames/sec of the per-B-frame codec path)",
+        "value": b_frames / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (band-limited texture + global translation + 2% noise, 1080x1920 padded to 1088x1920); seeded random weights",
+        "config": {"workload": "LHBDC 1080p GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
+                               "one GOP per GPU per step", "frames_per_step_per_gpu": 7, "gop": 8,
+                   "resolution": "1920x1080", "parallelism": f"gop-shard x{world}"},
+    }
+    q = vgop.summarize(rows)
+    result["quality"] = {"b_frames": q["frames"], "bpp_estimated": q["bpp"], "psnr_db": q["psnr"],
+                         "note": "seeded random weights: R-D values are parity references, not codec quality"}
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel: HIP events on the launch stream, one instrumented B-frame ----
+        with torch.no_grad():
+            hip.timer = hip.KernelTimer()
+            model(frames[0], frames[4], frames[8], False)
+            table = hip.timer.table()
+            hip.timer = None
+        total_ms = sum(v["ms"] for v in table.values())
+        ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
+        key, dom = ranked[0]
+        per_launch_flop = dom["flops"] / dom["launches"]
+        avg_ms = dom["ms"] / dom["launches"]
+        achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                              "launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
+                              "share_of_conv_time": dom["ms"] / total_ms,
+                              "algorithmic_flop_per_launch": per_launch_flop}
+        ns = [kv for kv in ranked if kv[0].startswith("conv k3 s1 128->128 @1x544x960")]
+        if ns:
+            v = ns[0][1]
+            a = v["flops"] / v["launches"] / (v["ms"] / v["launches"] * 1e-3) / 1e12
+            result["roofline_3x3_analysis_conv"] = {"kernel": ns[0][0], "achieved": a, "peak": PEAK_F32_MFMA_TFLOPS,
+                                                    "unit": "TFLOP/s", "frac": a / PEAK_F32_MFMA_TFLOPS,
+                                                    "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
+        all_flops = sum(v["flops"] for v in table.values())
+        result["conv_engine"] = {"frame_conv_ms": total_ms, "frame_conv_tflop": all_flops / 1e12,
+                                 "avg_tflops": all_flops / (total_ms * 1e-3) / 1e12}
+        if args.kernel_table:
+            with open(args.kernel_table, "w") as f:
+                json.dump({k: v for k, v in ranked}, f, indent=1)
+
+        # ---- CPU baseline: the oracle (PyTorch-CPU restatement, tensor-equal to the reference) ----
+        if not args.no_cpu_baseline:
+            from oracle import lhbdc as oracle_lhbdc
+            ora = oracle_lhbdc.LhbdcModel().eval()
+            ora.load_state_dict(sd)
+            cores = os.cpu_count() or 1
+            torch.set_num_threads(cores)
+            xb, xc, xa = frames[0].cpu(), frames[4].cpu(), frames[8].cpu()
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                ref_hat, _, ref_bits = ora(xb, xc, xa, False)
+                cpu_s = time.perf_counter() - t1
+                gpu_hat, _, gpu_bits = model(frames[0], frames[4], frames[8], False)
+            result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(),
+                                      "kind": "port", "sample": "1 B-frame 1088x1920 (frame 4 of the same GOP), "
+                                      "PyTorch-CPU fp32 oracle, no warm-up"}
+            src = frames[4]
+            d_psnr = abs(float(vgop.psnr_uint8(gpu_hat, src, H, W)) - float(vgop.psnr_uint8(ref_hat.to(dev), src, H, W)))
+            result["parity_vs_cpu"] = {"d_psnr_db": d_psnr, "bits_rel": abs(gpu_bits - ref_bits) / abs(ref_bits),
+                                       "max_abs": float((gpu_hat.cpu() - ref_hat).abs().max())}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

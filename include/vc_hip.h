@@ -55,7 +55,7 @@ const char *vc_target_arch(void);
  *           Flex.../b_model/unet.py:27-31,62-74, layers.py:79-123;
  *           compressai GDN (1x1 contraction on x^2) -- SURVEY.md A.2.
  * ---------------------------------------------------------------------------------------- */
-enum { VC_ACT_NONE = 0, VC_ACT_RELU = 1, VC_ACT_LRELU = 2, VC_ACT_SIGMOID = 3 };
+enum { VC_ACT_NONE = 0, VC_ACT_RELU = 1, VC_ACT_LRELU = 2, VC_ACT_SIGMOID = 3, VC_ACT_CLAMP01 = 4 /* Flex decompress clamp_(0,1) */ };
 enum { VC_EPI_NONE = 0, VC_EPI_GDN = 1, VC_EPI_IGDN = 2 };   /* out = mul * rsqrt(acc) / mul * sqrt(acc) */
 enum { VC_IN_NONE = 0, VC_IN_SQUARE = 1 };                   /* transform applied to the staged input */
 enum { VC_OUT_PLAIN = 0, VC_OUT_PIXELSHUFFLE2 = 1 };         /* nn.PixelShuffle(2) fused into the store */

@@ -1,0 +1,96 @@
+"""-m gpu: the Flex-Rate B-frame path (BidirFlowRef surface over the HIP kernels) against the golden
+fixtures recorded from the reference and against the CPU oracle; gain units, interpolated rate point,
+un-gained-y / clamp quirks included."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import frame_tensor, load_fixture, psnr
+
+pytestmark = pytest.mark.gpu
+PSNR_TOL_DB = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    from oracle import flex as of
+    from vcamd import flex
+    from vcamd.seeding import seeded_state_dict
+    prod = flex.BidirFlowRef(n=4)
+    sd = seeded_state_dict(prod.state_dict(), seed=1234)
+    prod.load_state_dict(sd)
+    ora = of.FlexModel(n=4).eval()
+    ora.load_state_dict(sd)
+    return ora, prod.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag,n,l", [("n0", 0, 1.0), ("n2", 2, 1.0), ("n1l033", 1, 0.33)])
+def test_forward_matches_reference_fixture(dev, models, tag, n, l):
+    _, prod = models
+    fx = load_fixture("flex_forward_a.npz")
+    xb, xc, xa = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    with torch.no_grad():
+        out = prod(xb, xc, xa, n=[n], l=l, train=False)
+    ref = torch.from_numpy(fx[f"x_hat_{tag}"])
+    src = frame_tensor(fx["current"])
+    d_psnr = abs(psnr(out["x_hat"].cpu(), src) - psnr(ref, src))
+    rel = abs(out["size"].item() - float(fx[f"size_{tag}"][0])) / float(fx[f"size_{tag}"][0])
+    print(f"flex {tag}: max|d|={(out['x_hat'].cpu() - ref).abs().max():.3e} dPSNR={d_psnr:.2e} size rel={rel:.2e}")
+    assert d_psnr < PSNR_TOL_DB and rel < 2e-3
+    assert abs(out["rate"].item() - float(fx[f"rate_{tag}"][0])) / float(fx[f"rate_{tag}"][0]) < 2e-3
+    assert out["x_hat"].shape == ref.shape and out["size"].shape == (1,)
+
+
+def test_unet_matches_oracle(dev, models):
+    ora, prod = models
+    x = torch.rand(1, 6, 64, 96, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = ora.flow_predictor(x)
+    out = prod.flow_predictor(x.to(dev))
+    assert ((out.cpu() - ref).abs() / (1 + ref.abs())).max().item() < 5e-5
+
+
+def test_process_and_backwarp_surface(dev, models):
+    ora, prod = models
+    g = torch.Generator().manual_seed(3)
+    x0, x1 = torch.rand(1, 3, 64, 64, generator=g), torch.rand(1, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        r0, r1, rc = ora.process(x0, x1)
+    p0, p1, pc = prod.process(x0.to(dev), x1.to(dev))
+    assert pc.shape == rc.shape == (1, 16, 64, 64)
+    for a, b in ((p0, r0), (p1, r1), (pc, rc)):
+        assert (a.cpu() - b).abs().max().item() < 2e-4
+
+
+def test_codec_against_reference_bitstream(dev, models):
+    from vcamd import flex
+    _, prod = models
+    for c in (prod.flow_compressor, prod.residual_compressor):
+        c.update(force=True)
+    fx = load_fixture("flex_codec_a.npz")
+    n, l = int(fx["n"]), float(fx["l"])
+    xb, xc, xa = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    with torch.no_grad():
+        mv_bits, res_bits = flex.encode_B(prod, xb, xc, xa, n=n, l=l)
+        blob = flex.write_container(None, l, mv_bits, res_bits)
+        _, s_mv, s_res, sh_mv, sh_res = flex.read_container(blob)
+        dec = flex.decode_B(prod, xb, xa, s_mv, s_res, sh_mv, sh_res, n, l)
+    assert tuple(sh_mv) == tuple(fx["flow_shape"]) and tuple(sh_res) == tuple(fx["res_shape"])
+    same = {}
+    for k, s in (("flow_y", mv_bits["strings"][0][0]), ("flow_z", mv_bits["strings"][1][0]),
+                 ("res_y", res_bits["strings"][0][0]), ("res_z", res_bits["strings"][1][0])):
+        same[k] = s == fx[k].tobytes()
+        assert abs(len(s) - fx[k].size) <= max(8, 0.01 * fx[k].size), k
+    ref = torch.from_numpy(fx["decoded"])
+    src = frame_tensor(fx["current"])
+    d_psnr = abs(psnr(dec.cpu(), src) - psnr(ref, src))
+    print("flex byte-identical to the reference bitstream:", same, f"dPSNR={d_psnr:.2e}")
+    assert d_psnr < 5e-3
+    assert dec.min().item() >= -1.0  # residual path is clamped to [0,1] then added to the prediction

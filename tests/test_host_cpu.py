@@ -61,3 +61,30 @@ def test_seeded_checkpoint_is_deterministic():
     assert all(torch.equal(a[k], b[k]) for k in a)
     c = seeded_state_dict(t, 6)
     assert not torch.equal(a["FlowNet.netBasic.0.netBasic.0.weight"], c["FlowNet.netBasic.0.netBasic.0.weight"])
+
+
+def test_flex_state_dict_schema_and_child_loading():
+    from vcamd import flex
+    ref = [l.strip() for l in open(os.path.join(GOLDEN, "flex_state_schema.txt"))]
+    m = flex.BidirFlowRef(n=4)
+    mine = sorted(f"{k} {list(v.shape)}" for k, v in m.state_dict().items())
+    assert mine == ref and len(mine) == 396
+    # Flex checkpoints are loaded child by child (test/utils.py:253-270), after update() was called
+    m.flow_compressor.update(force=True)
+    child = m.flow_compressor.state_dict()
+    fresh = flex.BidirFlowRef(n=4)
+    getattr(fresh, "flow_compressor").load_state_dict(child)
+    assert fresh.flow_compressor.gaussian_conditional._quantized_cdf.shape[0] == 64
+
+
+def test_flex_gain_vector_interpolation():
+    from vcamd import flex
+    g = flex.Gain_Module(n=4, N=128)
+    with torch.no_grad():
+        g.gain_matrix.copy_(torch.linspace(-2, 2, 4 * 128).reshape(4, 128))
+    v = g.vector([1], 0.33)
+    exp = torch.abs(g.gain_matrix[1]) ** 0.33 * torch.abs(g.gain_matrix[2]) ** 0.67
+    assert torch.allclose(v, exp.detach(), rtol=1e-6)
+    assert torch.equal(g.vector([3], 1), torch.abs(g.gain_matrix[3]).detach())
+    with pytest.raises(IndexError):
+        g.vector([3], 0.5)      # n+1 out of range, like the reference (Appendix B.7)

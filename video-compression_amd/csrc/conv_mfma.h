@@ -104,6 +104,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
     if (act == VC_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == VC_ACT_LRELU) return v >= 0.0f ? v : v * slope;
     if (act == VC_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == VC_ACT_CLAMP01) return fminf(fmaxf(v, 0.0f), 1.0f);
     return v;
 }
 

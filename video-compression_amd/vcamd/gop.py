@@ -1,0 +1,81 @@
+"""Hierarchical bi-directional GOP coding and the GOP sharding used for multi-GPU runs.
+
+Mirrors the evaluation loop that defines the reference's metric (LHBDC/test/testing.py:65-196):
+coding order [0, 8, 4, 2, 1, 3, 6, 5, 7], each B-frame predicted from the two already decoded frames in
+``DECODING_INFO``, PSNR on uint8-rounded crops, bpp = sum(bits) / sum(h*w) (test/utils.py:415-432).
+GOPs depend only on their two boundary I-frames, so they shard across GPUs with no data-path collective;
+the only exchange is the final gather of per-frame rate-distortion records.
+"""
+import math
+
+import torch
+
+CODING_ORDER = [0, 8, 4, 2, 1, 3, 6, 5, 7]                     # testing.py:70
+DECODING_INFO = {4: (0, 8), 2: (0, 4), 1: (0, 2), 3: (2, 4), 6: (4, 8), 5: (4, 6), 7: (6, 8)}  # :72
+HIER_LEVELS = {4: 0, 2: 1, 1: 2, 3: 2, 6: 1, 5: 2, 7: 2}       # :74
+
+
+def psnr_uint8(x_hat, x, h, w):
+    """testing.py:176-182 / utils.py:32-51: PSNR of round(clip(.,0,1)*255) on the un-padded crop."""
+    a = torch.round(torch.clamp(x_hat[0, :, :h, :w], 0, 1) * 255.0).double()
+    b = torch.round(torch.clamp(x[0, :, :h, :w], 0, 1) * 255.0).double()
+    mse = torch.mean((a - b) ** 2)
+    return 10.0 * torch.log10(255.0 ** 2 / mse)
+
+
+def code_gop_lhbdc(model, gop, dec_first, dec_last, h, w, records=None, video=0, gop_index=0):
+    """Code the 7 B-frames of one GOP-8.  ``gop``: list of 9 NCHW frames (padded), ``dec_first`` /
+    ``dec_last``: decoded boundary frames.  Appends (video, frame, level, psnr, bits, pixels) to
+    ``records`` (psnr stays a device scalar: no sync inside the GOP) and returns the decoded dict."""
+    decoded = {0: dec_first, 8: dec_last}
+    for order in CODING_ORDER[2:]:
+        r0, r1 = DECODING_INFO[order]
+        x_hat, _, bits = model(decoded[r0], gop[order], decoded[r1], False)
+        decoded[order] = x_hat
+        if records is not None:
+            records.append((video, gop_index * 8 + order, HIER_LEVELS[order], psnr_uint8(x_hat, gop[order], h, w),
+                            bits, float(h * w)))
+    return decoded
+
+
+def shard_gops(num_gops, world_size, rank):
+    """Contiguous GOP range [lo, hi) of ``rank`` (rank r gets [r*G/P, (r+1)*G/P))."""
+    lo = (rank * num_gops) // world_size
+    hi = ((rank + 1) * num_gops) // world_size
+    return lo, hi
+
+
+def gather_records(records, device):
+    """All-gather per-frame R-D records over the default process group (RCCL on GPUs, gloo on CPU) and
+    return them sorted in (video, frame) order on every rank.  Payload is a few KB: latency-bound."""
+    import torch.distributed as dist
+    rows = [[float(v), float(f), float(l), float(p), float(b), float(px)] for v, f, l, p, b, px in records]
+    local = torch.tensor(rows, dtype=torch.float64, device=device).reshape(-1, 6)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        allrows = local
+    else:
+        world = dist.get_world_size()
+        count = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+        counts = [torch.zeros_like(count) for _ in range(world)]
+        dist.all_gather(counts, count)
+        m = int(max(c.item() for c in counts))
+        padded = torch.zeros((m, 6), dtype=torch.float64, device=device)
+        padded[: local.shape[0]] = local
+        parts = [torch.zeros_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded)
+        allrows = torch.cat([p[: int(c.item())] for p, c in zip(parts, counts)], 0)
+    allrows = allrows.cpu()
+    key = allrows[:, 0] * 1e9 + allrows[:, 1]
+    return allrows[torch.argsort(key)]
+
+
+def summarize(rows):
+    """bpp = sum(bits)/sum(pixels); PSNR = mean of per-frame PSNR (utils.py:425-426), summed in frame order."""
+    if rows.numel() == 0:
+        return {"frames": 0, "bpp": math.nan, "psnr": math.nan}
+    bits, pix, ps = 0.0, 0.0, 0.0
+    for r in rows.tolist():
+        ps += r[3]
+        bits += r[4]
+        pix += r[5]
+    return {"frames": int(rows.shape[0]), "bpp": bits / pix, "psnr": ps / rows.shape[0]}

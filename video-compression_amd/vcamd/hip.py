@@ -13,7 +13,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_DIR, "libvc_hip.so")
 
 VC_OK = 0
-ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_CLAMP01 = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GDN, EPI_IGDN = 0, 1, 2
 IN_NONE, IN_SQUARE = 0, 1
 OUT_PLAIN, OUT_PIXELSHUFFLE2 = 0, 1
@@ -48,6 +48,35 @@ class ConvDesc(ctypes.Structure):
 
 
 _lib = None
+
+
+class KernelTimer:
+    """Opt-in per-launch timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  Used by bench.py for the roofline line; never active in production."""
+
+    def __init__(self):
+        self.items = []
+
+    def bracket(self, key, flops, launch):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = launch()
+        e1.record()
+        self.items.append((key, flops, e0, e1))
+        return out
+
+    def table(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in self.items:
+            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += flops
+        return agg
+
+
+timer = None  # set to a KernelTimer() to collect
 
 
 def lib():
@@ -233,7 +262,14 @@ class PackedConv:
         d.epi, d.in_xform = epi, in_xform
         d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
         d.cfg = self.cfg
-        check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})")
+        what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})"
+        if timer is None:
+            check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
+        else:
+            hq, wq = (ho // 2, wo // 2) if self.ps else (ho, wo)
+            flops = 2.0 * x.n * hq * wq * self.cout * self.cin * self.k * self.k
+            key = f"conv k{self.k} s{self.stride} {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
+            timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what))
         return out
 
 

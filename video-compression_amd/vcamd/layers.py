@@ -161,7 +161,7 @@ class ResidualBlock(_Prepared):
         return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity)
 
 
-def run_sequential(seq, x, cache, final_chscale=None):
+def run_sequential(seq, x, cache, final_chscale=None, final_act=None):
     """Execute an nn.Sequential of {Conv2d, subpel Sequential, LeakyReLU, Residual*} on the HIP path.
     A LeakyReLU following a convolution is fused into that convolution's epilogue."""
     mods = list(seq)
@@ -188,6 +188,8 @@ def run_sequential(seq, x, cache, final_chscale=None):
             act, slope = hip.ACT_LRELU, mods[i + 1].negative_slope
             i += 1
             last = i == len(mods) - 1
+        if last and final_act is not None:
+            act = final_act
         x = packed[key](x, act=act, slope=slope, chscale=final_chscale if last else None)
         i += 1
     return x
@@ -487,7 +489,7 @@ class MeanScaleHyperprior(_Prepared):
         y_strings = [hip.rans_encode(y_sym_h[i], y_idx_h[i], gc_cdf, gc_len, gc_off) for i in range(y.n)]
         return [y_strings, z_strings], (z.h, z.w)
 
-    def decompress_t(self, strings, shape, device, gains=(None, None, None, None)):
+    def decompress_t(self, strings, shape, device, gains=(None, None, None, None), final_act=None):
         assert isinstance(strings, list) and len(strings) == 2
         g, ig, hg, hig = gains
         L = hip.lib()
@@ -515,4 +517,4 @@ class MeanScaleHyperprior(_Prepared):
         y_hat = T.empty(n, gp.h, gp.w, m, device)
         hip.check(L.vc_gc_dequant(hip.stream(), y_sym_d.data_ptr(), means.view(), None if ig is None else ig.data_ptr(),
                                   y_hat.view()), "vc_gc_dequant")
-        return run_sequential(self.g_s, y_hat, self._cache["g_s"])
+        return run_sequential(self.g_s, y_hat, self._cache["g_s"], final_act=final_act)
