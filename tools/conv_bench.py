@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the convolution engine on chosen layer shapes (HIP events on the launch stream).
+
+    python tools/conv_bench.py [--reps R] cin,cout,k,stride,n,h,w [...]
+Prints achieved algorithmic TFLOP/s per shape; used for A/B work on csrc/conv_mfma.h and as the target of
+`rocprofv3 --pmc` passes (see profiles/README.md)."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
+from vcamd import hip  # noqa: E402
+
+DEFAULT = ["128,128,3,1,1,544,960", "64,32,7,1,4,1088,1920", "32,64,7,1,4,1088,1920", "128,512,3,1,1,272,480",
+           "192,64,5,1,1,544,960", "128,128,3,1,1,136,240", "128,128,3,1,1,40,64", "16,2,7,1,4,1088,1920",
+           "128,128,1,1,1,544,960"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("shapes", nargs="*", default=DEFAULT)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for spec in args.shapes:
+        cin, cout, k, s, n, h, w = (int(v) for v in spec.split(","))
+        g = torch.Generator().manual_seed(0)
+        wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        pc = hip.PackedConv(wt, b, stride=s, device=dev)
+        x = hip.T.empty(n, h, w, cin, dev)
+        x.buf.normal_()
+        ho, wo, co = pc.out_shape(h, w)
+        out = hip.T.empty(n, ho, wo, co, dev)
+        for _ in range(2):
+            pc(x, out=out, act=hip.ACT_LRELU)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            pc(x, out=out, act=hip.ACT_LRELU)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        flop = 2.0 * n * ho * wo * cout * cin * k * k
+        print(f"conv k{k} s{s} {cin:4d}->{cout:4d} @{n}x{h}x{w}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s "
+              f"({flop / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)")
+
+
+if __name__ == "__main__":
+    main()

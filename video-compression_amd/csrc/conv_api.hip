@@ -118,10 +118,19 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.mul = d->mul; a.mul_sn = d->mul_sn; a.mul_sh = d->mul_sh; a.mul_sw = d->mul_sw;
     a.chscale = d->chscale;
     a.cin_pad = round_up(a.Cin, ck);
-    const int bn = cfg_bn(d->cfg);
     const int th = 8, tw = 32;
     a.tiles_x = (a.Wo + tw - 1) / tw;
     a.tiles_y = (a.Ho + th - 1) / th;
+    // Small feature maps (hyper-networks, MV codec, coarse pyramid levels): a 128-channel block would
+    // leave most of the 256 CUs idle while each block walks the whole K loop alone.  The 32-wide MFMA
+    // configurations share one packed-weight layout, so drop to a narrower channel block (more blocks,
+    // shorter serial chain) until the launch can fill the chip twice over.
+    int cfg = d->cfg;
+    while ((cfg == VC_CFG_N128 || cfg == VC_CFG_N64) &&
+           (long long)a.tiles_x * a.tiles_y * a.N * (round_up(a.Cout, cfg_bn(cfg)) / cfg_bn(cfg)) < 512 &&
+           vc_conv_chunk(cfg + 1, k, st, d->in.c) == ck)
+        ++cfg;
+    const int bn = cfg_bn(cfg);
     a.nblks = round_up(a.Cout, bn) / bn;
     a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
     a.act = d->act; a.slope = d->slope;
@@ -131,10 +140,10 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     if (a.total_blocks <= 0) return VC_EINVAL;
     hipStream_t stream = as_stream(s);
     switch (k) {
-    case 1: return conv_dispatch_k1(stream, a, st, d->cfg, ck);
-    case 3: return conv_dispatch_k3(stream, a, st, d->cfg, ck);
-    case 5: return conv_dispatch_k5(stream, a, st, d->cfg, ck);
-    case 7: return conv_dispatch_k7(stream, a, st, d->cfg, ck);
+    case 1: return conv_dispatch_k1(stream, a, st, cfg, ck);
+    case 3: return conv_dispatch_k3(stream, a, st, cfg, ck);
+    case 5: return conv_dispatch_k5(stream, a, st, cfg, ck);
+    case 7: return conv_dispatch_k7(stream, a, st, cfg, ck);
     }
     return VC_EINVAL;
 }

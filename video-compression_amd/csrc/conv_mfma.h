@@ -108,6 +108,60 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
     return v;
 }
 
+template <int KH, int KW, int S, int CK, class C, bool VEC>
+__device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const float *in_img, int c0, int oy0, int ox0,
+                                            int iy0, int ix0)
+{
+    typedef ConvGeom<KH, KW, S, CK, C> G;
+    constexpr int C4 = CK / 4;
+    constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
+    constexpr int IPT = (ITEMS + 255) / 256;                    // items per thread
+    constexpr int BATCH = (C::WM * C::WN >= 8) ? 4 : 8;        // fewer live registers in the widest config
+#pragma unroll
+    for (int b0 = 0; b0 < IPT; b0 += BATCH) {
+        f32x4 v[BATCH];
+        int dst[BATCH];
+        bool ok[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (b0 + j >= IPT) continue;
+            const int idx = threadIdx.x + (b0 + j) * 256;
+            const int c4 = idx % C4;
+            const int pc = idx / C4;
+            const int col = pc % G::COLS_IN, row = pc / G::COLS_IN;
+            const int iy = G::POINT ? (oy0 + row) * S : iy0 + row;
+            const int ix = G::POINT ? (ox0 + col) * S : ix0 + col;
+            const int ch = c0 + c4 * 4;
+            ok[j] = (idx < ITEMS) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin;
+            const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+            const int pos = (G::LS == 2) ? ((col & 1) * G::HALF + (col >> 1)) : col;
+            dst[j] = (idx < ITEMS) ? (row * G::COLS_L + pos) * G::CKP + c4 * 4 : -1;
+            const float *src = in_img + (long long)iyc * p.in_sh + (long long)ixc * p.in_sw;
+            if (VEC) {
+                v[j] = *reinterpret_cast<const f32x4 *>(src + min(ch, p.Cin - 4));
+            } else {
+                const int cl = p.Cin - 1;
+                v[j].x = src[min(ch, cl)];
+                v[j].y = src[min(ch + 1, cl)];
+                v[j].z = src[min(ch + 2, cl)];
+                v[j].w = src[min(ch + 3, cl)];
+                if (ch + 1 >= p.Cin) v[j].y = 0.f;
+                if (ch + 2 >= p.Cin) v[j].z = 0.f;
+                if (ch + 3 >= p.Cin) v[j].w = 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (b0 + j >= IPT) continue;
+            f32x4 w = v[j];
+            if (p.in_xform == VC_IN_SQUARE) w = w * w;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            w = ok[j] ? w : z;
+            if (dst[j] >= 0) *reinterpret_cast<f32x4 *>(&lds[dst[j]]) = w;
+        }
+    }
+}
+
 template <int KH, int KW, int S, int CK, class C>
 __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs p)
 {
@@ -166,63 +220,67 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs p)
     for (int c0 = 0; c0 < p.cin_pad; c0 += CK) {
         __syncthreads();
         // ---- stage the input footprint of this channel chunk ----
-        {
-            constexpr int C4 = CK / 4;
-            constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
-            for (int idx = threadIdx.x; idx < ITEMS; idx += 256) {
-                const int c4 = idx % C4;
-                const int pc = idx / C4;
-                const int col = pc % G::COLS_IN, row = pc / G::COLS_IN;
-                const int iy = G::POINT ? (oy0 + row) * S : iy0 + row;
-                const int ix = G::POINT ? (ox0 + col) * S : ix0 + col;
-                const int ch = c0 + c4 * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin) {
-                    const float *src = in_img + (long long)iy * p.in_sh + (long long)ix * p.in_sw + ch;
-                    if (p.vec4) {
-                        v = *reinterpret_cast<const f32x4 *>(src);
-                    } else {
-                        v.x = src[0];
-                        if (ch + 1 < p.Cin) v.y = src[1];
-                        if (ch + 2 < p.Cin) v.z = src[2];
-                        if (ch + 3 < p.Cin) v.w = src[3];
-                    }
-                    if (p.in_xform == VC_IN_SQUARE) v = v * v;
-                }
-                const int pos = (G::LS == 2) ? ((col & 1) * G::HALF + (col >> 1)) : col;
-                *reinterpret_cast<f32x4 *>(&lds[(row * G::COLS_L + pos) * G::CKP + c4 * 4]) = v;
-            }
-        }
+        // Two phases per batch: issue all global loads of the batch (addresses clamped into the image so
+        // no load sits under a branch), then select-zero / transform and write LDS.  This keeps BATCH
+        // independent 16-byte loads in flight per lane instead of one load -> wait -> ds_write at a time.
+        if (p.vec4)
+            stage_chunk<KH, KW, S, CK, C, true>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+        else
+            stage_chunk<KH, KW, S, CK, C, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
         __syncthreads();
 
-        // ---- contraction over taps x k-steps of this chunk ----
+        // ---- contraction over taps x k-steps of this chunk, software-pipelined ----
+        // The fragments of step s+1 (one 1 KiB global_load_dwordx4 per N-tile, one ds_read_b128 per
+        // M-tile) are issued BEFORE the MFMAs of step s, so L2/LDS latency hides behind 8*WM*WN*... cycles
+        // of matrix work instead of stalling every step (the compiler alone waits right after issuing).
         const float *wchunk = wlane + (long long)(c0 / KS) * 256;
+        constexpr int STEPS_X = KW * KSTEPS;  // steps per kernel row, fully unrolled
+        f32x4 bc[WN], ac[WM], bn[WN], an[WM];
+        auto load_b = [&](f32x4(&b)[WN], const float *wrow, int sx) {
+            // sx = kx*KSTEPS + ks within the row; consecutive ks are 1 KiB apart, consecutive taps ksteps_total KiB
+            const int kx = sx / KSTEPS, ks = sx % KSTEPS;
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+                b[n] = *reinterpret_cast<const f32x4 *>(wrow + n * ntile_stride + ((long long)kx * ksteps_total + ks) * 256);
+        };
+        auto load_a = [&](f32x4(&a)[WM], int rowoff, int sx) {
+            const int kx = sx / KSTEPS, ks = sx % KSTEPS;
+            const int koff = (G::LS == 2) ? ((kx & 1) * G::HALF + (kx >> 1)) * G::CKP : kx * G::CKP;
+#pragma unroll
+            for (int t = 0; t < WM; ++t) a[t] = *reinterpret_cast<const f32x4 *>(&lds[abase[t] + rowoff + koff + ks * KS]);
+        };
+        load_b(bc, wchunk, 0);
+        load_a(ac, 0, 0);
 #pragma unroll 1
         for (int ky = 0; ky < KH; ++ky) {
+            const float *wrow = wchunk + (long long)ky * KW * ksteps_total * 256;
+            const int rowoff = ky * G::COLS_L * G::CKP;
+            // the row after this one (clamped: the last row re-fetches itself, a harmless extra load)
+            const int kyn = ky + 1 < KH ? ky + 1 : ky;
+            const float *wrow_n = wchunk + (long long)kyn * KW * ksteps_total * 256;
+            const int rowoff_n = kyn * G::COLS_L * G::CKP;
+            static_for<0, STEPS_X>([&](auto sc) {
+                constexpr int sx = decltype(sc)::value;
+                if constexpr (sx + 1 < STEPS_X) {
+                    load_b(bn, wrow, sx + 1);
+                    load_a(an, rowoff, sx + 1);
+                } else {
+                    load_b(bn, wrow_n, 0);
+                    load_a(an, rowoff_n, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kx = 0; kx < KW; ++kx) {
-                const int tap = ky * KW + kx;
-                const int tapoff = (G::LS == 2)
-                                       ? (ky * G::COLS_L + (kx & 1) * G::HALF + (kx >> 1)) * G::CKP
-                                       : (ky * G::COLS_L + kx) * G::CKP;
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    f32x4 b[WN], a[WM];
-#pragma unroll
-                    for (int n = 0; n < WN; ++n)
-                        b[n] = *reinterpret_cast<const f32x4 *>(
-                            wchunk + n * ntile_stride + ((long long)tap * ksteps_total + ks) * 256);
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int t = 0; t < WM; ++t)
-                        a[t] = *reinterpret_cast<const f32x4 *>(&lds[abase[t] + tapoff + ks * KS]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                        for (int n = 0; n < WN; ++n) acc[t][n] = M::run(ac[t][e], bc[n][e], acc[t][n]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int t = 0; t < WM; ++t)
+                for (int n = 0; n < WN; ++n) bc[n] = bn[n];
 #pragma unroll
-                            for (int n = 0; n < WN; ++n) acc[t][n] = M::run(a[t][e], b[n][e], acc[t][n]);
-                }
-            }
+                for (int t = 0; t < WM; ++t) ac[t] = an[t];
+            });
         }
     }
 

@@ -272,12 +272,13 @@ class Model(nn.Module):
                                            resid.view() if resid is not None else hip.NULL_VIEW), "vc_lhbdc_blend")
         return pred, resid
 
-    def forward(self, x_before, x_current, x_after, train=False):
+    def forward_device(self, x_before, x_current, x_after):
+        """The whole B-frame path with NO host synchronisation (graph-capturable): returns
+        (x_hat NCHW, bits) where bits is a float64 device tensor [4] = (mv.y, mv.z, res.y, res.z)."""
         for t in (x_before, x_current, x_after):
             _require_cuda(t)
         xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
-        n, _, h, w = xc_.shape
-        num_pixels = n * h * w
+        n = xc_.shape[0]
         dev = xc_.device
         frames = {"b": xb_, "c": xc_, "a": xa_}
         # m.py:38-47 -- four SPyNet calls as one batch: ba, ab, cb, ca
@@ -295,7 +296,12 @@ class Model(nn.Module):
         pred, resid = self._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww, cur=xc)
         res_hat = self.residual_compressor.forward_t(resid, bits)
         x_hat = hip.nhwc_to_nchw(hip.axpby(res_hat, pred))                   # m.py:71
-        tot = bits.totals()          # rows: mv.y, mv.z, res.y, res.z  (bits, float64, on device)
+        return x_hat, bits.totals()
+
+    def forward(self, x_before, x_current, x_after, train=False):
+        x_hat, tot = self.forward_device(x_before, x_current, x_after)
+        n, _, h, w = x_current.shape
+        num_pixels = n * h * w
         size = tot.sum()
         rate = (size / num_pixels / 2.0).to(torch.float32)                   # m.py:96,98 (halved)
         if train:
