@@ -26,11 +26,14 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for spec in args.shapes:
-        cin, cout, k, s, n, h, w = (int(v) for v in spec.split(","))
+        fields = [int(v) for v in spec.split(",")]
+        cin, cout, k, s, n, h, w = fields[:7]
         g = torch.Generator().manual_seed(0)
         wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
         b = torch.randn(cout, generator=g) * 0.1
         pc = hip.PackedConv(wt, b, stride=s, device=dev)
+        if len(fields) > 7:            # optional 8th field: force a (layout-compatible) narrower tile config
+            pc.cfg = fields[7]
         x = hip.T.empty(n, h, w, cin, dev)
         x.buf.normal_()
         ho, wo, co = pc.out_shape(h, w)
@@ -45,7 +48,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
         flop = 2.0 * n * ho * wo * cout * cin * k * k
-        print(f"conv k{k} s{s} {cin:4d}->{cout:4d} @{n}x{h}x{w}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s "
+        print(f"conv k{k} s{s} {cin:4d}->{cout:4d} @{n}x{h}x{w} cfg{pc.cfg}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s "
               f"({flop / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)")
 
 

@@ -76,6 +76,10 @@ template <> struct Mfma<16> {
 // WN N-tiles of the block (BN = WN*MT output channels).
 template <int MT_, int TH_, int XT_, int WM_, int WN_> struct TileCfg {
     static constexpr int MT = MT_, TH = TH_, XT = XT_, WM = WM_, WN = WN_;
+    // waves per SIMD the register allocation must leave room for: the 128-channel block needs ~250
+    // registers (2 waves); the narrower ones are held to 168 so that three workgroups share a CU and
+    // one of them can always feed the matrix pipe while another stages or stores
+    static constexpr int MIN_WAVES = (WM_ * WN_ >= 4) ? 2 : 3;
     static constexpr int TW = XT * MT, BN = WN * MT;
     static_assert(TH * XT == 4 * WM, "4 waves x WM M-tiles must cover the tile");
 };
@@ -116,7 +120,7 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
     constexpr int C4 = CK / 4;
     constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
     constexpr int IPT = (ITEMS + 255) / 256;                    // items per thread
-    constexpr int BATCH = (C::WM * C::WN >= 8) ? 4 : 8;        // fewer live registers in the widest config
+    constexpr int BATCH = 4;                                    // 4 x 16 B in flight per lane per round
 #pragma unroll
     for (int b0 = 0; b0 < IPT; b0 += BATCH) {
         f32x4 v[BATCH];
@@ -163,7 +167,7 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
 }
 
 template <int KH, int KW, int S, int CK, class C>
-__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvArgs p)
+__global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const ConvArgs p)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     typedef Mfma<C::MT> M;

@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libvc_hip.so")
+# VC_HIP_LIB lets a developer A/B two builds of the same ABI on one device; it must still be a HIP build.
+LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_PKG_DIR, "libvc_hip.so")
 
 VC_OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_CLAMP01 = 0, 1, 2, 3, 4
