@@ -31,7 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_HBM_GBS = 8000.0
 
 
-def synthetic_gop(seed, gop_index, device):
+def synthetic_gop(seed, gop_index, device, frames_per_gop=9):
     """Config 2: band-limited noise texture (Gaussian sigma=3 px) + global translation (1.5,0.75) px per
     frame + 2 % additive noise, quantised to uint8, then /255 and reflection-padded to 1088x1920."""
     from scipy import ndimage
@@ -41,8 +41,8 @@ def synthetic_gop(seed, gop_index, device):
     tex = np.stack([ndimage.gaussian_filter(c, 3.0) for c in tex])
     tex = (tex - tex.min()) / (tex.max() - tex.min())
     frames = []
-    for t in range(9):
-        tt = gop_index * 8 + t
+    for t in range(frames_per_gop):
+        tt = gop_index * (frames_per_gop - 1) + t
         dx, dy = 1.5 * (tt % 16), 0.75 * (tt % 16)
         shifted = np.stack([ndimage.shift(c, (dy, dx), order=1, mode="nearest") for c in tex])
         f = shifted[:, margin:margin + H, margin:margin + W]
@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", choices=["lhbdc", "flex"], default="lhbdc",
+                    help="lhbdc = BASELINE.json configs[1] (headline); flex = configs[2] (Flex-Rate, 4 rate points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel event timing table here (json)")
@@ -96,36 +98,49 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from vcamd import flex, hip, lhbdc
     from vcamd import gop as vgop
-    from vcamd import hip, lhbdc
     from vcamd.seeding import seeded_state_dict
 
-    model = lhbdc.Model()
+    is_flex = args.model == "flex"
+    model = flex.BidirFlowRef(n=4) if is_flex else lhbdc.Model()
     sd = seeded_state_dict(model.state_dict(), seed=1234)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
+    per_gop = 15 if is_flex else 7
 
     # every rank codes its own GOP (GOP index = rank): weak scaling, per-GPU work fixed
-    frames = synthetic_gop(1234, rank, dev)
+    frames = synthetic_gop(1234, rank, dev, 17 if is_flex else 9)
     records = []
+    # Flex: 4 rate points selected purely through the gain units (n = 0..3, l = 1), one per step in turn
+    rate_points = [{lvl: (n, 1.0) for lvl in range(4)} for n in range(4)]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    runner = None if args.no_graph else vgop.GopGraph(model, H, W)
+    if is_flex:
+        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="flex", quality=q) for q in rate_points]
+    else:
+        runners = [None if args.no_graph else vgop.GopGraph(model, H, W)]
+    counter = [0]
 
     def step(keep):
-        if runner is None:
-            vgop.code_gop_lhbdc(model, frames, frames[0], frames[8], H, W, records if keep else None,
-                                video=0, gop_index=rank)
+        i = counter[0] % len(runners)
+        counter[0] += 1
+        recs = records if keep else None
+        if runners[i] is not None:
+            runners[i].code(frames, gop_index=rank, records=recs)
+        elif is_flex:
+            vgop.code_gop_flex(model, frames, frames[0], frames[16], H, W, rate_points[i], recs, video=0, gop_index=rank)
         else:
-            runner.code(frames, gop_index=rank, records=records if keep else None)
+            vgop.code_gop_lhbdc(model, frames, frames[0], frames[8], H, W, recs, video=0, gop_index=rank)
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, len(runners))):   # every graph is captured before the clock starts
             step(False)
+        counter[0] = 0
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -138,9 +153,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    b_frames = 7 * args.steps * world
+    b_frames = per_gop * args.steps * world
     result = {
-        "metric": "B-frames/s, LHBDC 1080p GOP-8 (frames/sec of the per-B-frame codec path)",
+        "metric": ("B-frames/s, Flex-Rate 1080p GOP-16, 4 rate points" if is_flex else
+                   "B-frames/s, LHBDC 1080p GOP-8 (frames/sec of the per-B-frame codec path)"),
         "value": b_frames / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
@@ -152,8 +168,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (band-limited texture + global translation + 2% noise, 1080x1920 padded to 1088x1920); seeded random weights",
-        "config": {"workload": "LHBDC 1080p GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
-                               "one GOP per GPU per step", "frames_per_step_per_gpu": 7, "gop": 8,
+        "config": {"workload": ("Flex-Rate b_model 1080p GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
+                                "n=step%4 through the gain units, one GOP per GPU per step" if is_flex else
+                                "LHBDC 1080p GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
+                                "one GOP per GPU per step"), "frames_per_step_per_gpu": per_gop, "gop": 16 if is_flex else 8,
                    "resolution": "1920x1080", "parallelism": f"gop-shard x{world}",
                    "launch": "eager" if args.no_graph else "hip-graph per GOP"},
     }
@@ -165,7 +183,10 @@ def main():
         # ---- roofline of the dominant kernel: HIP events on the launch stream, one instrumented B-frame ----
         with torch.no_grad():
             hip.timer = hip.KernelTimer()
-            model(frames[0], frames[4], frames[8], False)
+            if is_flex:
+                model(frames[0], frames[8], frames[16], n=[1], l=1.0)
+            else:
+                model(frames[0], frames[4], frames[8], False)
             table = hip.timer.table()
             hip.timer = None
         total_ms = sum(v["ms"] for v in table.values())
@@ -195,21 +216,31 @@ def main():
 
         # ---- CPU baseline: the oracle (PyTorch-CPU restatement, tensor-equal to the reference) ----
         if not args.no_cpu_baseline:
+            from oracle import flex as oracle_flex
             from oracle import lhbdc as oracle_lhbdc
-            ora = oracle_lhbdc.LhbdcModel().eval()
+            ora = (oracle_flex.FlexModel(n=4) if is_flex else oracle_lhbdc.LhbdcModel()).eval()
             ora.load_state_dict(sd)
             torch.set_num_threads(pick_cpu_threads())
-            xb, xc, xa = frames[0].cpu(), frames[4].cpu(), frames[8].cpu()
+            mid = 8 if is_flex else 4
+            xb, xc, xa = frames[0].cpu(), frames[mid].cpu(), frames[2 * mid].cpu()
             with torch.no_grad():
                 t1 = time.perf_counter()
-                ref_hat, _, ref_bits = ora(xb, xc, xa, False)
+                if is_flex:
+                    o = ora(xb, xc, xa, n=[1], l=1.0, train=False)
+                    ref_hat, ref_bits = o["x_hat"], float(o["size"].item())
+                else:
+                    ref_hat, _, ref_bits = ora(xb, xc, xa, False)
                 cpu_s = time.perf_counter() - t1
-                gpu_hat, _, gpu_bits = model(frames[0], frames[4], frames[8], False)
+                if is_flex:
+                    g = model(frames[0], frames[mid], frames[2 * mid], n=[1], l=1.0)
+                    gpu_hat, gpu_bits = g["x_hat"], float(g["size"].item())
+                else:
+                    gpu_hat, _, gpu_bits = model(frames[0], frames[4], frames[8], False)
             result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(),
-                                      "kind": "port", "sample": "1 B-frame 1088x1920 (frame 4 of the same GOP), "
+                                      "kind": "port", "sample": "1 B-frame 1088x1920 (middle frame of the same GOP), "
                                       "PyTorch-CPU fp32 oracle (tensor-equal to the reference), thread count "
                                       "chosen by a conv micro-calibration"}
-            src = frames[4]
+            src = frames[mid]
             d_psnr = abs(float(vgop.psnr_uint8(gpu_hat, src, H, W)) - float(vgop.psnr_uint8(ref_hat.to(dev), src, H, W)))
             result["parity_vs_cpu"] = {"d_psnr_db": d_psnr, "bits_rel": abs(gpu_bits - ref_bits) / abs(ref_bits),
                                        "max_abs": float((gpu_hat.cpu() - ref_hat).abs().max())}

@@ -116,8 +116,9 @@ int vc_channel_scale(vc_stream s, vc_view a, const float *gain, vc_view out);
  * Warping (torch grid_sample call sites)
  *   VC_WARP_W1: LHBDC flow.py:15-25, m.py:111-126 -- sample at (x+u*W/(W-1), y+v*H/(H-1)), border clamp
  *   VC_WARP_W2: Flex b_model.py:99-112           -- sample at (x+u-.5, y+v-.5), zeros outside
+ *   VC_WARP_W3: ICIP2024 src/model/m.py:262-282  -- align_corners=True: sample exactly at (x+u, y+v), border clamp
  * ---------------------------------------------------------------------------------------- */
-enum { VC_WARP_W1 = 1, VC_WARP_W2 = 2 };
+enum { VC_WARP_W1 = 1, VC_WARP_W2 = 2, VC_WARP_W3 = 3 };
 int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, vc_view out);
 
 /* SPyNet pre-processing (flow.py:39-45): NCHW frame -> normalised, channel-flipped NHWC level-0 image */

@@ -94,3 +94,25 @@ def test_codec_against_reference_bitstream(dev, models):
     print("flex byte-identical to the reference bitstream:", same, f"dPSNR={d_psnr:.2e}")
     assert d_psnr < 5e-3
     assert dec.min().item() >= -1.0  # residual path is clamped to [0,1] then added to the prediction
+
+
+def test_gop16_graph_replay_equals_eager(dev, models):
+    from vcamd import gop as vgop
+    _, prod = models
+    g = torch.Generator().manual_seed(11)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 136, 216, generator=g), 9, 1)   # 128x208
+    frames = [base[..., :128, i:i + 192].contiguous().to(dev) for i in range(17)]
+    quality = vgop.FLEX_QUALITIES[3]
+    with torch.no_grad():
+        rec_e = []
+        dec_e = vgop.code_gop_flex(prod, frames, frames[0], frames[16], 120, 180, quality, rec_e)
+        dec_e = {k: v.clone() for k, v in dec_e.items()}
+        runner = vgop.GopGraph(prod, 120, 180, kind="flex", quality=quality)
+        rec_g = []
+        runner.code(frames, records=rec_g)
+        dec_g = runner.code(frames)
+    assert len(rec_e) == len(rec_g) == 15
+    for k in range(1, 16):
+        assert torch.equal(dec_e[k], dec_g[k]), k
+    for a, b in zip(rec_e, rec_g):
+        assert a[:3] == b[:3] and float(a[3]) == float(b[3]) and float(a[4]) == float(b[4])

@@ -157,7 +157,17 @@ def test_upsample(dev, factor, align, c, h, w):
     _close(out, ref, 1e-6, "upsample")
 
 
-@pytest.mark.parametrize("convention", [1, 2])
+def _warp_w3(img, flow):
+    """ICIP2024/src/model/m.py:262-282 restated (the third warp convention of SURVEY Appendix B.5)."""
+    b, _, h, w = flow.shape
+    xx = torch.linspace(-1.0, 1.0, w).view(1, 1, 1, w).expand(b, -1, h, -1)
+    yy = torch.linspace(-1.0, 1.0, h).view(1, 1, h, 1).expand(b, -1, -1, w)
+    fl = torch.cat([flow[:, 0:1] / ((w - 1.0) / 2.0), flow[:, 1:2] / ((h - 1.0) / 2.0)], 1)
+    return F.grid_sample(img, (torch.cat([xx, yy], 1) + fl).permute(0, 2, 3, 1), mode="bilinear",
+                         padding_mode="border", align_corners=True)
+
+
+@pytest.mark.parametrize("convention", [1, 2, 3])
 def test_warp(dev, convention):
     from oracle.flex import warp_w2
     from oracle.lhbdc import warp_w1
@@ -166,9 +176,29 @@ def test_warp(dev, convention):
     flow = _rand((2, 2, 40, 56), 15, 4.0)
     flow[:, :, :4, :4] = 100.0     # far out of range: border clamp / zero padding
     flow[:, :, -4:, -4:] = -100.0
-    ref = warp_w1(img, flow) if convention == 1 else warp_w2(img, flow)
+    ref = {1: warp_w1, 2: warp_w2, 3: _warp_w3}[convention](img, flow)
     out = hip.nhwc_to_nchw(hip.warp(convention, hip.nchw_to_nhwc(img.to(dev)), hip.nchw_to_nhwc(flow.to(dev))))
     _close(out, ref, 2e-5, f"warp W{convention}")
+
+
+@pytest.mark.parametrize("convention", [1, 2, 3])
+def test_warp_extreme_displacements(dev, convention):
+    """random-weight flow predictors emit absurd displacements: 1e4 .. 1e30, inf -- must stay in bounds and
+    agree with grid_sample (border clamp / zeros)"""
+    from oracle.flex import warp_w2
+    from oracle.lhbdc import warp_w1
+    from vcamd import hip
+    img = torch.rand(1, 3, 24, 40, generator=torch.Generator().manual_seed(24))
+    flow = torch.zeros(1, 2, 24, 40)
+    vals = torch.tensor([1e4, -1e4, 3e9, -3e9, 1e20, -1e20, 1e30, -1e30, float("inf"), -float("inf")])
+    flow[0, 0, :10, 0] = vals
+    flow[0, 1, :10, 1] = vals
+    flow[0, :, :10, 2] = vals
+    ref = {1: warp_w1, 2: warp_w2, 3: _warp_w3}[convention](img, flow)
+    out = hip.nhwc_to_nchw(hip.warp(convention, hip.nchw_to_nhwc(img.to(dev)), hip.nchw_to_nhwc(flow.to(dev)))).cpu()
+    finite = torch.isfinite(ref)
+    assert torch.isfinite(out).all()
+    assert ((out - ref).abs()[finite] < 2e-5).all()
 
 
 @pytest.mark.parametrize("h,w", [(64, 96), (70, 100), (192, 256)])

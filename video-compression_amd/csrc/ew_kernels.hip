@@ -237,18 +237,28 @@ __device__ __forceinline__ float grid_coord(int convention, int i, float d, int 
         const float g = linspace_at(-1.0f + inv, 1.0f - inv, size_flow, i);
         return g + d / (((float)size_img - 1.0f) / 2.0f);
     }
+    if (convention == VC_WARP_W3) {                    // ICIP2024 m.py:262-282: linspace(-1,1) grid
+        const float g = linspace_at(-1.0f, 1.0f, size_flow, i);
+        return g + d / (((float)size_flow - 1.0f) / 2.0f);
+    }
     const float x = (float)i + d;                      // W2: b_model.py:104-109
     return 2.0f * (x / (float)size_img - 0.5f);
 }
 
 __device__ __forceinline__ float sample_bilinear(const float *img, long long sh, long long sw, int H, int W,
-                                                 float gx, float gy, bool border)
+                                                 float gx, float gy, bool border, bool align_corners = false)
 {
-    float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;  // grid_sampler_unnormalize, align_corners=False
-    float iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    // grid_sampler_unnormalize: align_corners=False -> ((g+1)*size-1)/2 ; True -> (g+1)/2*(size-1)
+    float ix = align_corners ? ((gx + 1.0f) / 2.0f) * (float)(W - 1) : ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+    float iy = align_corners ? ((gy + 1.0f) / 2.0f) * (float)(H - 1) : ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
     if (border) {
         ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));
         iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+    } else {
+        // zeros padding: anything beyond one pixel outside samples nothing; clamping there keeps the
+        // float->int conversion defined for huge / infinite / NaN displacements (NaN -> -2 -> zeros)
+        ix = fminf(fmaxf(ix, -2.0f), (float)W + 1.0f);
+        iy = fminf(fmaxf(iy, -2.0f), (float)H + 1.0f);
     }
     const float xw = floorf(ix), yn = floorf(iy);
     const float w = ix - xw, e = 1.0f - w, n = iy - yn, s_ = 1.0f - n;
@@ -274,14 +284,15 @@ __global__ void k_warp(int convention, vc_view img, vc_view flow, vc_view out)
         const float gx = grid_coord(convention, x, f[0], flow.w, img.w);
         const float gy = grid_coord(convention, y, f[1], flow.h, img.h);
         out.p[view_off(out, n, y, x) + c] =
-            sample_bilinear(img.p + (long long)n * img.sn + c, img.sh, img.sw, img.h, img.w, gx, gy, convention == VC_WARP_W1);
+            sample_bilinear(img.p + (long long)n * img.sn + c, img.sh, img.sw, img.h, img.w, gx, gy,
+                            convention != VC_WARP_W2, convention == VC_WARP_W3);
     }
 }
 
 extern "C" int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, vc_view out)
 {
     if (!img.p || !flow.p || !out.p) return VC_EINVAL;
-    if (convention != VC_WARP_W1 && convention != VC_WARP_W2) return VC_EINVAL;
+    if (convention != VC_WARP_W1 && convention != VC_WARP_W2 && convention != VC_WARP_W3) return VC_EINVAL;
     if (flow.c < 2 || out.c > img.c || out.h != flow.h || out.w != flow.w || img.n != out.n || flow.n != out.n) return VC_EINVAL;
     const long long total = (long long)out.n * out.h * out.w * out.c;
     hipLaunchKernelGGL(k_warp, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);

@@ -249,26 +249,32 @@ class BidirFlowRef(nn.Module):
         return (hip.nhwc_to_nchw(buf.channels(0, 2)), hip.nhwc_to_nchw(buf.channels(2, 4)),
                 hip.nhwc_to_nchw(buf.channels(0, 16)))
 
-    def forward(self, x_before, x_current, x_after, n=None, l=1, train=False):
-        if train:
-            raise NotImplementedError("training-mode (noise) quantisation is outside the inference hot path")
+    def forward_device(self, x_before, x_current, x_after, n=None, l=1):
+        """Batch-1 B-frame path with no host synchronisation (graph-capturable): (x_hat, bits[4] float64
+        device tensor = flow.y, flow.z, res.y, res.z)."""
         for t in (x_before, x_current, x_after):
             _require_cuda(t)
-        if x_current.shape[0] != 1:   # per-item sizes: run items one by one (the reference harness uses batch 1)
-            outs = [self.forward(x_before[i:i + 1], x_current[i:i + 1], x_after[i:i + 1], n, l, train)
-                    for i in range(x_current.shape[0])]
-            return {k: torch.cat([o[k] for o in outs], 0) for k in ("x_hat", "size", "rate")}
+        if x_current.shape[0] != 1:
+            raise hip.VcError("forward_device codes one frame at a time")
         xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
-        _, _, h, w = xc_.shape
-        num_pixels = h * w
         dev = xc_.device
         buf = self._process_t(xb_, xa_, xc_)
         bits = BitCounter(dev)
         flow_hat = self.flow_compressor.forward_t(buf, bits, self.flow_compressor.gains(n, l))
         pred, resid = self._compensate_t(buf, flow_hat, cur=buf.channels(16, 19))
         res_hat = self.residual_compressor.forward_t(resid, bits, self.residual_compressor.gains(n, l))
-        x_hat = hip.nhwc_to_nchw(hip.axpby(pred, res_hat))
-        size = bits.totals().sum().reshape(1)
+        return hip.nhwc_to_nchw(hip.axpby(pred, res_hat)), bits.totals()
+
+    def forward(self, x_before, x_current, x_after, n=None, l=1, train=False):
+        if train:
+            raise NotImplementedError("training-mode (noise) quantisation is outside the inference hot path")
+        if x_current.shape[0] != 1:   # per-item sizes: run items one by one (the reference harness uses batch 1)
+            outs = [self.forward(x_before[i:i + 1], x_current[i:i + 1], x_after[i:i + 1], n, l, train)
+                    for i in range(x_current.shape[0])]
+            return {k: torch.cat([o[k] for o in outs], 0) for k in ("x_hat", "size", "rate")}
+        x_hat, tot = self.forward_device(x_before, x_current, x_after, n, l)
+        num_pixels = x_current.shape[2] * x_current.shape[3]
+        size = tot.sum().reshape(1)
         return {"x_hat": x_hat, "size": size.to(torch.float32), "rate": (size / num_pixels).to(torch.float32)}
 
 

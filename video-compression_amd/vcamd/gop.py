@@ -15,6 +15,20 @@ DECODING_INFO = {4: (0, 8), 2: (0, 4), 1: (0, 2), 3: (2, 4), 6: (4, 8), 5: (4, 6
 HIER_LEVELS = {4: 0, 2: 1, 1: 2, 3: 2, 6: 1, 5: 2, 7: 2}       # :74
 
 
+# Flex-Rate GOP-16 (Flex-Rate.../test/testing.py:71-89)
+CODING_ORDER_16 = [0, 16, 8, 4, 2, 1, 3, 6, 5, 7, 12, 10, 9, 11, 14, 13, 15]
+DECODING_INFO_16 = {8: (0, 16), 4: (0, 8), 2: (0, 4), 1: (0, 2), 3: (2, 4), 6: (4, 8), 5: (4, 6), 7: (6, 8),
+                    12: (8, 16), 10: (8, 12), 9: (8, 10), 11: (10, 12), 14: (12, 16), 13: (12, 14), 15: (14, 16)}
+HIER_LEVELS_16 = {8: 0, 4: 1, 2: 2, 1: 3, 3: 3, 6: 2, 5: 3, 7: 3, 12: 1, 10: 2, 9: 3, 11: 3, 14: 2, 13: 3, 15: 3}
+# (I-frame quality, {hierarchy level: (n, l)}) -- the 8 operating points of the published curve (:86-89)
+FLEX_QUALITIES = [
+    (5, {0: (1, 1.0), 1: (0, 0.33), 2: (0, 0.66), 3: (0, 1.0)}), (6, {0: (1, 0.66), 1: (1, 1.0), 2: (0, 0.33), 3: (0, 0.66)}),
+    (6, {0: (1, 0.33), 1: (1, 0.66), 2: (1, 1.0), 3: (0, 0.33)}), (6, {0: (2, 1.0), 1: (1, 0.33), 2: (1, 0.66), 3: (1, 1.0)}),
+    (7, {0: (2, 0.66), 1: (2, 1.0), 2: (1, 0.33), 3: (1, 0.66)}), (7, {0: (2, 0.33), 1: (2, 0.66), 2: (2, 1.0), 3: (1, 0.33)}),
+    (7, {0: (3, 1.0), 1: (2, 0.33), 2: (2, 0.66), 3: (2, 1.0)}), (8, {0: (3, 1.0), 1: (3, 1.0), 2: (2, 0.33), 3: (2, 0.66)}),
+]
+
+
 def psnr_uint8(x_hat, x, h, w):
     """testing.py:176-182 / utils.py:32-51: PSNR of round(clip(.,0,1)*255) on the un-padded crop."""
     a = torch.round(torch.clamp(x_hat[0, :, :h, :w], 0, 1) * 255.0).double()
@@ -39,16 +53,35 @@ def code_gop_lhbdc(model, gop, dec_first, dec_last, h, w, records=None, video=0,
     return decoded
 
 
+def code_gop_flex(model, gop, dec_first, dec_last, h, w, quality, records=None, video=0, gop_index=0):
+    """Code the 15 B-frames of one GOP-16 with the per-hierarchy-level (n, l) of ``quality`` (an entry of
+    FLEX_QUALITIES or a plain {level: (n, l)} dict), like Flex-Rate.../test/testing.py:192-201."""
+    table = quality[1] if isinstance(quality, tuple) else quality
+    decoded = {0: dec_first, 16: dec_last}
+    for order in CODING_ORDER_16[2:]:
+        r0, r1 = DECODING_INFO_16[order]
+        n, l = table[HIER_LEVELS_16[order]]
+        x_hat, tot = model.forward_device(decoded[r0], gop[order], decoded[r1], n=[n], l=l)
+        decoded[order] = x_hat
+        if records is not None:
+            records.append((video, gop_index * 16 + order, HIER_LEVELS_16[order], psnr_uint8(x_hat, gop[order], h, w),
+                            tot.sum(), float(h * w)))
+    return decoded
+
+
 class GopGraph:
-    """One GOP-8 of B-frame coding captured ONCE as a HIP graph and replayed per GOP.
+    """One GOP of B-frame coding captured ONCE as a HIP graph and replayed per GOP.
 
-    The per-frame path is ~200 kernel launches issued from Python; at ~100 ms of GPU work per 1080p frame
-    the launch gaps cost ~10 %.  Every kernel of libvc_hip.so launches on the caller's stream without
-    synchronising or allocating, so the whole 7-frame dependency chain captures into one graph
-    (static input slots for the 9 frames; intermediates live in the graph's private pool)."""
+    The per-frame path is ~200 kernel launches issued from Python.  Every kernel of libvc_hip.so launches
+    on the caller's stream without synchronising or allocating, so the whole dependency chain of a GOP
+    (7 B-frames for LHBDC GOP-8, 15 for Flex GOP-16) captures into one graph: static input slots for the
+    frames, intermediates in the graph's private pool, per-frame PSNR/bits left in static device tensors."""
 
-    def __init__(self, model, h, w, video=0):
-        self.model, self.h, self.w, self.video = model, h, w, video
+    def __init__(self, model, h, w, video=0, kind="lhbdc", quality=None):
+        self.model, self.h, self.w, self.video, self.kind, self.quality = model, h, w, video, kind, quality
+        self.orders = CODING_ORDER[2:] if kind == "lhbdc" else CODING_ORDER_16[2:]
+        self.levels = HIER_LEVELS if kind == "lhbdc" else HIER_LEVELS_16
+        self.span = 8 if kind == "lhbdc" else 16
         self.graph = None
         self.static_in = None
         self.out_psnr = self.out_bits = None
@@ -56,13 +89,16 @@ class GopGraph:
 
     def _run(self, frames):
         recs = []
-        dec = code_gop_lhbdc(self.model, frames, frames[0], frames[8], self.h, self.w, recs, self.video, 0)
+        if self.kind == "lhbdc":
+            dec = code_gop_lhbdc(self.model, frames, frames[0], frames[8], self.h, self.w, recs, self.video, 0)
+        else:
+            dec = code_gop_flex(self.model, frames, frames[0], frames[16], self.h, self.w, self.quality, recs, self.video, 0)
         psnr = torch.stack([r[3] for r in recs])
         bits = torch.stack([r[4] for r in recs])
         return dec, psnr, bits
 
     def code(self, frames, gop_index=0, records=None):
-        """frames: list of 9 padded NCHW device tensors (boundary frames taken as decoded I-frames)."""
+        """frames: the GOP's padded NCHW device tensors (boundary frames taken as decoded I-frames)."""
         if self.graph is None:
             self.static_in = [f.clone() for f in frames]
             with torch.no_grad():
@@ -77,8 +113,8 @@ class GopGraph:
                 dst.copy_(src)
         self.graph.replay()
         if records is not None:
-            for i, order in enumerate(CODING_ORDER[2:]):
-                records.append((self.video, gop_index * 8 + order, HIER_LEVELS[order], self.out_psnr[i].clone(),
+            for i, order in enumerate(self.orders):
+                records.append((self.video, gop_index * self.span + order, self.levels[order], self.out_psnr[i].clone(),
                                 self.out_bits[i].clone(), float(self.h * self.w)))
         return self.decoded
 

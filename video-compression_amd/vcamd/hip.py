@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_CLAMP01 = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GDN, EPI_IGDN = 0, 1, 2
 IN_NONE, IN_SQUARE = 0, 1
 OUT_PLAIN, OUT_PIXELSHUFFLE2 = 0, 1
-WARP_W1, WARP_W2 = 1, 2
+WARP_W1, WARP_W2, WARP_W3 = 1, 2, 3
 EB_PARAMS_PER_CHANNEL = 60
 
 _ERR = {-1: "VC_EINVAL (bad argument / unsupported shape)", -2: "VC_ELAUNCH (HIP launch failure)",
@@ -146,9 +146,17 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+DEBUG_SYNC = bool(int(os.environ.get("VC_DEBUG_SYNC", "0")))   # synchronise after every launch to localise a fault
+
+
 def check(rc, what):
     if rc != VC_OK:
         raise VcError(f"{what} failed: {_ERR.get(rc, rc)}")
+    if DEBUG_SYNC:
+        try:
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            raise VcError(f"device fault during {what}: {e}") from e
 
 
 def stream():
