@@ -122,9 +122,16 @@ def test_gop_graph_replay_equals_eager(dev, models):
     base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 200, 280, generator=g), 9, 1)   # 192x272
     frames = [base[..., :192, i:i + 256].contiguous().to(dev) for i in range(9)]
     with torch.no_grad():
+        rec_s = []
+        dec_s = vgop.code_gop_lhbdc(prod, frames, frames[0], frames[8], 180, 250, rec_s, batch_levels=False)
         rec_e = []
         dec_e = vgop.code_gop_lhbdc(prod, frames, frames[0], frames[8], 180, 250, rec_e)
         dec_e = {k: v.clone() for k, v in dec_e.items()}
+        # level-batched passes == frame-by-frame passes, bit for bit
+        for k in range(1, 8):
+            assert torch.equal(dec_s[k], dec_e[k]), k
+        for a, b in zip(rec_s, rec_e):
+            assert a[:3] == b[:3] and float(a[3]) == float(b[3]) and float(a[4]) == float(b[4])
         runner = vgop.GopGraph(prod, 180, 250)
         rec_g = []
         runner.code(frames, records=rec_g)

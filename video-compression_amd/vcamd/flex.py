@@ -165,7 +165,8 @@ class _GainedCodec(MeanScaleHyperprior):
         bits = BitCounter(x.device)
         x_hat = self.forward_t(hip.nchw_to_nhwc(x), bits, self.gains(n, l))
         tot = bits.totals()
-        return {"x_hat": hip.nhwc_to_nchw(x_hat), "bits": {"y": tot[0], "z": tot[1]}}
+        tot = tot.view(-1, 2)       # rows are (y, z) per image; the reference sums over the whole batch
+        return {"x_hat": hip.nhwc_to_nchw(x_hat), "bits": {"y": tot[:, 0].sum(), "z": tot[:, 1].sum()}}
 
     def compress(self, x, n, l):
         _require_cuda(x)
@@ -263,7 +264,7 @@ class BidirFlowRef(nn.Module):
         flow_hat = self.flow_compressor.forward_t(buf, bits, self.flow_compressor.gains(n, l))
         pred, resid = self._compensate_t(buf, flow_hat, cur=buf.channels(16, 19))
         res_hat = self.residual_compressor.forward_t(resid, bits, self.residual_compressor.gains(n, l))
-        return hip.nhwc_to_nchw(hip.axpby(pred, res_hat)), bits.totals()
+        return hip.nhwc_to_nchw(hip.axpby(pred, res_hat)), bits.totals().view(1, 4)
 
     def forward(self, x_before, x_current, x_after, n=None, l=1, train=False):
         if train:

@@ -37,19 +37,34 @@ def psnr_uint8(x_hat, x, h, w):
     return 10.0 * torch.log10(255.0 ** 2 / mse)
 
 
-def code_gop_lhbdc(model, gop, dec_first, dec_last, h, w, records=None, video=0, gop_index=0):
+LEVEL_GROUPS = [[4], [2, 6], [1, 3, 5, 7]]                    # frames of one hierarchy level are independent
+
+
+def code_gop_lhbdc(model, gop, dec_first, dec_last, h, w, records=None, video=0, gop_index=0, batch_levels=True):
     """Code the 7 B-frames of one GOP-8.  ``gop``: list of 9 NCHW frames (padded), ``dec_first`` /
     ``dec_last``: decoded boundary frames.  Appends (video, frame, level, psnr, bits, pixels) to
-    ``records`` (psnr and bits stay device scalars: no host sync inside the GOP) and returns the
-    decoded dict."""
+    ``records`` in the reference's coding order (psnr and bits stay device scalars: no host sync inside
+    the GOP) and returns the decoded dict.
+
+    ``batch_levels``: the frames of one hierarchy level ({4}, {2,6}, {1,3,5,7}) depend only on already
+    decoded levels, so each level runs as ONE batched pass (1, 2, 4 frames) through the same kernels --
+    identical per-frame arithmetic, but the small feature maps of the hyper-networks / MV codec / coarse
+    SPyNet levels get 2-4x more workgroups and the big layers lose their partial last wave."""
     decoded = {0: dec_first, 8: dec_last}
-    for order in CODING_ORDER[2:]:
-        r0, r1 = DECODING_INFO[order]
-        x_hat, tot = model.forward_device(decoded[r0], gop[order], decoded[r1])
-        decoded[order] = x_hat
-        if records is not None:
-            records.append((video, gop_index * 8 + order, HIER_LEVELS[order], psnr_uint8(x_hat, gop[order], h, w),
-                            tot.sum(), float(h * w)))
+    stats = {}
+    groups = LEVEL_GROUPS if batch_levels else [[o] for o in CODING_ORDER[2:]]
+    for group in groups:
+        xb = torch.cat([decoded[DECODING_INFO[o][0]] for o in group], 0)
+        xc = torch.cat([gop[o] for o in group], 0)
+        xa = torch.cat([decoded[DECODING_INFO[o][1]] for o in group], 0)
+        x_hat, tot = model.forward_device(xb, xc, xa)
+        for i, o in enumerate(group):
+            decoded[o] = x_hat[i:i + 1]
+            stats[o] = tot[i].sum()
+    if records is not None:
+        for order in CODING_ORDER[2:]:
+            records.append((video, gop_index * 8 + order, HIER_LEVELS[order],
+                            psnr_uint8(decoded[order], gop[order], h, w), stats[order], float(h * w)))
     return decoded
 
 

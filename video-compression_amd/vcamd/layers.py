@@ -363,7 +363,7 @@ class BitCounter:
     """Device-side accumulation of -log2(likelihood) sums: one row of workgroup partials per entropy
     launch, folded by vc_bits_reduce; a single D2H copy at the very end of the frame."""
 
-    def __init__(self, device, max_rows=8):
+    def __init__(self, device, max_rows=16):
         self.slots = hip.lib().vc_bits_slots()
         self.partial = torch.zeros(max_rows * self.slots, dtype=torch.float64, device=device)
         self.out = torch.zeros(max_rows, dtype=torch.float64, device=device)
@@ -428,18 +428,21 @@ class MeanScaleHyperprior(_Prepared):
         y = run_sequential(self.g_a, x, self._cache["g_a"], final_chscale=g)      # gained y when g is set
         z = run_sequential(self.h_a, y, self._cache["h_a"])
         z_hat = T.empty(z.n, z.h, z.w, z.c, z.buf.device)
-        row_y = bits.next_row_ptr()
-        row_z = bits.next_row_ptr()
-        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
-                                  None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
-                                  z_hat.view(), None, row_z, bits.slots), "vc_eb_forward")
+        # one (y, z) pair of counter rows PER IMAGE, so a batch of independent frames keeps per-frame sizes
+        rows = [(bits.next_row_ptr(), bits.next_row_ptr()) for _ in range(z.n)]
+        for i in range(z.n):
+            hip.check(L.vc_eb_forward(hip.stream(), z.images(i, i + 1).view(), self.entropy_bottleneck.device_params().data_ptr(),
+                                      None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
+                                      z_hat.images(i, i + 1).view(), None, rows[i][1], bits.slots), "vc_eb_forward")
         gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
         y_hat = T.empty(y.n, y.h, y.w, y.c, y.buf.device)
-        hip.check(L.vc_gc_forward(hip.stream(), y.view(), scales.view(), means.view(), None,
-                                  None if ig is None else ig.data_ptr(), y_hat.view(), row_y, bits.slots,
-                                  None, None, None, None, 0), "vc_gc_forward")
+        for i in range(y.n):
+            hip.check(L.vc_gc_forward(hip.stream(), y.images(i, i + 1).view(), scales.images(i, i + 1).view(),
+                                      means.images(i, i + 1).view(), None, None if ig is None else ig.data_ptr(),
+                                      y_hat.images(i, i + 1).view(), rows[i][0], bits.slots,
+                                      None, None, None, None, 0), "vc_gc_forward")
         return run_sequential(self.g_s, y_hat, self._cache["g_s"])
 
     def _scale_table_dev(self):

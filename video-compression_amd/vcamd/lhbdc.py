@@ -135,7 +135,8 @@ class _LhbdcCodec(MeanScaleHyperprior):
         bits = BitCounter(x.device)
         x_hat = self.forward_t(hip.nchw_to_nhwc(x), bits)
         tot = bits.totals()
-        return {"x_hat": hip.nhwc_to_nchw(x_hat), "bits": {"y": tot[0], "z": tot[1]}}
+        tot = tot.view(-1, 2)       # rows are (y, z) per image; the reference sums over the whole batch
+        return {"x_hat": hip.nhwc_to_nchw(x_hat), "bits": {"y": tot[:, 0].sum(), "z": tot[:, 1].sum()}}
 
     def compress(self, x):
         _require_cuda(x)
@@ -273,8 +274,9 @@ class Model(nn.Module):
         return pred, resid
 
     def forward_device(self, x_before, x_current, x_after):
-        """The whole B-frame path with NO host synchronisation (graph-capturable): returns
-        (x_hat NCHW, bits) where bits is a float64 device tensor [4] = (mv.y, mv.z, res.y, res.z)."""
+        """The whole B-frame path with NO host synchronisation (graph-capturable) for a batch of n
+        independent frames: returns (x_hat NCHW [n,3,H,W], bits float64 device tensor [n, 4] =
+        per frame (mv.y, mv.z, res.y, res.z))."""
         for t in (x_before, x_current, x_after):
             _require_cuda(t)
         xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
@@ -290,13 +292,15 @@ class Model(nn.Module):
         diff = T.empty(n, flow_ba.h, flow_ba.w, 4, dev)
         hip.axpby(flow_cb, flow_ab, 1.0, -1.0, out=diff.channels(0, 2))      # m.py:52
         hip.axpby(flow_ca, flow_ba, 1.0, -1.0, out=diff.channels(2, 4))
-        bits = BitCounter(dev)
+        bits = BitCounter(dev, max_rows=4 * n)
         mv_hat = self.mv_compressor.forward_t(diff, bits)
         xb, xc, xa = hip.nchw_to_nhwc(xb_), hip.nchw_to_nhwc(xc_), hip.nchw_to_nhwc(xa_)
         pred, resid = self._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww, cur=xc)
         res_hat = self.residual_compressor.forward_t(resid, bits)
         x_hat = hip.nhwc_to_nchw(hip.axpby(res_hat, pred))                   # m.py:71
-        return x_hat, bits.totals()
+        # counter rows were appended as mv:(y,z) per image, then res:(y,z) per image
+        tot = bits.totals().view(2, n, 2).permute(1, 0, 2).reshape(n, 4)
+        return x_hat, tot
 
     def forward(self, x_before, x_current, x_after, train=False):
         x_hat, tot = self.forward_device(x_before, x_current, x_after)
