@@ -66,3 +66,51 @@ class MeanScaleHyperprior(CompressionModel):
         _resize_registered_buffers(self.gaussian_conditional, "gaussian_conditional",
                                    _CDF_BUFFERS + ("scale_table",), state_dict)
         return super().load_state_dict(state_dict, strict=strict)
+
+
+# ---------------------------------------------------------------------------------------------------
+# I-frame codec: compressai.zoo.mbt2018_mean = MeanScaleHyperprior(N, M) with its default networks
+# (used at LHBDC/test/testing.py:209).  PARITY UNPINNED like the rest of this package.
+# ---------------------------------------------------------------------------------------------------
+def _conv(i, o, kernel_size=5, stride=2):
+    return nn.Conv2d(i, o, kernel_size=kernel_size, stride=stride, padding=kernel_size // 2)
+
+
+def _deconv(i, o, kernel_size=5, stride=2):
+    return nn.ConvTranspose2d(i, o, kernel_size=kernel_size, stride=stride, output_padding=stride - 1,
+                              padding=kernel_size // 2)
+
+
+class ImageMeanScaleHyperprior(MeanScaleHyperprior):
+    def __init__(self, N, M, **kwargs):
+        from .layers import GDN
+        super().__init__(N, M, **kwargs)
+        self.g_a = nn.Sequential(_conv(3, N), GDN(N), _conv(N, N), GDN(N), _conv(N, N), GDN(N), _conv(N, M))
+        self.g_s = nn.Sequential(_deconv(M, N), GDN(N, inverse=True), _deconv(N, N), GDN(N, inverse=True),
+                                 _deconv(N, N), GDN(N, inverse=True), _deconv(N, 3))
+        self.h_a = nn.Sequential(_conv(M, N, stride=1, kernel_size=3), nn.LeakyReLU(inplace=True), _conv(N, N),
+                                 nn.LeakyReLU(inplace=True), _conv(N, N))
+        self.h_s = nn.Sequential(_deconv(N, M), nn.LeakyReLU(inplace=True), _deconv(M, M * 3 // 2),
+                                 nn.LeakyReLU(inplace=True), _conv(M * 3 // 2, M * 2, stride=1, kernel_size=3))
+
+    def compress(self, x):
+        y = self.g_a(x)
+        z = self.h_a(y)
+        z_strings = self.entropy_bottleneck.compress(z)
+        z_hat = self.entropy_bottleneck.decompress(z_strings, z.size()[-2:])
+        scales, means = self.h_s(z_hat).chunk(2, 1)
+        idx = self.gaussian_conditional.build_indexes(scales)
+        y_strings = self.gaussian_conditional.compress(y, idx, means=means)
+        return {"strings": [y_strings, z_strings], "shape": z.size()[-2:]}
+
+    def decompress(self, strings, shape):
+        z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
+        scales, means = self.h_s(z_hat).chunk(2, 1)
+        idx = self.gaussian_conditional.build_indexes(scales)
+        y_hat = self.gaussian_conditional.decompress(strings[0], idx, means=means)
+        return {"x_hat": self.g_s(y_hat).clamp_(0, 1)}
+
+
+def mbt2018_mean(quality, metric="mse", pretrained=False):
+    n, m = (128, 192) if quality <= 4 else (192, 320)
+    return ImageMeanScaleHyperprior(n, m)

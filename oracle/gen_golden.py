@@ -257,11 +257,45 @@ def gen_flex(outdir, frames, seed):
             decoded=dec_r.numpy())
 
 
+def gen_harness(outdir):
+    """G5: item lists of the reference's own UVGTestDataset (LHBDC/test/utils.py:162-203 and the Flex twin)
+    for synthetic directory listings -- natsort / imageio / glob are stubbed, the class body is the reference's."""
+    import json
+    fake = {"n": 0}
+    nat = types.ModuleType("natsort")
+    nat.natsorted = sorted
+    img = types.ModuleType("imageio")
+    img.imread = lambda path: np.zeros((1080, 1920, 3), dtype=np.uint8)
+    sys.modules["natsort"], sys.modules["imageio"] = nat, img
+    out = {}
+    for tag, rel in (("lhbdc", "LHBDC/test/utils.py"), ("flex", "Flex-Rate-Hier-Bidir-Video-Compression/test/utils.py")):
+        path = os.path.join(REF, rel)
+        tree = ast.parse(open(path).read(), filename=path)
+        keep = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) and
+                not any(a.name.split(".")[0] in ("matplotlib", "pandas", "compressai") for a in n.names) and
+                not (isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] in ("matplotlib", "pandas", "compressai"))]
+        keep += [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "UVGTestDataset"]
+        keep += [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("normalize", "pad")]
+        tree.body = keep
+        ns = {}
+        exec(compile(tree, path, "exec"), ns)
+        ns["glob"].glob = lambda pattern: [f"/v/im{i:05d}.png" for i in range(fake["n"])]
+        for n_frames in (17, 25, 600):
+            for gop in (8, 16):
+                for test_size in (2, 3, 0):
+                    fake["n"] = n_frames
+                    ds = ns["UVGTestDataset"]("/d/", ["v"], gop, 1, test_size)
+                    out[f"{tag}:{n_frames}:{gop}:{test_size}"] = [int(f[-9:-4]) for f in ds.frames]
+    with open(os.path.join(outdir, "uvg_dataset_indices.json"), "w") as f:
+        json.dump(out, f)
+    print("  harness fixture:", len(out), "listings")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--only", choices=["lhbdc", "flex"], default=None)
+    ap.add_argument("--only", choices=["lhbdc", "flex", "harness"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         raise SystemExit("/root/reference is not present: fixtures can only be generated in the build container")
@@ -275,6 +309,8 @@ def main():
         gen_lhbdc(args.out, frames, args.seed)
     if args.only in (None, "flex"):
         gen_flex(args.out, frames, args.seed)
+    if args.only in (None, "harness"):
+        gen_harness(args.out)
     print("fixtures written to", args.out)
 
 

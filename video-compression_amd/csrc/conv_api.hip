@@ -32,7 +32,7 @@ extern "C" int vc_conv_chunk(int cfg, int k, int stride, int cin)
     switch (k) {
     case 1: return 32;
     case 3: return stride == 2 ? 8 : 32;
-    case 5: return 16;
+    case 5: return stride == 2 ? 8 : 16;
     case 7: return (cfg == VC_CFG_N32 && cin <= 8) ? 8 : 16;
     }
     return -1;

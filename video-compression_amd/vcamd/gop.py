@@ -175,3 +175,91 @@ def summarize(rows):
         bits += r[4]
         pix += r[5]
     return {"frames": int(rows.shape[0]), "bpp": bits / pix, "psnr": ps / rows.shape[0]}
+
+
+# ------------------------------------------------------------------------------------------------------
+# Sequence-level evaluation (LHBDC/test/testing.py:89-196, test/utils.py:162-203,393-489)
+# ------------------------------------------------------------------------------------------------------
+def uvg_frame_indices(num_available, gop_size=8, test_size=2):
+    """Source-frame index of every dataset item, as UVGTestDataset builds its list (utils.py:181-188):
+    the first ``test_size*gop_size+1`` frames (all frames when ``test_size`` is falsy), with every interior
+    GOP-boundary frame listed twice so that consecutive batches of ``gop_size+1`` items are I-B...B-I."""
+    n = min(num_available, test_size * gop_size + 1) if test_size else num_available
+    out = []
+    for idx in range(n):
+        out.append(idx)
+        if idx % gop_size == 0 and idx != 0 and idx // gop_size != test_size:
+            out.append(idx)
+    return out
+
+
+def gop_batches(indices, gop_size=8):
+    """DataLoader(batch_size=gop_size+1, drop_last=True) over the item list (testing.py:117-120)."""
+    step = gop_size + 1
+    return [indices[i:i + step] for i in range(0, len(indices) - step + 1, step)]
+
+
+def code_sequence_lhbdc(b_model, i_model, load_frame, num_available, h, w, video=0, gop_size=8, test_size=2,
+                        gop_range=None, runner=None):
+    """testing.py:125-188 for one video: I-frame 0 once, I-frame at the end of every GOP, 7 B-frames between.
+    ``load_frame(idx)`` returns the padded NCHW device tensor of source frame ``idx``.  ``gop_range=(lo,hi)``
+    restricts to a shard of GOPs (multi-GPU): a shard that does not start at GOP 0 re-codes its first
+    boundary I-frame itself (intra frames do not depend on neighbours) but does not record it again.
+    Returns records (video, frame_num, level|-1 for I, psnr, bits, pixels, is_intra)."""
+    batches = gop_batches(uvg_frame_indices(num_available, gop_size, test_size), gop_size)
+    lo, hi = gop_range if gop_range is not None else (0, len(batches))
+    records = []
+
+    def intra(idx, record):
+        x = load_frame(idx)
+        x_hat, tot = i_model.forward_device(x)
+        if record:
+            records.append((video, idx, -1, psnr_uint8(x_hat, x, h, w), tot.sum(), float(h * w), 1))
+        return x_hat
+
+    dec_last = None
+    for g in range(lo, hi):
+        idxs = batches[g]
+        gop = [load_frame(i) for i in idxs]
+        dec_first = dec_last if dec_last is not None else intra(idxs[0], record=(g == 0))
+        dec_last = intra(idxs[-1], record=True)
+        recs = []
+        if runner is not None:
+            frames = [dec_first] + gop[1:-1] + [dec_last]
+            runner.code(frames, gop_index=g, records=recs)
+        else:
+            code_gop_lhbdc(b_model, gop, dec_first, dec_last, h, w, recs, video, g)
+        records.extend(r + (0,) for r in recs)
+    return records
+
+
+class RdTable:
+    """Aggregation of TestInfographic (utils.py:393-489) without pandas: PSNR = mean of per-frame PSNR,
+    bpp = sum(size)/sum(pixels), grouped like print_per_level / per_video_level / per_frame_type."""
+
+    def __init__(self):
+        self.rows = []   # (video, level, frame_num, frame_type, psnr, size, pixels)
+
+    def update(self, frame_type, frame_num, level, video, psnr, size, pixels):
+        self.rows.append((video, level, int(frame_num), frame_type, float(psnr), float(size), float(pixels)))
+
+    def extend_from_records(self, rows, level):
+        for r in rows:
+            intra = len(r) > 6 and int(r[6]) == 1
+            self.update("I" if intra else "B", r[1], level, int(r[0]), r[3], r[4], r[5])
+
+    def _group(self, key):
+        out = {}
+        for row in self.rows:
+            acc = out.setdefault(key(row), [0.0, 0.0, 0.0, 0])
+            acc[0] += row[4]; acc[1] += row[5]; acc[2] += row[6]; acc[3] += 1
+        return {k: {"psnr": v[0] / v[3], "bpp": v[1] / v[2], "frames": v[3]} for k, v in sorted(out.items())}
+
+    def per_level(self):
+        return self._group(lambda r: r[1])
+
+    def per_video_level(self):
+        return self._group(lambda r: (r[0], r[1]))
+
+    def per_level_frame_type(self):
+        return self._group(lambda r: (r[1], r[3]))

@@ -161,9 +161,36 @@ class ResidualBlock(_Prepared):
         return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity)
 
 
+def deconv_as_subpel_weights(deconv):
+    """ConvTranspose2d(k=5, stride=2, padding=2, output_padding=1) == conv3x3(pad 1) to 4*Cout channels +
+    PixelShuffle(2): output phase (dy,dx) only ever meets taps of matching parity, at most 3x3 of them.
+    With w_T[ci, co, ky, kx]:  W3[co*4 + dy*2 + dx, ci, jy, jx] = w_T[ci, co, 4-2*jy+dy, 4-2*jx+dx] (0 if > 4).
+    Lets the transposed convolutions of the I-frame codec run on the same MFMA kernel with the
+    pixel-shuffle store fused (36 tap slots for 25 taps)."""
+    if tuple(deconv.kernel_size) != (5, 5) or tuple(deconv.stride) != (2, 2) or tuple(deconv.padding) != (2, 2) \
+            or tuple(deconv.output_padding) != (1, 1):
+        raise hip.VcError("only ConvTranspose2d(k=5, s=2, p=2, output_padding=1) is supported")
+    wt = deconv.weight.detach().to("cpu", torch.float32)          # [cin, cout, 5, 5]
+    cin, cout = wt.shape[0], wt.shape[1]
+    w3 = torch.zeros(cout, 2, 2, cin, 3, 3)
+    for dy in range(2):
+        for dx in range(2):
+            for jy in range(3):
+                ky = 4 - 2 * jy + dy
+                if ky > 4:
+                    continue
+                for jx in range(3):
+                    kx = 4 - 2 * jx + dx
+                    if kx > 4:
+                        continue
+                    w3[:, dy, dx, :, jy, jx] = wt[:, :, ky, kx].t()
+    bias = None if deconv.bias is None else deconv.bias.detach().to("cpu", torch.float32).repeat_interleave(4)
+    return w3.reshape(cout * 4, cin, 3, 3), bias
+
+
 def run_sequential(seq, x, cache, final_chscale=None, final_act=None):
-    """Execute an nn.Sequential of {Conv2d, subpel Sequential, LeakyReLU, Residual*} on the HIP path.
-    A LeakyReLU following a convolution is fused into that convolution's epilogue."""
+    """Execute an nn.Sequential of {Conv2d, ConvTranspose2d, subpel Sequential, GDN, LeakyReLU, Residual*}
+    on the HIP path.  A LeakyReLU following a convolution is fused into that convolution's epilogue."""
     mods = list(seq)
     if cache.get("seq") is None:
         cache["seq"] = {}
@@ -176,13 +203,22 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None):
             x = m.run(x)
             i += 1
             continue
+        if isinstance(m, GDN):
+            x = m.run(x)
+            i += 1
+            continue
         is_subpel = isinstance(m, nn.Sequential)
         conv = m[0] if is_subpel else m
-        if not isinstance(conv, nn.Conv2d):
-            raise hip.VcError(f"unsupported layer in sequential: {type(m).__name__}")
         key = id(conv)
-        if key not in packed:
-            packed[key] = pack_conv(conv, pixelshuffle=is_subpel)
+        if isinstance(conv, nn.ConvTranspose2d):
+            if key not in packed:
+                w3, b3 = deconv_as_subpel_weights(conv)
+                packed[key] = hip.PackedConv(w3, b3, stride=1, pixelshuffle=True, device=conv.weight.device)
+        elif isinstance(conv, nn.Conv2d):
+            if key not in packed:
+                packed[key] = pack_conv(conv, pixelshuffle=is_subpel)
+        else:
+            raise hip.VcError(f"unsupported layer in sequential: {type(m).__name__}")
         act, slope = hip.ACT_NONE, 0.0
         if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
             act, slope = hip.ACT_LRELU, mods[i + 1].negative_slope
