@@ -214,6 +214,26 @@ def main():
             with open(args.kernel_table, "w") as f:
                 json.dump({k: v for k, v in ranked}, f, indent=1)
 
+        if not is_flex:
+            # ---- whole GOP as testing.py codes it: 1 I-frame (mbt2018_mean q7 architecture) + 7 B-frames ----
+            from vcamd import iframe
+            i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
+            i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=4321, conv_gain=0.8))
+            i_model = i_model.to(dev).eval()
+            with torch.no_grad():
+                def full_gop():
+                    dec_last, _ = i_model.forward_device(frames[8])
+                    return vgop.code_gop_lhbdc(model, frames, frames[0], dec_last, H, W)
+                full_gop()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    full_gop()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 2
+            result["full_gop"] = {"frames_per_s": 8.0 / dt, "ms_per_gop": 1000.0 * dt,
+                                  "what": "1 I-frame (mbt2018_mean q7 architecture, seeded) + 7 B-frames per GOP, eager launches"}
+
         # ---- CPU baseline: the oracle (PyTorch-CPU restatement, tensor-equal to the reference) ----
         if not args.no_cpu_baseline:
             from oracle import flex as oracle_flex

@@ -62,6 +62,10 @@ enum { VC_OUT_PLAIN = 0, VC_OUT_PIXELSHUFFLE2 = 1 };         /* nn.PixelShuffle(
 
 /* Tile configurations (output-channel block / MFMA shape).  Chosen by vc_conv_select_cfg. */
 enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3 };
+/* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
+ * same packed weights and produces bit-identical results); without it the library narrows the block for
+ * small feature maps by itself. */
+#define VC_CFG_EXACT 0x100
 
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */

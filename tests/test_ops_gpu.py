@@ -82,6 +82,18 @@ def test_conv2d(dev, cin, cout, k, stride, h, w, n, act, ps):
     _close(out, ref, 2e-5, f"conv {cin}->{cout} k{k} s{stride}")
 
 
+def test_tile_configs_are_bit_identical(dev):
+    """the autotuner may pick any 32-wide tile configuration: results must not depend on it"""
+    from vcamd import hip
+    x = hip.nchw_to_nhwc(_rand((1, 128, 40, 72), 31).to(dev))
+    pc = hip.PackedConv(_rand((128, 128, 3, 3), 32, 0.03), _rand((128,), 33, 0.1), device=dev)
+    outs = []
+    for cfg in (0, 1, 2):
+        pc.tuned = {(x.n, x.h, x.w): cfg | hip.CFG_EXACT}
+        outs.append(hip.nhwc_to_nchw(pc(x, act=hip.ACT_LRELU)))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_conv_residual_and_channel_slices(dev):
     """residual add + reading/writing channel slices of wider buffers (concat-free U-Net plumbing)"""
     from vcamd import hip

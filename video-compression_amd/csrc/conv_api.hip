@@ -95,7 +95,7 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     if (!d || !d->in.p || !d->out.p || !d->wpk || !d->bias) return VC_EINVAL;
     if (d->kh != d->kw) return VC_EINVAL;
     const int k = d->kh, st = d->stride;
-    const int ck = vc_conv_chunk(d->cfg, k, st, d->in.c);
+    const int ck = vc_conv_chunk(d->cfg & 0xff, k, st, d->in.c);
     if (ck <= 0) return VC_EINVAL;
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -125,8 +125,9 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     // leave most of the 256 CUs idle while each block walks the whole K loop alone.  The 32-wide MFMA
     // configurations share one packed-weight layout, so drop to a narrower channel block (more blocks,
     // shorter serial chain) until the launch can fill the chip twice over.
-    int cfg = d->cfg;
-    while ((cfg == VC_CFG_N128 || cfg == VC_CFG_N64) &&
+    int cfg = d->cfg & 0xff;
+    const bool exact = (d->cfg & VC_CFG_EXACT) != 0;   // caller (autotuner) pinned the tile configuration
+    while (!exact && (cfg == VC_CFG_N128 || cfg == VC_CFG_N64) &&
            (long long)a.tiles_x * a.tiles_y * a.N * (round_up(a.Cout, cfg_bn(cfg)) / cfg_bn(cfg)) < 512 &&
            vc_conv_chunk(cfg + 1, k, st, d->in.c) == ck)
         ++cfg;

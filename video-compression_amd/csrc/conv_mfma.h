@@ -100,7 +100,7 @@ template <int KH, int KW, int S, int CK, class C> struct ConvGeom {
     static constexpr int KS = Mfma<C::MT>::KS;
     static constexpr int KSTEPS = CK / KS;
     static_assert(CK % KS == 0, "chunk must be a whole number of k-steps");
-    static_assert(LDS_FLOATS * 4 <= 65536, "keep two workgroups per CU");
+    static_assert(LDS_FLOATS * 4 + 16 <= 65536, "keep two workgroups per CU");
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
@@ -120,7 +120,7 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
     constexpr int C4 = CK / 4;
     constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
     constexpr int IPT = (ITEMS + 255) / 256;                    // items per thread
-    constexpr int BATCH = 4;                                    // 4 x 16 B in flight per lane per round
+    constexpr int BATCH = (IPT + 1) / 2 > 8 ? 8 : (IPT + 1) / 2;   // two rounds per chunk when registers allow
 #pragma unroll
     for (int b0 = 0; b0 < IPT; b0 += BATCH) {
         f32x4 v[BATCH];
@@ -139,7 +139,9 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
             ok[j] = (idx < ITEMS) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin;
             const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
             const int pos = (G::LS == 2) ? ((col & 1) * G::HALF + (col >> 1)) : col;
-            dst[j] = (idx < ITEMS) ? (row * G::COLS_L + pos) * G::CKP + c4 * 4 : -1;
+            // items past the end of the footprint (last round only) go to a 16-byte dump slot behind the tile:
+            // no branch anywhere in the staging code, so every round's loads issue back to back
+            dst[j] = (idx < ITEMS) ? (row * G::COLS_L + pos) * G::CKP + c4 * 4 : G::LDS_FLOATS;
             const float *src = in_img + (long long)iyc * p.in_sh + (long long)ixc * p.in_sw;
             if (VEC) {
                 v[j] = *reinterpret_cast<const f32x4 *>(src + min(ch, p.Cin - 4));
@@ -161,7 +163,7 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
             if (p.in_xform == VC_IN_SQUARE) w = w * w;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             w = ok[j] ? w : z;
-            if (dst[j] >= 0) *reinterpret_cast<f32x4 *>(&lds[dst[j]]) = w;
+            *reinterpret_cast<f32x4 *>(&lds[dst[j]]) = w;
         }
     }
 }
@@ -331,7 +333,7 @@ template <int KH, int KW, int S, int CK, class C> int launch_conv(hipStream_t st
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, S, CK, C>), dim3(a.total_blocks), dim3(256),
-                       G::LDS_FLOATS * sizeof(float), st, a);
+                       (G::LDS_FLOATS + 4) * sizeof(float), st, a);   // + the staging dump slot
     return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
 }
 

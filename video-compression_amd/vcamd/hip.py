@@ -223,8 +223,17 @@ def nhwc_to_nchw(t):
 # ------------------------------------------------------------------------------------------------
 # convolution
 # ------------------------------------------------------------------------------------------------
+CFG_EXACT = 0x100
+AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
+
+
 class PackedConv:
-    """Weights of one nn.Conv2d re-laid out for the MFMA kernel (done once per model load)."""
+    """Weights of one nn.Conv2d re-laid out for the MFMA kernel (done once per model load).
+
+    The three 32-wide tile configurations (128/64/32 output channels per workgroup) read the same packed
+    weights and give bit-identical results; which one is fastest depends on how the launch quantises over
+    256 CUs (tail effects), so the first eager call per input shape times the candidates on the device and
+    keeps the winner (never during graph capture)."""
 
     def __init__(self, weight, bias, stride=1, pixelshuffle=False, device=None):
         L = lib()
@@ -245,6 +254,31 @@ class PackedConv:
               "vc_conv_pack_weights")
         self.wpk = torch.from_numpy(wpk).to(device)
         self.bias = torch.from_numpy(bpk).to(device)
+        self.tuned = {}
+        ck = L.vc_conv_chunk(self.cfg, kh, stride, cin)
+        self.candidates = [c for c in range(self.cfg, 3) if L.vc_conv_chunk(c, kh, stride, cin) == ck] if self.cfg <= 2 else []
+
+    def _pick_cfg(self, d, key):
+        if key in self.tuned:
+            return self.tuned[key]
+        if not AUTOTUNE or len(self.candidates) < 2 or torch.cuda.is_current_stream_capturing():
+            return self.cfg
+        best, best_ms = self.cfg, float("inf")
+        for c in self.candidates:
+            d.cfg = c | CFG_EXACT
+            if lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)) != VC_OK:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                lib().vc_conv2d_nhwc(stream(), ctypes.byref(d))
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            if ms < best_ms:
+                best, best_ms = c, ms
+        self.tuned[key] = best | CFG_EXACT
+        return self.tuned[key]
 
     def out_shape(self, h, w):
         k, s = self.k, self.stride
@@ -271,6 +305,7 @@ class PackedConv:
         d.epi, d.in_xform = epi, in_xform
         d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
         d.cfg = self.cfg
+        d.cfg = self._pick_cfg(d, (x.n, x.h, x.w))
         what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})"
         if timer is None:
             check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
