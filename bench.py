@@ -200,6 +200,16 @@ def main():
                               "launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
                               "share_of_conv_time": dom["ms"] / total_ms,
                               "algorithmic_flop_per_launch": per_launch_flop}
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/r01/traffic.json:
+        # FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 correction)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
+                tr = json.load(f)["kernels"].get(key)
+            if tr:
+                result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc, separate passes)"
+        except (OSError, KeyError, ValueError):
+            pass
         ns = [kv for kv in ranked if kv[0].startswith("conv k3 s1 128->128 @1x544x960")]
         if ns:
             v = ns[0][1]
