@@ -104,9 +104,36 @@ __global__ void k_maxpool2(vc_view in, vc_view out)
     }
 }
 
+__global__ void k_maxpool2_v4(vc_view in, vc_view out)
+{
+    const int c4n = out.c >> 2;
+    const long long total = (long long)out.n * out.h * out.w * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long long t = i / c4n;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        const float *p = in.p + view_off(in, n, 2 * y, 2 * x) + c;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p), b = *reinterpret_cast<const f32x4 *>(p + in.sw);
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(p + in.sh), e = *reinterpret_cast<const f32x4 *>(p + in.sh + in.sw);
+        f32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(d[k], e[k]));
+        *reinterpret_cast<f32x4 *>(out.p + view_off(out, n, y, x) + c) = r;
+    }
+}
+
 extern "C" int vc_maxpool2(vc_stream s, vc_view in, vc_view out)
 {
     if (!in.p || !out.p || in.c != out.c || in.n != out.n || out.h != in.h / 2 || out.w != in.w / 2) return VC_EINVAL;
+    if (((in.c % 4) == 0 && (in.sw % 4) == 0 && (in.sh % 4) == 0 && (in.sn % 4) == 0 && ((uintptr_t)in.p % 16) == 0) &&
+        ((out.sw % 4) == 0 && (out.sh % 4) == 0 && (out.sn % 4) == 0 && ((uintptr_t)out.p % 16) == 0)) {
+        const long long total4 = (long long)out.n * out.h * out.w * (out.c / 4);
+        hipLaunchKernelGGL(k_maxpool2_v4, dim3(ew_grid(total4, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out);
+        VC_LAUNCH_CHECK();
+        return VC_OK;
+    }
     const long long total = (long long)out.n * out.h * out.w * out.c;
     hipLaunchKernelGGL(k_maxpool2, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out);
     VC_LAUNCH_CHECK();
@@ -156,10 +183,48 @@ __global__ void k_upsample_bilinear(vc_view in, vc_view out, int factor, int ali
     }
 }
 
+// 4 channels per lane (16-byte loads/stores) when the views allow it: the U-Net up-sampling layers move
+// hundreds of MB per call and are purely HBM-bound
+__global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int align_corners, float scale)
+{
+    const int c4n = out.c >> 2;
+    const long long total = (long long)out.n * out.h * out.w * c4n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        long long t = i / c4n;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        bilinear_src(y, in.h, out.h, factor, align_corners, y0, y1, ly0, ly1);
+        bilinear_src(x, in.w, out.w, factor, align_corners, x0, x1, lx0, lx1);
+        const float *b = in.p + (long long)n * in.sn + c;
+        const f32x4 v00 = *reinterpret_cast<const f32x4 *>(b + (long long)y0 * in.sh + (long long)x0 * in.sw);
+        const f32x4 v01 = *reinterpret_cast<const f32x4 *>(b + (long long)y0 * in.sh + (long long)x1 * in.sw);
+        const f32x4 v10 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x0 * in.sw);
+        const f32x4 v11 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x1 * in.sw);
+        const f32x4 v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        *reinterpret_cast<f32x4 *>(out.p + view_off(out, n, y, x) + c) = v * scale;
+    }
+}
+
+static inline bool view_vec4(const vc_view &v)
+{
+    return (v.c % 4) == 0 && (v.sw % 4) == 0 && (v.sh % 4) == 0 && (v.sn % 4) == 0 && ((uintptr_t)v.p % 16) == 0;
+}
+
 extern "C" int vc_upsample_bilinear(vc_stream s, vc_view in, vc_view out, int factor, int align_corners, float scale)
 {
     if (!in.p || !out.p || factor < 1 || in.c != out.c || in.n != out.n) return VC_EINVAL;
     if (out.h != in.h * factor || out.w != in.w * factor) return VC_EINVAL;
+    if (view_vec4(in) && view_vec4(out)) {
+        const long long total4 = (long long)out.n * out.h * out.w * (out.c / 4);
+        hipLaunchKernelGGL(k_upsample_bilinear_v4, dim3(ew_grid(total4, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out,
+                           factor, align_corners, scale);
+        VC_LAUNCH_CHECK();
+        return VC_OK;
+    }
     const long long total = (long long)out.n * out.h * out.w * out.c;
     hipLaunchKernelGGL(k_upsample_bilinear, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out,
                        factor, align_corners, scale);
