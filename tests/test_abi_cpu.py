@@ -34,11 +34,11 @@ def test_library_is_in_tree():
 def _unpack(wpk, cfg, cout, cin, k, stride, ps):
     """inverse of the documented fragment layout [n-tile][tap][k-step][lane][4]"""
     L = hip.lib()
-    mt = 16 if cfg == 3 else 32
-    ks = 16 if mt == 16 else 8
+    mt = {3: 16, 4: 4}.get(cfg, 32)
+    ks = {3: 16, 4: 4}.get(cfg, 8)
     ck = L.vc_conv_chunk(cfg, k, stride, cin)
     cin_pad = -(-cin // ck) * ck
-    bn = {0: 128, 1: 64, 2: 32, 3: 16}[cfg]
+    bn = {0: 128, 1: 64, 2: 32, 3: 16, 4: 4}[cfg]
     cout_pad = -(-cout // bn) * bn
     arr = wpk.reshape(cout_pad // mt, k * k, cin_pad // ks, 64, 4)
     w = np.zeros((cout, cin, k, k), dtype=np.float32)
@@ -48,7 +48,7 @@ def _unpack(wpk, cfg, cout, cin, k, stride, ps):
         for ci in range(cin):
             kst, r = divmod(ci, ks)
             kk, e = divmod(r, 4)
-            lane = kk * mt + cop % mt
+            lane = kk * mt + cop % mt       # cfg 4: ks == 4 so kk == 0; lanes 4..63 replicate lanes 0..3
             w[co, ci] = arr[cop // mt, :, kst, lane, e].reshape(k, k)
     return w
 
@@ -65,7 +65,8 @@ def test_weight_packing_is_a_permutation_with_zero_padding():
         wpk = pc.wpk.numpy()
         assert wpk.size == L.vc_conv_packed_weight_floats(pc.cfg, cout, cin, k, k, stride)
         assert np.array_equal(_unpack(wpk, pc.cfg, cout, cin, k, stride, ps), w)
-        assert np.isclose(np.abs(wpk).sum(), np.abs(w).sum(), rtol=1e-5)        # padding is zeros
+        rep = 16 if pc.cfg == 4 else 1                                           # N4 replicates over the 16 MFMA blocks
+        assert np.isclose(np.abs(wpk).sum(), rep * np.abs(w).sum(), rtol=1e-5)   # padding is zeros
         bias = pc.bias.numpy()
         if ps:
             cps = cout // 4

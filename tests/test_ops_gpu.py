@@ -59,7 +59,10 @@ CONV_CASES = [
     (256, 128, 3, 1, 16, 32, 1, "relu", False),
     (6, 32, 3, 1, 32, 32, 1, "lrelu", False),      # Flex U-Net
     (512, 512, 3, 1, 8, 16, 1, "lrelu", False),
-    (32, 4, 3, 1, 32, 32, 1, "none", False),
+    (32, 4, 3, 1, 32, 32, 1, "none", False),       # N4 (4x4x1 MFMA) heads
+    (32, 2, 3, 1, 40, 100, 2, "sigmoid", False),
+    (16, 2, 7, 1, 70, 130, 1, "none", False),
+    (32, 1, 5, 1, 33, 65, 1, "relu", False),
 ]
 
 

@@ -2,13 +2,16 @@
 #include <string.h>
 #include "conv_mfma.h"
 
-static inline int cfg_mt(int cfg) { return cfg == VC_CFG_N16 ? 16 : 32; }
+// N-tile width (output channels per MFMA tile), k-step (channels per packed fragment) and lanes per k-group
+static inline int cfg_nt(int cfg) { return cfg == VC_CFG_N4 ? 4 : (cfg == VC_CFG_N16 ? 16 : 32); }
+static inline int cfg_ks(int cfg) { return cfg == VC_CFG_N4 ? 4 : (cfg == VC_CFG_N16 ? 16 : 8); }
 static inline int cfg_bn(int cfg)
 {
     switch (cfg) {
     case VC_CFG_N128: return 128;
     case VC_CFG_N64: return 64;
     case VC_CFG_N32: return 32;
+    case VC_CFG_N4: return 4;
     default: return 16;
     }
 }
@@ -18,7 +21,8 @@ extern "C" int vc_conv_select_cfg(int cout, int cin, int k, int stride)
 {
     (void)cin;
     int cfg;
-    if (cout <= 16) cfg = VC_CFG_N16;
+    if (cout <= 4 && stride == 1 && (k == 3 || k == 5 || k == 7)) cfg = VC_CFG_N4;
+    else if (cout <= 16) cfg = VC_CFG_N16;
     else if (cout <= 32) cfg = VC_CFG_N32;
     else if (cout <= 64 || (cout % 128 != 0 && cout % 64 == 0)) cfg = VC_CFG_N64;
     else cfg = VC_CFG_N128;
@@ -29,6 +33,10 @@ extern "C" int vc_conv_select_cfg(int cout, int cin, int k, int stride)
 
 extern "C" int vc_conv_chunk(int cfg, int k, int stride, int cin)
 {
+    if (cfg == VC_CFG_N4) {   // 64-pixel-wide tiles: smaller channel chunks keep the footprint in LDS
+        if (stride != 1) return -1;
+        return k == 3 ? 16 : ((k == 5 || k == 7) ? 8 : -1);
+    }
     switch (k) {
     case 1: return 32;
     case 3: return stride == 2 ? 8 : 32;
@@ -43,7 +51,8 @@ extern "C" size_t vc_conv_packed_weight_floats(int cfg, int cout, int cin, int k
     const int ck = vc_conv_chunk(cfg, kh, stride, cin);
     if (ck <= 0) return 0;
     const int cin_pad = round_up(cin, ck), cout_pad = round_up(cout, cfg_bn(cfg));
-    return (size_t)cout_pad * kh * kw * cin_pad;
+    // one 64-lane x 4-float fragment per (N-tile, tap, k-step); N4 replicates its 16 weights over the 16 blocks
+    return (size_t)(cout_pad / cfg_nt(cfg)) * kh * kw * (cin_pad / cfg_ks(cfg)) * 256;
 }
 
 extern "C" size_t vc_conv_packed_bias_floats(int cfg, int cout) { return (size_t)round_up(cout, cfg_bn(cfg)); }
@@ -55,7 +64,7 @@ extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout,
     const int ck = vc_conv_chunk(cfg, kh, stride, cin);
     if (ck <= 0) return VC_EINVAL;
     if (pixelshuffle && (cout % 4)) return VC_EINVAL;
-    const int mt = cfg_mt(cfg), ks = (mt == 32) ? 8 : 16;
+    const int mt = cfg_nt(cfg), ks = cfg_ks(cfg);
     const int cin_pad = round_up(cin, ck), cout_pad = round_up(cout, cfg_bn(cfg));
     const int taps = kh * kw, ksteps = cin_pad / ks, ntiles = cout_pad / mt;
     const int cps = cout / 4;
@@ -63,7 +72,8 @@ extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout,
         for (int tap = 0; tap < taps; ++tap)
             for (int kst = 0; kst < ksteps; ++kst)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int j = lane % mt, kk = lane / mt;
+                    // N4: every 4-lane block carries the same 4 channels (k = 1 per MFMA, no k-groups)
+                    const int j = lane % mt, kk = (cfg == VC_CFG_N4) ? 0 : lane / mt;
                     const int cop = nt * mt + j;  // packed (possibly permuted) output channel
                     int co = cop;
                     if (pixelshuffle && cop < cout) {
@@ -118,7 +128,7 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.mul = d->mul; a.mul_sn = d->mul_sn; a.mul_sh = d->mul_sh; a.mul_sw = d->mul_sw;
     a.chscale = d->chscale;
     a.cin_pad = round_up(a.Cin, ck);
-    const int th = 8, tw = 32;
+    const int th = 8, tw = ((d->cfg & 0xff) == VC_CFG_N4) ? 64 : 32;
     a.tiles_x = (a.Wo + tw - 1) / tw;
     a.tiles_y = (a.Ho + th - 1) / th;
     // Small feature maps (hyper-networks, MV codec, coarse pyramid levels): a 128-channel block would

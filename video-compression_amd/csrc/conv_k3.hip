@@ -2,6 +2,7 @@
 #include "conv_mfma.h"
 int conv_dispatch_k3(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck)
 {
+    if (cfg == VC_CFG_N4) return (stride == 1 && ck == 16) ? launch_conv<3, 3, 1, 16, CfgN4>(st, a) : VC_EINVAL;
     if (stride == 1 && ck == 32) {
         switch (cfg) {
         case VC_CFG_N128: return launch_conv<3, 3, 1, 32, CfgN128>(st, a);

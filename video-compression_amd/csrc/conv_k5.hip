@@ -4,6 +4,7 @@
 #include "conv_mfma.h"
 int conv_dispatch_k5(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck)
 {
+    if (cfg == VC_CFG_N4) return (stride == 1 && ck == 8) ? launch_conv<5, 5, 1, 8, CfgN4>(st, a) : VC_EINVAL;
     if (stride == 2 && ck == 8) {
         switch (cfg) {
         case VC_CFG_N128: return launch_conv<5, 5, 2, 8, CfgN128>(st, a);

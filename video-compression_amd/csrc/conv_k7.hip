@@ -2,6 +2,7 @@
 #include "conv_mfma.h"
 int conv_dispatch_k7(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck)
 {
+    if (cfg == VC_CFG_N4) return (stride == 1 && ck == 8) ? launch_conv<7, 7, 1, 8, CfgN4>(st, a) : VC_EINVAL;
     if (stride != 1) return VC_EINVAL;
     if (ck == 8 && cfg == VC_CFG_N32) return launch_conv<7, 7, 1, 8, CfgN32>(st, a);
     if (ck != 16) return VC_EINVAL;

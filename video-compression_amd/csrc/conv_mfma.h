@@ -53,9 +53,14 @@ struct ConvArgs {
 };
 
 template <int MT> struct Mfma;
+// arow/akk: which pixel of the M-tile and which k-group a lane feeds as the A operand;
+// col: which output channel of the N-tile a lane owns in C/D; row(reg, lane): the pixel of accumulator `reg`.
 template <> struct Mfma<32> {
     typedef f32x16 acc_t;
-    static constexpr int NREG = 16, KS = 8;
+    static constexpr int NREG = 16, KS = 8, NT = 32;
+    static __device__ __forceinline__ int arow(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int akk(int lane) { return lane >> 5; }
+    static __device__ __forceinline__ int col(int lane) { return lane & 31; }
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
     {
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -64,12 +69,33 @@ template <> struct Mfma<32> {
 };
 template <> struct Mfma<16> {
     typedef f32x4 acc_t;
-    static constexpr int NREG = 4, KS = 16;
+    static constexpr int NREG = 4, KS = 16, NT = 16;
+    static __device__ __forceinline__ int arow(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int akk(int lane) { return lane >> 4; }
+    static __device__ __forceinline__ int col(int lane) { return lane & 15; }
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
     {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int row(int reg, int lane) { return (lane >> 4) * 4 + reg; }
+};
+
+// v_mfma_f32_4x4x1_16B_f32: 16 independent (4 pixel x 4 channel) outer products per instruction, k = 1, at the
+// full fp32 matrix rate.  M-tile = 64 consecutive pixels (one per lane), N-tile = 4 output channels: the
+// layers that end in 1-4 channels (SPyNet's 16->2 flow head, the mask net's 32->1, U-Net heads) would
+// otherwise burn a 16-wide tile on mostly padding.  A (pixels): lane 4b+i; B (weights): lane 4b+j holds
+// channel j (replicated over the 16 blocks at pack time); D: lane 4b+j, register i = pixel 4b+i.
+template <> struct Mfma<64> {
+    typedef f32x4 acc_t;
+    static constexpr int NREG = 4, KS = 4, NT = 4;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
+    {
+        return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int arow(int lane) { return lane; }
+    static __device__ __forceinline__ int akk(int) { return 0; }
+    static __device__ __forceinline__ int col(int lane) { return lane & 3; }
+    static __device__ __forceinline__ int row(int reg, int lane) { return (lane >> 2) * 4 + reg; }
 };
 
 // Tile configuration: 4 waves split the M-tiles of a TH x (XT*MT) output tile; every wave covers all
@@ -80,13 +106,15 @@ template <int MT_, int TH_, int XT_, int WM_, int WN_> struct TileCfg {
     // registers (2 waves); the narrower ones are held to 168 so that three workgroups share a CU and
     // one of them can always feed the matrix pipe while another stages or stores
     static constexpr int MIN_WAVES = (WM_ * WN_ >= 4) ? 2 : 3;
-    static constexpr int TW = XT * MT, BN = WN * MT;
+    static constexpr int NT = Mfma<MT_>::NT;
+    static constexpr int TW = XT * MT, BN = WN * NT;
     static_assert(TH * XT == 4 * WM, "4 waves x WM M-tiles must cover the tile");
 };
 typedef TileCfg<32, 8, 1, 2, 4> CfgN128;
 typedef TileCfg<32, 8, 1, 2, 2> CfgN64;
 typedef TileCfg<32, 8, 1, 2, 1> CfgN32;
 typedef TileCfg<16, 8, 2, 4, 1> CfgN16;
+typedef TileCfg<64, 8, 1, 2, 1> CfgN4;
 
 template <int KH, int KW, int S, int CK, class C> struct ConvGeom {
     static constexpr bool POINT = (KH == 1 && KW == 1);
@@ -193,13 +221,14 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane % MT, kk = lane / MT;
+    const int li = M::arow(lane), kk = M::akk(lane), cj = M::col(lane);
+    constexpr int NT = C::NT;
 
     // ---- accumulators start at the bias of the lane's output channel ----
     typename M::acc_t acc[WM][WN];
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
-        const float b = p.bias[nblk * C::BN + n * MT + li];
+        const float b = p.bias[nblk * C::BN + n * NT + cj];
 #pragma unroll
         for (int t = 0; t < WM; ++t)
 #pragma unroll
@@ -298,7 +327,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         const int xbase = ox0 + (m % C::XT) * MT;
         static_for<0, WN>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
-            const int co = nblk * C::BN + n * MT + li;
+            const int co = nblk * C::BN + n * NT + cj;
             const bool co_ok = (co < p.Cout) && (oy < p.Ho);
             const float gain = (p.chscale && co_ok) ? p.chscale[co] : 1.0f;
             const int cps = p.Cout >> 2;
