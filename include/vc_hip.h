@@ -61,7 +61,8 @@ enum { VC_IN_NONE = 0, VC_IN_SQUARE = 1 };                   /* transform applie
 enum { VC_OUT_PLAIN = 0, VC_OUT_PIXELSHUFFLE2 = 1 };         /* nn.PixelShuffle(2) fused into the store */
 
 /* Tile configurations (output-channel block / MFMA shape).  Chosen by vc_conv_select_cfg. */
-enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N4 = 4 /* 64 px x 4 ch, 4x4x1 MFMA */ };
+enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N4 = 4 /* 64 px x 4 ch, 4x4x1 MFMA */,
+       VC_CFG_N128B = 5 /* 128 channels, waves 2x2 (3x3 stride-1 only; same packed weights as N128) */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
  * same packed weights and produces bit-identical results); without it the library narrows the block for
  * small feature maps by itself. */

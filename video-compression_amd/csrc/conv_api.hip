@@ -8,7 +8,8 @@ static inline int cfg_ks(int cfg) { return cfg == VC_CFG_N4 ? 4 : (cfg == VC_CFG
 static inline int cfg_bn(int cfg)
 {
     switch (cfg) {
-    case VC_CFG_N128: return 128;
+    case VC_CFG_N128:
+    case VC_CFG_N128B: return 128;
     case VC_CFG_N64: return 64;
     case VC_CFG_N32: return 32;
     case VC_CFG_N4: return 4;

@@ -5,6 +5,7 @@ int conv_dispatch_k3(hipStream_t st, const ConvArgs &a, int stride, int cfg, int
     if (cfg == VC_CFG_N4) return (stride == 1 && ck == 16) ? launch_conv<3, 3, 1, 16, CfgN4>(st, a) : VC_EINVAL;
     if (stride == 1 && ck == 32) {
         switch (cfg) {
+        case VC_CFG_N128B: return launch_conv<3, 3, 1, 32, CfgN128b>(st, a);
         case VC_CFG_N128: return launch_conv<3, 3, 1, 32, CfgN128>(st, a);
         case VC_CFG_N64: return launch_conv<3, 3, 1, 32, CfgN64>(st, a);
         case VC_CFG_N32: return launch_conv<3, 3, 1, 32, CfgN32>(st, a);

@@ -100,21 +100,24 @@ template <> struct Mfma<64> {
 
 // Tile configuration: 4 waves split the M-tiles of a TH x (XT*MT) output tile; every wave covers all
 // WN N-tiles of the block (BN = WN*MT output channels).
-template <int MT_, int TH_, int XT_, int WM_, int WN_> struct TileCfg {
+template <int MT_, int TH_, int XT_, int WM_, int WN_, int WAVES_N_ = 1> struct TileCfg {
     static constexpr int MT = MT_, TH = TH_, XT = XT_, WM = WM_, WN = WN_;
+    // the 4 waves form a (4/WAVES_N) x WAVES_N grid over (M-tiles, N-tiles)
+    static constexpr int WAVES_N = WAVES_N_, WAVES_M = 4 / WAVES_N_;
     // waves per SIMD the register allocation must leave room for: the 128-channel block needs ~250
     // registers (2 waves); the narrower ones are held to 168 so that three workgroups share a CU and
     // one of them can always feed the matrix pipe while another stages or stores
     static constexpr int MIN_WAVES = (WM_ * WN_ >= 4) ? 2 : 3;
     static constexpr int NT = Mfma<MT_>::NT;
-    static constexpr int TW = XT * MT, BN = WN * NT;
-    static_assert(TH * XT == 4 * WM, "4 waves x WM M-tiles must cover the tile");
+    static constexpr int TW = XT * MT, BN = WAVES_N * WN * NT;
+    static_assert(TH * XT == WAVES_M * WM, "WAVES_M waves x WM M-tiles must cover the tile");
 };
 typedef TileCfg<32, 8, 1, 2, 4> CfgN128;
 typedef TileCfg<32, 8, 1, 2, 2> CfgN64;
 typedef TileCfg<32, 8, 1, 2, 1> CfgN32;
 typedef TileCfg<16, 8, 2, 4, 1> CfgN16;
 typedef TileCfg<64, 8, 1, 2, 1> CfgN4;
+typedef TileCfg<32, 8, 1, 4, 2, 2> CfgN128b;   // 2x2 waves: each wave 4 rows x 64 channels (half the B-fragment loads)
 
 template <int KH, int KW, int S, int CK, class C> struct ConvGeom {
     static constexpr bool POINT = (KH == 1 && KW == 1);
@@ -128,7 +131,7 @@ template <int KH, int KW, int S, int CK, class C> struct ConvGeom {
     static constexpr int KS = Mfma<C::MT>::KS;
     static constexpr int KSTEPS = CK / KS;
     static_assert(CK % KS == 0, "chunk must be a whole number of k-steps");
-    static_assert(LDS_FLOATS * 4 + 16 <= 65536, "keep two workgroups per CU");
+    static_assert(LDS_FLOATS * 4 + 16 <= 80 * 1024, "keep two workgroups per CU (160 KiB LDS)");
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
@@ -221,6 +224,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
     const int li = M::arow(lane), kk = M::akk(lane), cj = M::col(lane);
     constexpr int NT = C::NT;
 
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     typename M::acc_t acc[WM][WN];
 #pragma unroll
     for (int n = 0; n < WN; ++n) {
-        const float b = p.bias[nblk * C::BN + n * NT + cj];
+        const float b = p.bias[nblk * C::BN + (wn * WN + n) * NT + cj];
 #pragma unroll
         for (int t = 0; t < WM; ++t)
 #pragma unroll
@@ -239,14 +243,14 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     int abase[WM];
 #pragma unroll
     for (int t = 0; t < WM; ++t) {
-        const int m = wave * WM + t;
+        const int m = wm * WM + t;
         const int row = m / C::XT, xt = m % C::XT;
         abase[t] = ((row * G::LS) * G::COLS_L + (xt * MT + li)) * G::CKP + 4 * kk;
     }
 
     const int ksteps_total = p.cin_pad / KS;
     const long long ntile_stride = (long long)TAPS * ksteps_total * 256;
-    const float *wlane = p.wpk + (long long)(nblk * WN) * ntile_stride + lane * 4;
+    const float *wlane = p.wpk + (long long)(nblk * (C::BN / NT) + wn * WN) * ntile_stride + lane * 4;
 
     const int pad_y = KH / 2, pad_x = KW / 2;
     const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
@@ -322,12 +326,12 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     // ---- epilogue: (GDN) -> activation -> channel gain -> residual -> store (plain / pixel-shuffle) ----
     static_for<0, WM>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        const int m = wave * WM + t;
+        const int m = wm * WM + t;
         const int oy = oy0 + m / C::XT;
         const int xbase = ox0 + (m % C::XT) * MT;
         static_for<0, WN>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
-            const int co = nblk * C::BN + n * NT + cj;
+            const int co = nblk * C::BN + (wn * WN + n) * NT + cj;
             const bool co_ok = (co < p.Cout) && (oy < p.Ho);
             const float gain = (p.chscale && co_ok) ? p.chscale[co] : 1.0f;
             const int cps = p.Cout >> 2;
@@ -361,8 +365,18 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 template <int KH, int KW, int S, int CK, class C> int launch_conv(hipStream_t st, const ConvArgs &a)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
-    hipLaunchKernelGGL((conv_mfma_kernel<KH, KW, S, CK, C>), dim3(a.total_blocks), dim3(256),
-                       (G::LDS_FLOATS + 4) * sizeof(float), st, a);   // + the staging dump slot
+    constexpr size_t lds_bytes = (G::LDS_FLOATS + 4) * sizeof(float);   // + the staging dump slot
+    auto kern = conv_mfma_kernel<KH, KW, S, CK, C>;
+    if (lds_bytes > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instance
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes) != hipSuccess)
+                return VC_ELAUNCH;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.total_blocks), dim3(256), lds_bytes, st, a);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
 }
 

@@ -257,6 +257,8 @@ class PackedConv:
         self.tuned = {}
         ck = L.vc_conv_chunk(self.cfg, kh, stride, cin)
         self.candidates = [c for c in range(self.cfg, 3) if L.vc_conv_chunk(c, kh, stride, cin) == ck] if self.cfg <= 2 else []
+        if self.cfg == 0 and kh == 3 and stride == 1:
+            self.candidates.append(5)          # VC_CFG_N128B: 128-channel block with the waves arranged 2x2
 
     def _pick_cfg(self, d, key):
         if key in self.tuned:
