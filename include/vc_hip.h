@@ -67,6 +67,11 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
  * same packed weights and produces bit-identical results); without it the library narrows the block for
  * small feature maps by itself. */
 #define VC_CFG_EXACT 0x100
+/* OR into vc_conv_desc.cfg: `wpk` holds half-precision fragments from vc_conv_pack_weights_f16 and the layer runs on
+ * v_mfma_f32_32x32x16_f16 (activations converted to half while staged, fp32 accumulate) -- the "fp16 MFMA conv
+ * path" of BASELINE.json configs[4].  32-wide tile configurations with cin % 8 == 0 only; not bit-comparable with
+ * the fp32 reference (judged on PSNR/bpp tolerance). */
+#define VC_CFG_F16 0x200
 
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */
@@ -93,6 +98,9 @@ size_t vc_conv_packed_bias_floats(int cfg, int cout);
  * (c*4+dy*2+dx) -> ((dy*2+dx)*cout/4 + c) output-channel permutation the fused store expects. */
 int vc_conv_pack_weights(const float *w_oihw, const float *bias, int cout, int cin, int kh, int kw,
                          int stride, int cfg, int pixelshuffle, float *wpk_out, float *bias_out);
+size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride); /* 0 = not eligible */
+int vc_conv_pack_weights_f16(const float *w_oihw, const float *bias, int cout, int cin, int kh, int kw,
+                             int stride, int cfg, int pixelshuffle, void *wpk_half_out, float *bias_out);
 int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d);
 
 /* ------------------------------------------------------------------------------------------

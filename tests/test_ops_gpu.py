@@ -92,9 +92,40 @@ def test_tile_configs_are_bit_identical(dev):
     pc = hip.PackedConv(_rand((128, 128, 3, 3), 32, 0.03), _rand((128,), 33, 0.1), device=dev)
     outs = []
     for cfg in (0, 1, 2, 5):
-        pc.tuned = {(x.n, x.h, x.w): cfg | hip.CFG_EXACT}
+        pc.tuned = {(x.n, x.h, x.w, False): cfg | hip.CFG_EXACT}
         outs.append(hip.nhwc_to_nchw(pc(x, act=hip.ACT_LRELU)))
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+F16_CASES = [(128, 128, 3, 1, 40, 72, "lrelu", False), (128, 512, 3, 1, 17, 30, "lrelu", True), (64, 32, 7, 1, 34, 60, "relu", False),
+             (32, 64, 7, 1, 34, 60, "relu", False), (192, 64, 5, 1, 16, 32, "relu", False), (128, 128, 3, 2, 34, 66, "none", False),
+             (256, 128, 3, 1, 16, 32, "relu", False), (128, 128, 1, 2, 32, 64, "none", False), (512, 512, 3, 1, 8, 16, "lrelu", False)]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w,act,ps", F16_CASES)
+def test_conv2d_fp16_path(dev, cin, cout, k, stride, h, w, act, ps):
+    """fp16 MFMA conv path (BASELINE configs[4]): compared with the SAME convolution on half-rounded operands in
+    fp32 (tight: only accumulation order differs) and with the exact fp32 result (loose: input rounding, 2^-11)."""
+    from vcamd import hip
+    x = _rand((1, cin, h, w), 41)
+    wt = _rand((cout, cin, k, k), 42, 1.0 / np.sqrt(cin * k * k))
+    b = _rand((cout,), 43, 0.1)
+    f = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.01)}[act]
+
+    def ref(xx, ww):
+        r = F.conv2d(xx, ww, b, stride=stride, padding=k // 2)
+        return f(F.pixel_shuffle(r, 2) if ps else r)
+    exact, rounded = ref(x, wt), ref(x.half().float(), wt.half().float())
+    hip.set_conv_precision("fp16")
+    try:
+        pc = hip.PackedConv(wt, b, stride=stride, pixelshuffle=ps, device=dev)
+    finally:
+        hip.set_conv_precision("fp32")
+    assert pc.wpk16 is not None
+    code = {"none": hip.ACT_NONE, "relu": hip.ACT_RELU, "lrelu": hip.ACT_LRELU}[act]
+    out = hip.nhwc_to_nchw(pc(hip.nchw_to_nhwc(x.to(dev)), act=code, slope=0.01))
+    _close(out, rounded, 3e-5, "fp16 conv vs half-rounded operands")
+    _close(out, exact, 5e-3, "fp16 conv vs exact fp32")
 
 
 def test_conv_residual_and_channel_slices(dev):

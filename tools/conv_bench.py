@@ -22,9 +22,11 @@ DEFAULT = ["128,128,3,1,1,544,960", "64,32,7,1,4,1088,1920", "32,64,7,1,4,1088,1
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32")
     ap.add_argument("shapes", nargs="*", default=DEFAULT)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    hip.set_conv_precision(args.precision)
     for spec in args.shapes:
         fields = [int(v) for v in spec.split(",")]
         cin, cout, k, s, n, h, w = fields[:7]
@@ -33,7 +35,8 @@ def main():
         b = torch.randn(cout, generator=g) * 0.1
         pc = hip.PackedConv(wt, b, stride=s, device=dev)
         if len(fields) > 7:            # optional 8th field: force a (layout-compatible) narrower tile config
-            pc.tuned = {(n, h, w): fields[7] | hip.CFG_EXACT}
+            f16 = pc.wpk16 is not None
+            pc.tuned = {(n, h, w, f16): fields[7] | hip.CFG_EXACT | (hip.CFG_F16 if f16 else 0)}
         x = hip.T.empty(n, h, w, cin, dev)
         x.buf.normal_()
         ho, wo, co = pc.out_shape(h, w)
@@ -48,7 +51,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
         flop = 2.0 * n * ho * wo * cout * cin * k * k
-        print(f"conv k{k} s{s} {cin:4d}->{cout:4d} @{n}x{h}x{w} cfg{pc.tuned.get((n, h, w), pc.cfg) & 0xff}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s "
+        print(f"conv k{k} s{s} {cin:4d}->{cout:4d} @{n}x{h}x{w} cfg{[v for v in pc.tuned.values()][0] & 0xff if pc.tuned else pc.cfg} {args.precision}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s "
               f"({flop / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)")
 
 

@@ -101,6 +101,59 @@ extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout,
     return VC_OK;
 }
 
+// ---- fp16 path: same fragment order with 8 halves (16 B) per lane = 16 input channels per k-step ----
+static inline bool cfg_f16_ok(int cfg, int cin)
+{
+    return (cfg == VC_CFG_N128 || cfg == VC_CFG_N64 || cfg == VC_CFG_N32 || cfg == VC_CFG_N128B) && (cin % 8) == 0;
+}
+
+extern "C" size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride)
+{
+    const int ck = vc_conv_chunk(cfg, kh, stride, cin);
+    if (ck <= 0 || !cfg_f16_ok(cfg, cin)) return 0;
+    const int cin_pad = round_up(cin, 2 * ck), cout_pad = round_up(cout, cfg_bn(cfg));
+    return (size_t)(cout_pad / 32) * kh * kw * (cin_pad / 16) * 1024;
+}
+
+extern "C" int vc_conv_pack_weights_f16(const float *w, const float *bias, int cout, int cin, int kh, int kw, int stride,
+                                        int cfg, int pixelshuffle, void *wpk_out, float *bpk)
+{
+    if (kh != kw || !cfg_f16_ok(cfg, cin)) return VC_EINVAL;
+    const int ck = vc_conv_chunk(cfg, kh, stride, cin);
+    if (ck <= 0) return VC_EINVAL;
+    if (pixelshuffle && (cout % 4)) return VC_EINVAL;
+    _Float16 *wpk = static_cast<_Float16 *>(wpk_out);
+    const int cin_pad = round_up(cin, 2 * ck), cout_pad = round_up(cout, cfg_bn(cfg));
+    const int taps = kh * kw, ksteps = cin_pad / 16, ntiles = cout_pad / 32;
+    const int cps = cout / 4;
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int kst = 0; kst < ksteps; ++kst)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = lane % 32, h = lane / 32;
+                    const int cop = nt * 32 + j;
+                    int co = cop;
+                    if (pixelshuffle && cop < cout) co = (cop % cps) * 4 + cop / cps;
+                    _Float16 *dst = wpk + ((((size_t)nt * taps + tap) * ksteps + kst) * 64 + lane) * 8;
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = kst * 16 + h * 8 + e;
+                        float v = 0.0f;
+                        if (cop < cout && ci < cin) v = w[(((size_t)co * cin + ci) * kh + tap / kw) * kw + tap % kw];
+                        dst[e] = (_Float16)v;
+                    }
+                }
+    for (int cop = 0; cop < cout_pad; ++cop) {
+        float v = 0.0f;
+        if (cop < cout && bias) {
+            int co = cop;
+            if (pixelshuffle) co = (cop % cps) * 4 + cop / cps;
+            v = bias[co];
+        }
+        bpk[cop] = v;
+    }
+    return VC_OK;
+}
+
 extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
 {
     if (!d || !d->in.p || !d->out.p || !d->wpk || !d->bias) return VC_EINVAL;
@@ -128,7 +181,9 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.res = d->res; a.res_sn = d->res_sn; a.res_sh = d->res_sh; a.res_sw = d->res_sw;
     a.mul = d->mul; a.mul_sn = d->mul_sn; a.mul_sh = d->mul_sh; a.mul_sw = d->mul_sw;
     a.chscale = d->chscale;
-    a.cin_pad = round_up(a.Cin, ck);
+    const bool f16 = (d->cfg & VC_CFG_F16) != 0;
+    if (f16 && (!cfg_f16_ok(d->cfg & 0xff, a.Cin) || d->in_xform != VC_IN_NONE)) return VC_EINVAL;
+    a.cin_pad = round_up(a.Cin, f16 ? 2 * ck : ck);
     const int th = 8, tw = ((d->cfg & 0xff) == VC_CFG_N4) ? 64 : 32;
     a.tiles_x = (a.Wo + tw - 1) / tw;
     a.tiles_y = (a.Ho + th - 1) / th;
@@ -150,12 +205,13 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.vec4 = ((a.Cin % 4) == 0 && (a.in_sw % 4) == 0 && (a.in_sh % 4) == 0 && (a.in_sn % 4) == 0 &&
               ((uintptr_t)a.in % 16) == 0) ? 1 : 0;
     if (a.total_blocks <= 0) return VC_EINVAL;
+    if (f16 && !a.vec4) return VC_EINVAL;   // the fp16 staging path reads 2 x 16 bytes per item
     hipStream_t stream = as_stream(s);
     switch (k) {
-    case 1: return conv_dispatch_k1(stream, a, st, cfg, ck);
-    case 3: return conv_dispatch_k3(stream, a, st, cfg, ck);
-    case 5: return conv_dispatch_k5(stream, a, st, cfg, ck);
-    case 7: return conv_dispatch_k7(stream, a, st, cfg, ck);
+    case 1: return conv_dispatch_k1(stream, a, st, cfg, ck, f16);
+    case 3: return conv_dispatch_k3(stream, a, st, cfg, ck, f16);
+    case 5: return conv_dispatch_k5(stream, a, st, cfg, ck, f16);
+    case 7: return conv_dispatch_k7(stream, a, st, cfg, ck, f16);
     }
     return VC_EINVAL;
 }

@@ -52,6 +52,9 @@ struct ConvArgs {
     int epi, in_xform, out_mode, vec4;
 };
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
 template <int MT> struct Mfma;
 // arow/akk: which pixel of the M-tile and which k-group a lane feeds as the A operand;
 // col: which output channel of the N-tile a lane owns in C/D; row(reg, lane): the pixel of accumulator `reg`.
@@ -143,18 +146,20 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
     return v;
 }
 
-template <int KH, int KW, int S, int CK, class C, bool VEC>
+template <int KH, int KW, int S, int CK, class C, bool VEC, bool F16>
 __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const float *in_img, int c0, int oy0, int ox0,
                                             int iy0, int ix0)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
-    constexpr int C4 = CK / 4;
+    constexpr int C4 = CK / 4;                                   // 16-byte LDS items per pixel
+    constexpr int CPI = F16 ? 8 : 4;                             // input channels behind one item
     constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
     constexpr int IPT = (ITEMS + 255) / 256;                    // items per thread
-    constexpr int BATCH = (IPT + 1) / 2 > 8 ? 8 : (IPT + 1) / 2;   // two rounds per chunk when registers allow
+    constexpr int BATCH0 = (IPT + 1) / 2 > 8 ? 8 : (IPT + 1) / 2;   // two rounds per chunk when registers allow
+    constexpr int BATCH = F16 ? (BATCH0 > 4 ? 4 : BATCH0) : BATCH0; // (an fp16 item is two 16-byte loads)
 #pragma unroll
     for (int b0 = 0; b0 < IPT; b0 += BATCH) {
-        f32x4 v[BATCH];
+        f32x4 v[BATCH], v2[F16 ? BATCH : 1];
         int dst[BATCH];
         bool ok[BATCH];
 #pragma unroll
@@ -166,7 +171,7 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
             const int col = pc % G::COLS_IN, row = pc / G::COLS_IN;
             const int iy = G::POINT ? (oy0 + row) * S : iy0 + row;
             const int ix = G::POINT ? (ox0 + col) * S : ix0 + col;
-            const int ch = c0 + c4 * 4;
+            const int ch = c0 + c4 * CPI;
             ok[j] = (idx < ITEMS) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin;
             const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
             const int pos = (G::LS == 2) ? ((col & 1) * G::HALF + (col >> 1)) : col;
@@ -174,7 +179,11 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
             // no branch anywhere in the staging code, so every round's loads issue back to back
             dst[j] = (idx < ITEMS) ? (row * G::COLS_L + pos) * G::CKP + c4 * 4 : G::LDS_FLOATS;
             const float *src = in_img + (long long)iyc * p.in_sh + (long long)ixc * p.in_sw;
-            if (VEC) {
+            if (F16) {   // Cin % 8 == 0 guaranteed by the host
+                const float *q = src + min(ch, p.Cin - 8);
+                v[j] = *reinterpret_cast<const f32x4 *>(q);
+                v2[j] = *reinterpret_cast<const f32x4 *>(q + 4);
+            } else if (VEC) {
                 v[j] = *reinterpret_cast<const f32x4 *>(src + min(ch, p.Cin - 4));
             } else {
                 const int cl = p.Cin - 1;
@@ -191,7 +200,17 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
         for (int j = 0; j < BATCH; ++j) {
             if (b0 + j >= IPT) continue;
             f32x4 w = v[j];
-            if (p.in_xform == VC_IN_SQUARE) w = w * w;
+            if (F16) {   // 8 channels -> 8 halves = one 16-byte item
+                f16x8 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (_Float16)v[j][e];
+                    h[4 + e] = (_Float16)v2[j][e];
+                }
+                w = __builtin_bit_cast(f32x4, h);
+            } else if (p.in_xform == VC_IN_SQUARE) {
+                w = w * w;
+            }
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             w = ok[j] ? w : z;
             *reinterpret_cast<f32x4 *>(&lds[dst[j]]) = w;
@@ -199,12 +218,20 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
     }
 }
 
-template <int KH, int KW, int S, int CK, class C>
+// F16: the "fp16 MFMA conv path" (BASELINE.json configs[4]): activations are converted to half while being
+// staged, weights are pre-packed as half fragments, v_mfma_f32_32x32x16_f16 accumulates in fp32.  A 16-byte LDS item /
+// weight fragment then carries 8 channels instead of 4 and ONE MFMA consumes it (16x the fp32 matrix rate), so all
+// addressing below is unchanged when expressed in 16-byte units: CK stays "LDS floats per pixel", the channel chunk
+// doubles.  32-wide tiles only; everything else (tiny channel counts, GDN) stays on the exact fp32 instances.
+template <int KH, int KW, int S, int CK, class C, bool F16 = false>
 __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const ConvArgs p)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     typedef Mfma<C::MT> M;
+    static_assert(!F16 || C::MT == 32, "the fp16 path uses the 32x32x16 MFMA");
     constexpr int MT = C::MT, WM = C::WM, WN = C::WN, KS = G::KS, KSTEPS = G::KSTEPS;
+    constexpr int CKC = F16 ? 2 * CK : CK;   // input channels per chunk
+    constexpr int KSC = F16 ? 2 * KS : KS;   // input channels per k-step (per packed fragment)
     constexpr int TAPS = KH * KW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -248,7 +275,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         abase[t] = ((row * G::LS) * G::COLS_L + (xt * MT + li)) * G::CKP + 4 * kk;
     }
 
-    const int ksteps_total = p.cin_pad / KS;
+    const int ksteps_total = p.cin_pad / KSC;
     const long long ntile_stride = (long long)TAPS * ksteps_total * 256;
     const float *wlane = p.wpk + (long long)(nblk * (C::BN / NT) + wn * WN) * ntile_stride + lane * 4;
 
@@ -256,23 +283,25 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
     const float *in_img = p.in + (long long)img * p.in_sn;
 
-    for (int c0 = 0; c0 < p.cin_pad; c0 += CK) {
+    for (int c0 = 0; c0 < p.cin_pad; c0 += CKC) {
         __syncthreads();
         // ---- stage the input footprint of this channel chunk ----
         // Two phases per batch: issue all global loads of the batch (addresses clamped into the image so
         // no load sits under a branch), then select-zero / transform and write LDS.  This keeps BATCH
         // independent 16-byte loads in flight per lane instead of one load -> wait -> ds_write at a time.
-        if (p.vec4)
-            stage_chunk<KH, KW, S, CK, C, true>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+        if (F16)
+            stage_chunk<KH, KW, S, CK, C, true, true>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+        else if (p.vec4)
+            stage_chunk<KH, KW, S, CK, C, true, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
         else
-            stage_chunk<KH, KW, S, CK, C, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+            stage_chunk<KH, KW, S, CK, C, false, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
         __syncthreads();
 
         // ---- contraction over taps x k-steps of this chunk, software-pipelined ----
         // The fragments of step s+1 (one 1 KiB global_load_dwordx4 per N-tile, one ds_read_b128 per
         // M-tile) are issued BEFORE the MFMAs of step s, so L2/LDS latency hides behind 8*WM*WN*... cycles
         // of matrix work instead of stalling every step (the compiler alone waits right after issuing).
-        const float *wchunk = wlane + (long long)(c0 / KS) * 256;
+        const float *wchunk = wlane + (long long)(c0 / KSC) * 256;
         constexpr int STEPS_X = KW * KSTEPS;  // steps per kernel row, fully unrolled
         f32x4 bc[WN], ac[WM], bn[WN], an[WM];
         auto load_b = [&](f32x4(&b)[WN], const float *wrow, int sx) {
@@ -308,12 +337,21 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                     load_a(an, rowoff_n, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
+                if constexpr (F16) {
 #pragma unroll
                     for (int t = 0; t < WM; ++t)
 #pragma unroll
-                        for (int n = 0; n < WN; ++n) acc[t][n] = M::run(ac[t][e], bc[n][e], acc[t][n]);
+                        for (int n = 0; n < WN; ++n)
+                            acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[t]),
+                                                                               __builtin_bit_cast(f16x8, bc[n]), acc[t][n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < WM; ++t)
+#pragma unroll
+                            for (int n = 0; n < WN; ++n) acc[t][n] = M::run(ac[t][e], bc[n][e], acc[t][n]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int n = 0; n < WN; ++n) bc[n] = bn[n];
@@ -362,11 +400,11 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     });
 }
 
-template <int KH, int KW, int S, int CK, class C> int launch_conv(hipStream_t st, const ConvArgs &a)
+template <int KH, int KW, int S, int CK, class C, bool F16 = false> int launch_conv(hipStream_t st, const ConvArgs &a)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     constexpr size_t lds_bytes = (G::LDS_FLOATS + 4) * sizeof(float);   // + the staging dump slot
-    auto kern = conv_mfma_kernel<KH, KW, S, CK, C>;
+    auto kern = conv_mfma_kernel<KH, KW, S, CK, C, F16>;
     if (lds_bytes > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instance
         static bool raised = false;
         if (!raised) {
@@ -380,8 +418,15 @@ template <int KH, int KW, int S, int CK, class C> int launch_conv(hipStream_t st
     return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
 }
 
+// fp32 or fp16 instance of the same tile configuration
+template <int KH, int KW, int S, int CK, class C> int launch_conv_p(hipStream_t st, const ConvArgs &a, bool f16)
+{
+    return f16 ? launch_conv<KH, KW, S, CK, C, true>(st, a) : launch_conv<KH, KW, S, CK, C, false>(st, a);
+}
+
 // one translation unit per kernel size (parallel build); each exports a dispatcher over the tile configs
-int conv_dispatch_k1(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
-int conv_dispatch_k3(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
-int conv_dispatch_k5(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
-int conv_dispatch_k7(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
+// (`ck` = LDS floats per pixel of the instance; `f16` selects the half-precision instance of 32-wide tiles)
+int conv_dispatch_k1(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16);
+int conv_dispatch_k3(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16);
+int conv_dispatch_k5(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16);
+int conv_dispatch_k7(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16);

@@ -106,6 +106,8 @@ def lib():
     sig("vc_conv_packed_weight_floats", sz, ci, ci, ci, ci, ci, ci)
     sig("vc_conv_packed_bias_floats", sz, ci, ci)
     sig("vc_conv_pack_weights", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp)
+    sig("vc_conv_packed_weight_bytes_f16", sz, ci, ci, ci, ci, ci, ci)
+    sig("vc_conv_pack_weights_f16", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp)
     sig("vc_conv2d_nhwc", ci, vp, ctypes.POINTER(ConvDesc))
     sig("vc_nchw_to_nhwc", ci, vp, vp, View)
     sig("vc_nhwc_to_nchw", ci, vp, View, vp)
@@ -137,7 +139,8 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "vc_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
-    "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
+    "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
+    "vc_conv_pack_weights_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
@@ -224,7 +227,24 @@ def nhwc_to_nchw(t):
 # convolution
 # ------------------------------------------------------------------------------------------------
 CFG_EXACT = 0x100
+CFG_F16 = 0x200
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
+# "fp32" (default, exact fp32 FMA chains like the reference) or "fp16" (BASELINE.json configs[4]: half-precision MFMA
+# with fp32 accumulate for every eligible layer; judged on PSNR/bpp tolerance, never the headline number).
+_PRECISION = os.environ.get("VC_CONV_PRECISION", "fp32")
+
+
+def set_conv_precision(mode):
+    """Applies to PackedConv objects created afterwards (models pack lazily: set it before the first forward, or
+    call ``model.float()`` to drop the caches)."""
+    global _PRECISION
+    if mode not in ("fp32", "fp16"):
+        raise ValueError("precision must be 'fp32' or 'fp16'")
+    _PRECISION = mode
+
+
+def conv_precision():
+    return _PRECISION
 
 
 class PackedConv:
@@ -254,20 +274,32 @@ class PackedConv:
               "vc_conv_pack_weights")
         self.wpk = torch.from_numpy(wpk).to(device)
         self.bias = torch.from_numpy(bpk).to(device)
+        self.wpk16 = None
+        if _PRECISION == "fp16":
+            nbytes = L.vc_conv_packed_weight_bytes_f16(self.cfg, cout, cin, kh, kw, stride)
+            if nbytes:
+                w16 = np.empty(nbytes // 2, dtype=np.float16)
+                check(L.vc_conv_pack_weights_f16(wnp.ctypes.data, None if bnp is None else bnp.ctypes.data, cout, cin, kh,
+                                                 kw, stride, self.cfg, int(self.ps), w16.ctypes.data, bpk.ctypes.data),
+                      "vc_conv_pack_weights_f16")
+                self.wpk16 = torch.from_numpy(w16).to(device)
         self.tuned = {}
         ck = L.vc_conv_chunk(self.cfg, kh, stride, cin)
         self.candidates = [c for c in range(self.cfg, 3) if L.vc_conv_chunk(c, kh, stride, cin) == ck] if self.cfg <= 2 else []
         if self.cfg == 0 and kh == 3 and stride == 1:
             self.candidates.append(5)          # VC_CFG_N128B: 128-channel block with the waves arranged 2x2
 
-    def _pick_cfg(self, d, key):
+    def _pick_cfg(self, d, key, flags=0):
         if key in self.tuned:
             return self.tuned[key]
-        if not AUTOTUNE or len(self.candidates) < 2 or torch.cuda.is_current_stream_capturing():
-            return self.cfg
+        cands = self.candidates
+        if flags & CFG_F16 and 5 in cands:
+            cands = [c for c in cands if c != 0]     # the 4x1 128-channel fp16 instance spills registers
+        if not AUTOTUNE or len(cands) < 2 or torch.cuda.is_current_stream_capturing():
+            return (cands[0] if cands else self.cfg) | flags
         best, best_ms = self.cfg, float("inf")
-        for c in self.candidates:
-            d.cfg = c | CFG_EXACT
+        for c in cands:
+            d.cfg = c | CFG_EXACT | flags
             if lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)) != VC_OK:
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -279,7 +311,7 @@ class PackedConv:
             ms = e0.elapsed_time(e1)
             if ms < best_ms:
                 best, best_ms = c, ms
-        self.tuned[key] = best | CFG_EXACT
+        self.tuned[key] = best | CFG_EXACT | flags
         return self.tuned[key]
 
     def out_shape(self, h, w):
@@ -307,7 +339,11 @@ class PackedConv:
         d.epi, d.in_xform = epi, in_xform
         d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
         d.cfg = self.cfg
-        d.cfg = self._pick_cfg(d, (x.n, x.h, x.w))
+        use16 = (self.wpk16 is not None and in_xform == IN_NONE and x.sw % 4 == 0 and x.sh % 4 == 0 and x.sn % 4 == 0
+                 and x.ptr % 16 == 0)
+        if use16:
+            d.wpk = self.wpk16.data_ptr()
+        d.cfg = self._pick_cfg(d, (x.n, x.h, x.w, use16), CFG_F16 if use16 else 0)
         what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})"
         if timer is None:
             check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
