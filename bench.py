@@ -28,10 +28,12 @@ sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
 
 H, W = 1080, 1920
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
+PEAK_F16_MFMA_TFLOPS = 2500.0    # BF16/FP16 matrix peak, dense
 PEAK_HBM_GBS = 8000.0
 
 
-def synthetic_gop(seed, gop_index, device, frames_per_gop=9):
+def synthetic_gop(seed, gop_index, device, frames_per_gop=9, hw=None):
+    H, W = hw if hw is not None else (1080, 1920)
     """Config 2: band-limited noise texture (Gaussian sigma=3 px) + global translation (1.5,0.75) px per
     frame + 2 % additive noise, quantised to uint8, then /255 and reflection-padded to 1088x1920."""
     from scipy import ndimage
@@ -81,6 +83,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", choices=["lhbdc", "flex"], default="lhbdc",
                     help="lhbdc = BASELINE.json configs[1] (headline); flex = configs[2] (Flex-Rate, 4 rate points)")
+    ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32",
+                    help="fp32 = exact path (headline); fp16 = half-precision MFMA conv path of BASELINE configs[4]")
+    ap.add_argument("--resolution", choices=["1080p", "2160p"], default="1080p")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel event timing table here (json)")
@@ -102,6 +107,11 @@ def main():
     from vcamd import gop as vgop
     from vcamd.seeding import seeded_state_dict
 
+    global H, W
+    if args.resolution == "2160p":
+        H, W = 2160, 3840
+    hip.set_conv_precision(args.precision)
+    f16 = args.precision == "fp16"
     is_flex = args.model == "flex"
     model = flex.BidirFlowRef(n=4) if is_flex else lhbdc.Model()
     sd = seeded_state_dict(model.state_dict(), seed=1234)
@@ -110,7 +120,7 @@ def main():
     per_gop = 15 if is_flex else 7
 
     # every rank codes its own GOP (GOP index = rank): weak scaling, per-GPU work fixed
-    frames = synthetic_gop(1234, rank, dev, 17 if is_flex else 9)
+    frames = synthetic_gop(1234, rank, dev, 17 if is_flex else 9, (H, W))
     records = []
     # Flex: 4 rate points selected purely through the gain units (n = 0..3, l = 1), one per step in turn
     rate_points = [{lvl: (n, 1.0) for lvl in range(4)} for n in range(4)]
@@ -166,13 +176,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f16 operands / f32 accumulate (eligible convolutions), f32 elsewhere" if f16 else "f32",
         "data": "synthetic (band-limited texture + global translation + 2% noise, 1080x1920 padded to 1088x1920); seeded random weights",
         "config": {"workload": ("Flex-Rate b_model 1080p GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
                                 "n=step%4 through the gain units, one GOP per GPU per step" if is_flex else
                                 "LHBDC 1080p GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
                                 "one GOP per GPU per step"), "frames_per_step_per_gpu": per_gop, "gop": 16 if is_flex else 8,
-                   "resolution": "1920x1080", "parallelism": f"gop-shard x{world}",
+                   "resolution": f"{W}x{H}", "precision": args.precision, "parallelism": f"gop-shard x{world}",
                    "launch": "eager" if args.no_graph else "hip-graph per GOP"},
     }
     q = vgop.summarize(rows)
@@ -195,8 +205,9 @@ def main():
         per_launch_flop = dom["flops"] / dom["launches"]
         avg_ms = dom["ms"] / dom["launches"]
         achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak,
+                              "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                               "launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
                               "share_of_conv_time": dom["ms"] / total_ms,
                               "algorithmic_flop_per_launch": per_launch_flop}
@@ -205,7 +216,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
                 tr = json.load(f)["kernels"].get(key)
-            if tr:
+            if tr and not f16 and args.resolution == "1080p":
                 result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 result["roofline"]["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc, separate passes)"
         except (OSError, KeyError, ValueError):
@@ -214,8 +225,8 @@ def main():
         if ns:
             v = ns[0][1]
             a = v["flops"] / v["launches"] / (v["ms"] / v["launches"] * 1e-3) / 1e12
-            result["roofline_3x3_analysis_conv"] = {"kernel": ns[0][0], "achieved": a, "peak": PEAK_F32_MFMA_TFLOPS,
-                                                    "unit": "TFLOP/s", "frac": a / PEAK_F32_MFMA_TFLOPS,
+            result["roofline_3x3_analysis_conv"] = {"kernel": ns[0][0], "achieved": a, "peak": peak,
+                                                    "unit": "TFLOP/s", "frac": a / peak,
                                                     "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
         all_flops = sum(v["flops"] for v in table.values())
         result["conv_engine"] = {"frame_conv_ms": total_ms, "frame_conv_tflop": all_flops / 1e12,
@@ -224,7 +235,7 @@ def main():
             with open(args.kernel_table, "w") as f:
                 json.dump({k: v for k, v in ranked}, f, indent=1)
 
-        if not is_flex:
+        if not is_flex and args.resolution == "1080p":
             # ---- whole GOP as testing.py codes it: 1 I-frame (mbt2018_mean q7 architecture) + 7 B-frames ----
             from vcamd import iframe
             i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
@@ -245,7 +256,7 @@ def main():
                                   "what": "1 I-frame (mbt2018_mean q7 architecture, seeded) + 7 B-frames per GOP, eager launches"}
 
         # ---- CPU baseline: the oracle (PyTorch-CPU restatement, tensor-equal to the reference) ----
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.resolution == "1080p":
             from oracle import flex as oracle_flex
             from oracle import lhbdc as oracle_lhbdc
             ora = (oracle_flex.FlexModel(n=4) if is_flex else oracle_lhbdc.LhbdcModel()).eval()

@@ -99,7 +99,8 @@ def test_tile_configs_are_bit_identical(dev):
 
 F16_CASES = [(128, 128, 3, 1, 40, 72, "lrelu", False), (128, 512, 3, 1, 17, 30, "lrelu", True), (64, 32, 7, 1, 34, 60, "relu", False),
              (32, 64, 7, 1, 34, 60, "relu", False), (192, 64, 5, 1, 16, 32, "relu", False), (128, 128, 3, 2, 34, 66, "none", False),
-             (256, 128, 3, 1, 16, 32, "relu", False), (128, 128, 1, 2, 32, 64, "none", False), (512, 512, 3, 1, 8, 16, "lrelu", False)]
+             (256, 128, 3, 1, 16, 32, "relu", False), (128, 128, 1, 2, 32, 64, "none", False), (512, 512, 3, 1, 8, 16, "lrelu", False),
+             (32, 16, 7, 1, 34, 60, "relu", False), (128, 12, 3, 1, 16, 48, "none", True), (96, 16, 5, 1, 20, 36, "relu", False)]
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,h,w,act,ps", F16_CASES)

@@ -104,7 +104,8 @@ extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout,
 // ---- fp16 path: same fragment order with 8 halves (16 B) per lane = 16 input channels per k-step ----
 static inline bool cfg_f16_ok(int cfg, int cin)
 {
-    return (cfg == VC_CFG_N128 || cfg == VC_CFG_N64 || cfg == VC_CFG_N32 || cfg == VC_CFG_N128B) && (cin % 8) == 0;
+    return (cfg == VC_CFG_N128 || cfg == VC_CFG_N64 || cfg == VC_CFG_N32 || cfg == VC_CFG_N128B || cfg == VC_CFG_N16) &&
+           (cin % 8) == 0;
 }
 
 extern "C" size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride)
@@ -112,7 +113,7 @@ extern "C" size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, in
     const int ck = vc_conv_chunk(cfg, kh, stride, cin);
     if (ck <= 0 || !cfg_f16_ok(cfg, cin)) return 0;
     const int cin_pad = round_up(cin, 2 * ck), cout_pad = round_up(cout, cfg_bn(cfg));
-    return (size_t)(cout_pad / 32) * kh * kw * (cin_pad / 16) * 1024;
+    return (size_t)(cout_pad / cfg_nt(cfg)) * kh * kw * (cin_pad / (2 * cfg_ks(cfg))) * 1024;
 }
 
 extern "C" int vc_conv_pack_weights_f16(const float *w, const float *bias, int cout, int cin, int kh, int kw, int stride,
@@ -124,19 +125,20 @@ extern "C" int vc_conv_pack_weights_f16(const float *w, const float *bias, int c
     if (pixelshuffle && (cout % 4)) return VC_EINVAL;
     _Float16 *wpk = static_cast<_Float16 *>(wpk_out);
     const int cin_pad = round_up(cin, 2 * ck), cout_pad = round_up(cout, cfg_bn(cfg));
-    const int taps = kh * kw, ksteps = cin_pad / 16, ntiles = cout_pad / 32;
+    const int mt = cfg_nt(cfg), kch = 2 * cfg_ks(cfg);   // 32 x (2 groups of 8) or 16 x (4 groups of 8) channels per k-step
+    const int taps = kh * kw, ksteps = cin_pad / kch, ntiles = cout_pad / mt;
     const int cps = cout / 4;
     for (int nt = 0; nt < ntiles; ++nt)
         for (int tap = 0; tap < taps; ++tap)
             for (int kst = 0; kst < ksteps; ++kst)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int j = lane % 32, h = lane / 32;
-                    const int cop = nt * 32 + j;
+                    const int j = lane % mt, h = lane / mt;
+                    const int cop = nt * mt + j;
                     int co = cop;
                     if (pixelshuffle && cop < cout) co = (cop % cps) * 4 + cop / cps;
                     _Float16 *dst = wpk + ((((size_t)nt * taps + tap) * ksteps + kst) * 64 + lane) * 8;
                     for (int e = 0; e < 8; ++e) {
-                        const int ci = kst * 16 + h * 8 + e;
+                        const int ci = kst * kch + h * 8 + e;
                         float v = 0.0f;
                         if (cop < cout && ci < cin) v = w[(((size_t)co * cin + ci) * kh + tap / kw) * kw + tap % kw];
                         dst[e] = (_Float16)v;

@@ -8,7 +8,7 @@ int conv_dispatch_k1(hipStream_t st, const ConvArgs &a, int stride, int cfg, int
         case VC_CFG_N128: return launch_conv_p<1, 1, 1, 32, CfgN128>(st, a, f16);
         case VC_CFG_N64: return launch_conv_p<1, 1, 1, 32, CfgN64>(st, a, f16);
         case VC_CFG_N32: return launch_conv_p<1, 1, 1, 32, CfgN32>(st, a, f16);
-        case VC_CFG_N16: return launch_conv<1, 1, 1, 32, CfgN16>(st, a);
+        case VC_CFG_N16: return launch_conv_p<1, 1, 1, 32, CfgN16>(st, a, f16);
         }
     } else if (stride == 2) {
         switch (cfg) {

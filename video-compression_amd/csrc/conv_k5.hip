@@ -18,7 +18,7 @@ int conv_dispatch_k5(hipStream_t st, const ConvArgs &a, int stride, int cfg, int
     case VC_CFG_N128: return launch_conv_p<5, 5, 1, 16, CfgN128>(st, a, f16);
     case VC_CFG_N64: return launch_conv_p<5, 5, 1, 16, CfgN64>(st, a, f16);
     case VC_CFG_N32: return launch_conv_p<5, 5, 1, 16, CfgN32>(st, a, f16);
-    case VC_CFG_N16: return launch_conv<5, 5, 1, 16, CfgN16>(st, a);
+    case VC_CFG_N16: return launch_conv_p<5, 5, 1, 16, CfgN16>(st, a, f16);
     }
     return VC_EINVAL;
 }

@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     typedef Mfma<C::MT> M;
-    static_assert(!F16 || C::MT == 32, "the fp16 path uses the 32x32x16 MFMA");
+    static_assert(!F16 || C::MT == 32 || C::MT == 16, "the fp16 path uses the 32x32x16 / 16x16x32 MFMAs");
     constexpr int MT = C::MT, WM = C::WM, WN = C::WN, KS = G::KS, KSTEPS = G::KSTEPS;
     constexpr int CKC = F16 ? 2 * CK : CK;   // input channels per chunk
     constexpr int KSC = F16 ? 2 * KS : KS;   // input channels per k-step (per packed fragment)
@@ -341,9 +341,14 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
                     for (int t = 0; t < WM; ++t)
 #pragma unroll
-                        for (int n = 0; n < WN; ++n)
-                            acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[t]),
-                                                                               __builtin_bit_cast(f16x8, bc[n]), acc[t][n], 0, 0, 0);
+                        for (int n = 0; n < WN; ++n) {
+                            if constexpr (MT == 32)
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[t]),
+                                                                                   __builtin_bit_cast(f16x8, bc[n]), acc[t][n], 0, 0, 0);
+                            else
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ac[t]),
+                                                                                   __builtin_bit_cast(f16x8, bc[n]), acc[t][n], 0, 0, 0);
+                        }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
