@@ -165,8 +165,8 @@ def main():
 
     b_frames = per_gop * args.steps * world
     result = {
-        "metric": ("B-frames/s, Flex-Rate 1080p GOP-16, 4 rate points" if is_flex else
-                   "B-frames/s, LHBDC 1080p GOP-8 (frames/sec of the per-B-frame codec path)"),
+        "metric": (f"B-frames/s, Flex-Rate {args.resolution} GOP-16, 4 rate points" if is_flex else
+                   f"B-frames/s, LHBDC {args.resolution} GOP-8 (frames/sec of the per-B-frame codec path)"),
         "value": b_frames / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
@@ -177,10 +177,10 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f16 operands / f32 accumulate (eligible convolutions), f32 elsewhere" if f16 else "f32",
-        "data": "synthetic (band-limited texture + global translation + 2% noise, 1080x1920 padded to 1088x1920); seeded random weights",
-        "config": {"workload": ("Flex-Rate b_model 1080p GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
+        "data": f"synthetic (band-limited texture + global translation + 2% noise, {H}x{W} reflection-padded to x64); seeded random weights",
+        "config": {"workload": (f"Flex-Rate b_model {args.resolution} GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
                                 "n=step%4 through the gain units, one GOP per GPU per step" if is_flex else
-                                "LHBDC 1080p GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
+                                f"LHBDC {args.resolution} GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
                                 "one GOP per GPU per step"), "frames_per_step_per_gpu": per_gop, "gop": 16 if is_flex else 8,
                    "resolution": f"{W}x{H}", "precision": args.precision, "parallelism": f"gop-shard x{world}",
                    "launch": "eager" if args.no_graph else "hip-graph per GOP"},
