@@ -17,7 +17,7 @@ from . import hip
 from .hip import T
 from .layers import (BitCounter, MeanScaleHyperprior, ResidualBlock, ResidualBlockUpsample, ResidualBlockWithStride,
                      _Prepared, conv3x3, pack_conv, subpel_conv3x3)
-from .lhbdc import _require_cuda
+from .lhbdc import _require_cuda, _require_frames
 
 
 # ------------------------------------------------------------------------------------------------
@@ -253,8 +253,7 @@ class BidirFlowRef(nn.Module):
     def forward_device(self, x_before, x_current, x_after, n=None, l=1):
         """Batch-1 B-frame path with no host synchronisation (graph-capturable): (x_hat, bits[4] float64
         device tensor = flow.y, flow.z, res.y, res.z)."""
-        for t in (x_before, x_current, x_after):
-            _require_cuda(t)
+        _require_frames(x_before, x_current, x_after)
         if x_current.shape[0] != 1:
             raise hip.VcError("forward_device codes one frame at a time")
         xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))

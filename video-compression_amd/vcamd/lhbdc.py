@@ -26,6 +26,21 @@ def _require_cuda(x):
         raise hip.VcError("inputs must be CUDA (HIP) tensors: this implementation has no CPU path")
 
 
+def _require_frames(*frames):
+    """The caller pads frames to a multiple of 64 (encode_B.py:49-56, test/utils.py `pad`); the reference fails with
+    shape mismatches deep inside otherwise -- fail early and clearly instead."""
+    shape = None
+    for f in frames:
+        _require_cuda(f)
+        if f.dim() != 4 or f.shape[1] != 3:
+            raise hip.VcError(f"expected [N,3,H,W] frames, got {tuple(f.shape)}")
+        if f.shape[2] % 64 or f.shape[3] % 64:
+            raise hip.VcError(f"frame size {f.shape[2]}x{f.shape[3]} is not a multiple of 64: pad it first (pad/process_frame)")
+        if shape is not None and tuple(f.shape) != shape:
+            raise hip.VcError("all frames of a triple must have the same shape")
+        shape = tuple(f.shape)
+
+
 # ------------------------------------------------------------------------------------------------
 # SPyNet
 # ------------------------------------------------------------------------------------------------
@@ -277,8 +292,7 @@ class Model(nn.Module):
         """The whole B-frame path with NO host synchronisation (graph-capturable) for a batch of n
         independent frames: returns (x_hat NCHW [n,3,H,W], bits float64 device tensor [n, 4] =
         per frame (mv.y, mv.z, res.y, res.z))."""
-        for t in (x_before, x_current, x_after):
-            _require_cuda(t)
+        _require_frames(x_before, x_current, x_after)
         xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
         n = xc_.shape[0]
         dev = xc_.device
