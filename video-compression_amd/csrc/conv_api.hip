@@ -179,6 +179,7 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     }
     if (d->out.n != d->in.n) return VC_EINVAL;
     if (d->epi != VC_EPI_NONE && !d->mul) return VC_EINVAL;
+    if (d->epi != VC_EPI_NONE && d->act != VC_ACT_NONE) return VC_EINVAL;   // GDN/IGDN are never followed by an activation
     a.wpk = d->wpk; a.bias = d->bias;
     a.res = d->res; a.res_sn = d->res_sn; a.res_sh = d->res_sh; a.res_sw = d->res_sw;
     a.mul = d->mul; a.mul_sn = d->mul_sn; a.mul_sh = d->mul_sh; a.mul_sw = d->mul_sw;
@@ -206,14 +207,33 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.epi = d->epi; a.in_xform = d->in_xform; a.out_mode = d->out_mode;
     a.vec4 = ((a.Cin % 4) == 0 && (a.in_sw % 4) == 0 && (a.in_sh % 4) == 0 && (a.in_sn % 4) == 0 &&
               ((uintptr_t)a.in % 16) == 0) ? 1 : 0;
+    {   // 16-byte epilogue accesses: every view that is touched must keep groups of 4 channels aligned
+        auto ok = [](const void *ptr, long long sn, long long sh, long long sw) {
+            return !ptr || (((uintptr_t)ptr % 16) == 0 && (sn % 4) == 0 && (sh % 4) == 0 && (sw % 4) == 0);
+        };
+        const int cgrp = (d->out_mode == VC_OUT_PIXELSHUFFLE2) ? (a.Cout >> 2) : a.Cout;   // channels per output pixel
+        a.vec_out = (cgrp % 4) == 0 && ok(a.out, a.out_sn, a.out_sh, a.out_sw) && ok(a.res, a.res_sn, a.res_sh, a.res_sw) &&
+                    ok(a.mul, a.mul_sn, a.mul_sh, a.mul_sw) && ok(a.chscale, 0, 0, 0);
+    }
     if (a.total_blocks <= 0) return VC_EINVAL;
     if (f16 && !a.vec4) return VC_EINVAL;   // the fp16 staging path reads 2 x 16 bytes per item
     hipStream_t stream = as_stream(s);
     switch (k) {
-    case 1: return conv_dispatch_k1(stream, a, st, cfg, ck, f16);
-    case 3: return conv_dispatch_k3(stream, a, st, cfg, ck, f16);
-    case 5: return conv_dispatch_k5(stream, a, st, cfg, ck, f16);
-    case 7: return conv_dispatch_k7(stream, a, st, cfg, ck, f16);
+    case 1: return f16 ? conv_dispatch_k1_f16(stream, a, st, cfg, ck) : conv_dispatch_k1_f32(stream, a, st, cfg, ck);
+    case 3: return f16 ? conv_dispatch_k3_f16(stream, a, st, cfg, ck) : conv_dispatch_k3_f32(stream, a, st, cfg, ck);
+    case 5: return f16 ? conv_dispatch_k5_f16(stream, a, st, cfg, ck) : conv_dispatch_k5_f32(stream, a, st, cfg, ck);
+    case 7: return f16 ? conv_dispatch_k7_f16(stream, a, st, cfg, ck) : conv_dispatch_k7_f32(stream, a, st, cfg, ck);
     }
     return VC_EINVAL;
 }
+
+#ifdef VC_STAMPS
+extern "C" int vc_debug_read_stamps(unsigned long long *out8)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return VC_ELAUNCH;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vc_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return VC_ELAUNCH;
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_vc_stamps), zero, sizeof(zero)) != hipSuccess) return VC_ELAUNCH;
+    return VC_OK;
+}
+#endif

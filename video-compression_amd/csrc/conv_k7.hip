@@ -1,16 +1,16 @@
 // 7x7 convolutions of SPyNet's Basic blocks (LHBDC/model/flow.py:52-62).
 #include "conv_mfma.h"
-int conv_dispatch_k7(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16)
+int VC_DISPATCH(k7)(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck)
 {
-    if (cfg == VC_CFG_N4) return (stride == 1 && ck == 8) ? launch_conv<7, 7, 1, 8, CfgN4>(st, a) : VC_EINVAL;
+    if (cfg == VC_CFG_N4) return (stride == 1 && ck == 8) ? launch_conv_n4<7, 7, 1, 8>(st, a) : VC_EINVAL;
     if (stride != 1) return VC_EINVAL;
-    if (ck == 8 && cfg == VC_CFG_N32) return launch_conv_p<7, 7, 1, 8, CfgN32>(st, a, f16);
+    if (ck == 8 && cfg == VC_CFG_N32) return launch_conv_p<7, 7, 1, 8, CfgN32>(st, a);
     if (ck != 16) return VC_EINVAL;
     switch (cfg) {
-    case VC_CFG_N128: return launch_conv_p<7, 7, 1, 16, CfgN128>(st, a, f16);
-    case VC_CFG_N64: return launch_conv_p<7, 7, 1, 16, CfgN64>(st, a, f16);
-    case VC_CFG_N32: return launch_conv_p<7, 7, 1, 16, CfgN32>(st, a, f16);
-    case VC_CFG_N16: return launch_conv_p<7, 7, 1, 16, CfgN16>(st, a, f16);
+    case VC_CFG_N128: return launch_conv_p<7, 7, 1, 16, CfgN128>(st, a);
+    case VC_CFG_N64: return launch_conv_p<7, 7, 1, 16, CfgN64>(st, a);
+    case VC_CFG_N32: return launch_conv_p<7, 7, 1, 16, CfgN32>(st, a);
+    case VC_CFG_N16: return launch_conv_p<7, 7, 1, 16, CfgN16>(st, a);
     }
     return VC_EINVAL;
 }

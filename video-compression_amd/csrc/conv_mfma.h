@@ -31,6 +31,17 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
     }
 }
 
+#ifdef VC_STAMPS
+// Diagnostic build only (make stamps): per-phase shader-clock totals summed over all waves, read back with
+// vc_debug_read_stamps.  Never compiled into libvc_hip.so.
+__device__ unsigned long long g_vc_stamps[8];
+#define VC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define VC_ACC(slot, t1, t0) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_vc_stamps[slot], (t1) - (t0)); } while (0)
+#else
+#define VC_T(var)
+#define VC_ACC(slot, t1, t0)
+#endif
+
 struct ConvArgs {
     const float *in;
     long long in_sn, in_sh, in_sw;
@@ -50,6 +61,7 @@ struct ConvArgs {
     int act;
     float slope;
     int epi, in_xform, out_mode, vec4;
+    int vec_out;   // out / res / mul / chscale allow 16-byte accesses on groups of 4 consecutive output channels
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -64,6 +76,9 @@ template <> struct Mfma<32> {
     static __device__ __forceinline__ int arow(int lane) { return lane & 31; }
     static __device__ __forceinline__ int akk(int lane) { return lane >> 5; }
     static __device__ __forceinline__ int col(int lane) { return lane & 31; }
+    // C/D with the WEIGHT fragment as the first MFMA operand: lane -> pixel, register -> output channel
+    static __device__ __forceinline__ int px(int lane) { return lane & 31; }
+    static __device__ __forceinline__ int crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
     {
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -76,6 +91,8 @@ template <> struct Mfma<16> {
     static __device__ __forceinline__ int arow(int lane) { return lane & 15; }
     static __device__ __forceinline__ int akk(int lane) { return lane >> 4; }
     static __device__ __forceinline__ int col(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int px(int lane) { return lane & 15; }
+    static __device__ __forceinline__ int crow(int reg, int lane) { return (lane >> 4) * 4 + reg; }
     static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
     {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -98,6 +115,8 @@ template <> struct Mfma<64> {
     static __device__ __forceinline__ int arow(int lane) { return lane; }
     static __device__ __forceinline__ int akk(int) { return 0; }
     static __device__ __forceinline__ int col(int lane) { return lane & 3; }
+    static __device__ __forceinline__ int px(int lane) { return lane; }
+    static __device__ __forceinline__ int crow(int reg, int) { return reg; }
     static __device__ __forceinline__ int row(int reg, int lane) { return (lane >> 2) * 4 + reg; }
 };
 
@@ -252,19 +271,21 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
-    const int li = M::arow(lane), kk = M::akk(lane), cj = M::col(lane);
+    const int li = M::arow(lane), kk = M::akk(lane);
     constexpr int NT = C::NT;
 
     // ---- accumulators start at the bias of the lane's output channel ----
     typename M::acc_t acc[WM][WN];
+    // (the weight fragment is the FIRST MFMA operand: accumulator register -> output channel, lane -> pixel, so a
+    //  lane ends up with 4 consecutive channels of one pixel per register quad = one 16-byte store)
 #pragma unroll
-    for (int n = 0; n < WN; ++n) {
-        const float b = p.bias[nblk * C::BN + (wn * WN + n) * NT + cj];
+    for (int n = 0; n < WN; ++n)
 #pragma unroll
-        for (int t = 0; t < WM; ++t)
+        for (int r = 0; r < M::NREG; ++r) {
+            const float b = p.bias[nblk * C::BN + (wn * WN + n) * NT + M::crow(r, lane)];
 #pragma unroll
-            for (int r = 0; r < M::NREG; ++r) acc[t][n][r] = b;
-    }
+            for (int t = 0; t < WM; ++t) acc[t][n][r] = b;
+        }
 
     // ---- per-lane LDS read bases of the wave's M-tiles ----
     int abase[WM];
@@ -283,8 +304,11 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
     const float *in_img = p.in + (long long)img * p.in_sn;
 
+    VC_T(t_start);
     for (int c0 = 0; c0 < p.cin_pad; c0 += CKC) {
+        VC_T(t_a);
         __syncthreads();
+        VC_T(t_b);
         // ---- stage the input footprint of this channel chunk ----
         // Two phases per batch: issue all global loads of the batch (addresses clamped into the image so
         // no load sits under a branch), then select-zero / transform and write LDS.  This keeps BATCH
@@ -295,7 +319,9 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
             stage_chunk<KH, KW, S, CK, C, true, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
         else
             stage_chunk<KH, KW, S, CK, C, false, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+        VC_T(t_c);
         __syncthreads();
+        VC_T(t_d);
 
         // ---- contraction over taps x k-steps of this chunk, software-pipelined ----
         // The fragments of step s+1 (one 1 KiB global_load_dwordx4 per N-tile, one ds_read_b128 per
@@ -343,11 +369,11 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
                         for (int n = 0; n < WN; ++n) {
                             if constexpr (MT == 32)
-                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[t]),
-                                                                                   __builtin_bit_cast(f16x8, bc[n]), acc[t][n], 0, 0, 0);
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bc[n]),
+                                                                                   __builtin_bit_cast(f16x8, ac[t]), acc[t][n], 0, 0, 0);
                             else
-                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ac[t]),
-                                                                                   __builtin_bit_cast(f16x8, bc[n]), acc[t][n], 0, 0, 0);
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bc[n]),
+                                                                                   __builtin_bit_cast(f16x8, ac[t]), acc[t][n], 0, 0, 0);
                         }
                 } else {
 #pragma unroll
@@ -355,7 +381,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
                         for (int t = 0; t < WM; ++t)
 #pragma unroll
-                            for (int n = 0; n < WN; ++n) acc[t][n] = M::run(ac[t][e], bc[n][e], acc[t][n]);
+                            for (int n = 0; n < WN; ++n) acc[t][n] = M::run(bc[n][e], ac[t][e], acc[t][n]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -364,45 +390,98 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                 for (int t = 0; t < WM; ++t) ac[t] = an[t];
             });
         }
+        VC_T(t_e);
+        VC_ACC(0, t_b, t_a);   // barrier before staging (waiting for the slowest wave of the previous chunk)
+        VC_ACC(1, t_c, t_b);   // staging: loads + LDS writes
+        VC_ACC(2, t_d, t_c);   // barrier after staging
+        VC_ACC(3, t_e, t_d);   // contraction loop (MFMA + fragment traffic)
     }
 
+    VC_T(t_loop_end);
     // ---- epilogue: (GDN) -> activation -> channel gain -> residual -> store (plain / pixel-shuffle) ----
-    static_for<0, WM>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        const int m = wm * WM + t;
-        const int oy = oy0 + m / C::XT;
-        const int xbase = ox0 + (m % C::XT) * MT;
-        static_for<0, WN>([&](auto nc) {
-            constexpr int n = decltype(nc)::value;
-            const int co = nblk * C::BN + (wn * WN + n) * NT + cj;
-            const bool co_ok = (co < p.Cout) && (oy < p.Ho);
-            const float gain = (p.chscale && co_ok) ? p.chscale[co] : 1.0f;
-            const int cps = p.Cout >> 2;
-            const int pos = (p.out_mode == VC_OUT_PLAIN) ? 0 : co / cps;
-            const int cch = (p.out_mode == VC_OUT_PLAIN) ? co : co - pos * cps;
-            const int sc = (p.out_mode == VC_OUT_PLAIN) ? 1 : 2;
-            const int yy = sc * oy + (pos >> 1);
-            const long long out_row = (long long)img * p.out_sn + (long long)yy * p.out_sh + cch;
-            const long long res_row = (long long)img * p.res_sn + (long long)yy * p.res_sh + cch;
-            const long long mul_row = (long long)img * p.mul_sn + (long long)oy * p.mul_sh + co;
+    // One lane owns one pixel of the M-tile and, per register quad, 4 consecutive output channels: the residual /
+    // GDN-input loads and the store are single 16-byte accesses.  The mode (GDN / IGDN / sigmoid / clamp / plain)
+    // is resolved ONCE per wave: a per-element switch unrolled over 128 accumulators cost ~40k instructions.
+    const int pxl = M::px(lane);
+    auto epilogue = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;   // 0 plain/relu/lrelu, 1 GDN, 2 IGDN, 3 sigmoid, 4 clamp01
+        // plain / ReLU / LeakyReLU share one formula: v >= 0 ? v : v * neg
+        const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+        static_for<0, WM>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int m = wm * WM + t;
+            const int oy = oy0 + m / C::XT;
+            const int ox = ox0 + (m % C::XT) * MT + pxl;
+            const bool pix_ok = (oy < p.Ho) && (ox < p.Wo);
+            const long long mul_pix = (long long)img * p.mul_sn + (long long)oy * p.mul_sh + (long long)ox * p.mul_sw;
+            static_for<0, WN>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
 #pragma unroll
-            for (int r = 0; r < M::NREG; ++r) {
-                const int ox = xbase + M::row(r, lane);
-                float v = acc[t][n][r];
-                if (co_ok && ox < p.Wo) {
-                    if (p.epi != VC_EPI_NONE) {
-                        const float x = p.mul[mul_row + (long long)ox * p.mul_sw];
-                        // IEEE sqrt and divide, like the CPU path's x * rsqrt(norm)
-                        v = (p.epi == VC_EPI_GDN) ? x * (1.0f / sqrtf(v)) : x * sqrtf(v);
+                for (int g = 0; g < M::NREG / 4; ++g) {
+                    const int co = nblk * C::BN + (wn * WN + n) * NT + M::crow(4 * g, lane);   // first of 4 consecutive channels
+                    f32x4 v = {acc[t][n][4 * g], acc[t][n][4 * g + 1], acc[t][n][4 * g + 2], acc[t][n][4 * g + 3]};
+                    if (pix_ok && co < p.Cout) {
+                        const int cps = p.Cout >> 2;
+                        const bool ps = p.out_mode != VC_OUT_PLAIN;
+                        const int pos = ps ? co / cps : 0;
+                        const int cch = ps ? co - pos * cps : co;
+                        const int sc = ps ? 2 : 1;
+                        const int yy = sc * oy + (pos >> 1), xx = sc * ox + (pos & 1);
+                        const long long o_off = (long long)img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
+                        const long long r_off = (long long)img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
+                        if (p.vec_out) {
+                            if constexpr (MODE == 1 || MODE == 2) {
+                                const f32x4 x = *reinterpret_cast<const f32x4 *>(p.mul + mul_pix + co);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)   // IEEE sqrt and divide, like the CPU path's x * rsqrt(norm)
+                                    v[e] = (MODE == 1) ? x[e] * (1.0f / sqrtf(v[e])) : x[e] * sqrtf(v[e]);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if constexpr (MODE == 3) v[e] = 1.0f / (1.0f + expf(-v[e]));
+                                else if constexpr (MODE == 4) v[e] = fminf(fmaxf(v[e], 0.0f), 1.0f);
+                                else if constexpr (MODE == 0) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
+                            }
+                            if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
+                            if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                            *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (co + e < p.Cout) {
+                                    float w = v[e];
+                                    if constexpr (MODE == 1 || MODE == 2) {
+                                        const float x = p.mul[mul_pix + co + e];
+                                        w = (MODE == 1) ? x * (1.0f / sqrtf(w)) : x * sqrtf(w);
+                                    }
+                                    if constexpr (MODE == 3) w = 1.0f / (1.0f + expf(-w));
+                                    else if constexpr (MODE == 4) w = fminf(fmaxf(w, 0.0f), 1.0f);
+                                    else if constexpr (MODE == 0) w = w >= 0.0f ? w : w * neg;
+                                    if (p.chscale) w *= p.chscale[co + e];
+                                    // (pixel-shuffle: a quad may straddle two output positions when cout/4 % 4 != 0)
+                                    const int pe = ps ? (co + e) / cps : 0;
+                                    const int ce = ps ? co + e - pe * cps : co + e;
+                                    const int ye = sc * oy + (pe >> 1), xe = sc * ox + (pe & 1);
+                                    if (p.res) w += p.res[(long long)img * p.res_sn + (long long)ye * p.res_sh + (long long)xe * p.res_sw + ce];
+                                    p.out[(long long)img * p.out_sn + (long long)ye * p.out_sh + (long long)xe * p.out_sw + ce] = w;
+                                }
+                            }
+                        }
                     }
-                    v = apply_act(v, p.act, p.slope) * gain;
-                    const int xx = sc * ox + (pos & 1);
-                    if (p.res) v += p.res[res_row + (long long)xx * p.res_sw];
-                    p.out[out_row + (long long)xx * p.out_sw] = v;
                 }
-            }
+            });
         });
-    });
+    };
+    // (the reference never combines GDN with an activation, nor sigmoid/clamp with GDN)
+    if (p.epi == VC_EPI_GDN) epilogue(std::integral_constant<int, 1>{});
+    else if (p.epi == VC_EPI_IGDN) epilogue(std::integral_constant<int, 2>{});
+    else if (p.act == VC_ACT_SIGMOID) epilogue(std::integral_constant<int, 3>{});
+    else if (p.act == VC_ACT_CLAMP01) epilogue(std::integral_constant<int, 4>{});
+    else epilogue(std::integral_constant<int, 0>{});
+    VC_T(t_end);
+    VC_ACC(4, t_end, t_loop_end);   // epilogue
+    VC_ACC(5, t_end, t_start);      // whole wave lifetime after the prologue
+    VC_ACC(6, 1ull, 0ull);          // waves
 }
 
 template <int KH, int KW, int S, int CK, class C, bool F16 = false> int launch_conv(hipStream_t st, const ConvArgs &a)
@@ -423,15 +502,33 @@ template <int KH, int KW, int S, int CK, class C, bool F16 = false> int launch_c
     return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
 }
 
-// fp32 or fp16 instance of the same tile configuration
-template <int KH, int KW, int S, int CK, class C> int launch_conv_p(hipStream_t st, const ConvArgs &a, bool f16)
+// Every dispatcher source is compiled twice (parallel build): -DVC_TU_F16=0 gives the fp32 instances and the
+// conv_dispatch_kN_f32 symbol, -DVC_TU_F16=1 the fp16 ones (conv_dispatch_kN_f16).  The N4 tile exists in fp32 only.
+#ifdef VC_TU_F16
+template <int KH, int KW, int S, int CK, class C> int launch_conv_p(hipStream_t st, const ConvArgs &a)
 {
-    return f16 ? launch_conv<KH, KW, S, CK, C, true>(st, a) : launch_conv<KH, KW, S, CK, C, false>(st, a);
+    return launch_conv<KH, KW, S, CK, C, VC_TU_F16 != 0>(st, a);
 }
+template <int KH, int KW, int S, int CK> int launch_conv_n4(hipStream_t st, const ConvArgs &a)
+{
+#if VC_TU_F16
+    return VC_EINVAL;
+#else
+    return launch_conv<KH, KW, S, CK, CfgN4, false>(st, a);
+#endif
+}
+#if VC_TU_F16
+#define VC_DISPATCH(k) conv_dispatch_##k##_f16
+#else
+#define VC_DISPATCH(k) conv_dispatch_##k##_f32
+#endif
+#endif
 
-// one translation unit per kernel size (parallel build); each exports a dispatcher over the tile configs
-// (`ck` = LDS floats per pixel of the instance; `f16` selects the half-precision instance of 32-wide tiles)
-int conv_dispatch_k1(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16);
-int conv_dispatch_k3(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16);
-int conv_dispatch_k5(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16);
-int conv_dispatch_k7(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck, bool f16);
+// one dispatcher over the tile configs per kernel size and precision (`ck` = LDS floats per pixel of the instance)
+#define VC_DECLARE_DISPATCH(k)                                                             \
+    int conv_dispatch_##k##_f32(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck); \
+    int conv_dispatch_##k##_f16(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
+VC_DECLARE_DISPATCH(k1)
+VC_DECLARE_DISPATCH(k3)
+VC_DECLARE_DISPATCH(k5)
+VC_DECLARE_DISPATCH(k7)
