@@ -152,6 +152,32 @@ int vc_flex_blend(vc_stream s, vc_view xb, vc_view xa, vc_view mask, vc_view cur
 int vc_flex_motion_split(vc_stream s, vc_view flow4, vc_view ft0, vc_view ft1, float t);
 
 /* ------------------------------------------------------------------------------------------
+ * ICIP2024 flow-guided deformable compensation
+ * ---------------------------------------------------------------------------------------- */
+/* Quantise-and-mask used by the checkerboard / channel-context entropy model
+ * (ICIP2024/src/model/compression_bottlenecks.py:237-246,268-269):
+ *   out = keep(y,x) ? (do_round ? round_half_even(in) : in) * (gain ? gain[c] : 1) : 0
+ * keep_parity: -1 keeps every position, 0 keeps (y+x) even, 1 keeps (y+x) odd ("anchors":
+ * y_half[:, :, 0::2, 0::2] = 0; y_half[:, :, 1::2, 1::2] = 0  <=>  keep_parity 1;
+ * ctx_params[:, :, 0::2, 1::2] = 0; ctx_params[:, :, 1::2, 0::2] = 0  <=>  keep_parity 0).  in may alias out. */
+int vc_quantize_mask(vc_stream s, vc_view in, vc_view out, const float *gain, int keep_parity, int do_round);
+
+/* torchvision.ops.deform_conv2d, modulated (DCNv2), kernel 3x3, stride 1, padding 1, dilation 1, as called at
+ * ICIP2024/src/model/helpers.py:56 (DeformConv2d(2C, C, 3, padding=1, groups=16)):
+ *   in [n,h,w,G*cg], offset [n,h,w,G*9*2] (per group and tap: dy then dx), mask [n,h,w,G*9] (p==0: all ones),
+ *   out [n,h,w,G*og]; conv groups == offset groups == G, cg in {4,8,12,16}, og <= 8.
+ * wpk: weights re-laid out by vc_deform_pack_weights ([G][9][cg][og] floats), bias [G*og] or NULL. */
+int vc_deform_pack_weights(const float *w_oihw, int cout, int cin_per_group, int groups, float *dst);
+int vc_deform_conv2d(vc_stream s, vc_view in, vc_view offset, vc_view mask, const float *wpk, const float *bias,
+                     int groups, vc_view out);
+/* OffsetDiversity.forward (helpers.py:43-58) in one launch: for each reference r in {1,2}
+ *   o1, o2, m = chunk(raw_r, 3); offset_r = tanh(cat(o1,o2))*magnitude + flow_r.flip(1).repeat(..); mask_r = sigmoid(m)
+ * then deform_conv2d(cat(x1,x2), cat(offset1,offset2), cat(mask1,mask2)) with groups 0..G/2-1 reading x1 and
+ * the rest x2.  raw_r [n,h,w,27*G/2], flow_r [n,h,w,2] = (u,v), x_r [n,h,w,(G/2)*cg], out [n,h,w,G*og]. */
+int vc_offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2,
+                        float magnitude, const float *wpk, const float *bias, int groups, vc_view out);
+
+/* ------------------------------------------------------------------------------------------
  * Entropy models (CompressAI EntropyBottleneck / GaussianConditional)
  * ---------------------------------------------------------------------------------------- */
 /* Factorised prior parameters for C channels, pre-resolved on the host at load time:

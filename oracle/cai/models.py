@@ -114,3 +114,57 @@ class ImageMeanScaleHyperprior(MeanScaleHyperprior):
 def mbt2018_mean(quality, metric="mse", pretrained=False):
     n, m = (128, 192) if quality <= 4 else (192, 320)
     return ImageMeanScaleHyperprior(n, m)
+
+
+# ---------------------------------------------------------------------------------------------------
+# compressai.models.JointAutoregressiveHierarchicalPriors (v1.1.8) -- the parent class of the ICIP2024
+# compressors (ICIP2024/src/model/compression_bottlenecks.py:72,322).  Those subclasses replace h_a, h_s
+# and entropy_parameters and never call the parent's forward; g_a, g_s and context_prediction survive
+# only as (dead) entries of the state_dict, which a strict checkpoint load still needs.
+# PARITY UNPINNED like the rest of this package.
+# ---------------------------------------------------------------------------------------------------
+class MaskedConv2d(nn.Conv2d):
+    """Type-A/B masked convolution (PixelCNN); buffer ``mask`` is part of the state_dict."""
+
+    def __init__(self, *args, mask_type="A", **kwargs):
+        super().__init__(*args, **kwargs)
+        if mask_type not in ("A", "B"):
+            raise ValueError(f'Invalid "mask_type" value "{mask_type}"')
+        self.register_buffer("mask", torch.ones_like(self.weight.data))
+        _, _, h, w = self.mask.size()
+        self.mask[:, :, h // 2, w // 2 + (mask_type == "B"):] = 0
+        self.mask[:, :, h // 2 + 1:] = 0
+
+    def forward(self, x):
+        self.weight.data *= self.mask
+        return super().forward(x)
+
+
+class JointAutoregressiveHierarchicalPriors(MeanScaleHyperprior):
+    def __init__(self, N=192, M=192, **kwargs):
+        from .layers import GDN
+        super().__init__(N=N, M=M, **kwargs)
+        self.g_a = nn.Sequential(_conv(3, N), GDN(N), _conv(N, N), GDN(N), _conv(N, N), GDN(N), _conv(N, M))
+        self.g_s = nn.Sequential(_deconv(M, N), GDN(N, inverse=True), _deconv(N, N), GDN(N, inverse=True),
+                                 _deconv(N, N), GDN(N, inverse=True), _deconv(N, 3))
+        self.h_a = nn.Sequential(_conv(M, N, stride=1, kernel_size=3), nn.LeakyReLU(inplace=True),
+                                 _conv(N, N, stride=2, kernel_size=5), nn.LeakyReLU(inplace=True),
+                                 _conv(N, N, stride=2, kernel_size=5))
+        self.h_s = nn.Sequential(_deconv(N, M, stride=2, kernel_size=5), nn.LeakyReLU(inplace=True),
+                                 _deconv(M, M * 3 // 2, stride=2, kernel_size=5), nn.LeakyReLU(inplace=True),
+                                 _conv(M * 3 // 2, M * 2, stride=1, kernel_size=3))
+        self.entropy_parameters = nn.Sequential(
+            nn.Conv2d(M * 12 // 3, M * 10 // 3, 1), nn.LeakyReLU(inplace=True),
+            nn.Conv2d(M * 10 // 3, M * 8 // 3, 1), nn.LeakyReLU(inplace=True),
+            nn.Conv2d(M * 8 // 3, M * 6 // 3, 1))
+        self.context_prediction = MaskedConv2d(M, 2 * M, kernel_size=5, padding=2, stride=1)
+        self.gaussian_conditional = GaussianConditional(None)
+        self.N, self.M = int(N), int(M)
+
+
+class Cheng2020Anchor(nn.Module):
+    """Imported by ICIP2024/src/model/compression_bottlenecks.py:7 and never instantiated on the path."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("Cheng2020Anchor is not on the hot path")

@@ -7,7 +7,8 @@ bundled frames, LHBDC/frames/*.png), the seed of the synthetic checkpoint, and t
 
 Stand-ins needed to import the reference here:
   * ``compressai``  -> ``oracle.cai`` (the library is not installed; PARITY UNPINNED at that boundary)
-  * ``torchvision.ops.deform_conv`` -> empty stub (imported by Flex b_model.py:6, unused)
+  * ``torchvision.ops.deform_conv`` -> empty stub (imported by Flex b_model.py:6, unused);
+    ``torchvision.ops.DeformConv2d`` -> ``oracle.deform.DeformConv2d`` (ICIP2024 helpers.py:10; PARITY UNPINNED there too)
   * module-level ``device = torch.device("cuda")`` patched to CPU; ``Tensor.cuda`` -> identity
 The CLI scripts (encode_B.py / decode_B.py) execute on import, so only their function definitions are
 pulled out with ``ast`` and executed in a scratch namespace.
@@ -33,7 +34,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "video-compression_amd"))
 
-from oracle import cai, flex as oflex, lhbdc as olhbdc  # noqa: E402
+from oracle import cai, deform as odeform, flex as oflex, icip2024 as oicip, lhbdc as olhbdc  # noqa: E402
 from vcamd.seeding import seeded_state_dict  # noqa: E402
 
 
@@ -44,6 +45,7 @@ def install_standins():
     sys.modules["compressai.layers"] = cai.layers
     sys.modules["compressai.entropy_models"] = cai.entropy_models
     sys.modules["compressai.models"] = cai.models
+    sys.modules["compressai.ans"] = cai.ans
     utils = types.ModuleType("compressai.models.utils")
     utils.conv = lambda i, o, kernel_size=5, stride=2: nn.Conv2d(i, o, kernel_size, stride, kernel_size // 2)
     utils.deconv = lambda i, o, kernel_size=5, stride=2: nn.ConvTranspose2d(
@@ -56,6 +58,7 @@ def install_standins():
     tv = types.ModuleType("torchvision")
     tv.ops = types.ModuleType("torchvision.ops")
     tv.ops.deform_conv = types.ModuleType("torchvision.ops.deform_conv")
+    tv.ops.DeformConv2d = odeform.DeformConv2d
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.ops"] = tv.ops
     sys.modules["torchvision.ops.deform_conv"] = tv.ops.deform_conv
@@ -257,6 +260,82 @@ def gen_flex(outdir, frames, seed):
             decoded=dec_r.numpy())
 
 
+def gen_icip2024(outdir, frames, seed):
+    """ICIP2024 FlowGuidedB.forward, the flow-resolution search and the GOP-16 bookkeeping, run from the reference's
+    own modules (src/model/*.py, src/opt_helpers.py, src/utils.py) with the stand-ins above."""
+    import json
+    nat = types.ModuleType("natsort")
+    nat.natsorted = sorted
+    sys.modules.setdefault("natsort", nat)
+    sys.path.insert(0, os.path.join(REF, "ICIP2024"))
+    from src.model import m as ref_m  # noqa
+    from src import opt_helpers as ref_opt  # noqa
+    from src import utils as ref_utils  # noqa
+    sys.path.pop(0)
+    torch.manual_seed(0)
+    ref = ref_m.FlowGuidedB().eval()
+    sd = seeded_state_dict(ref.state_dict(), seed=seed)
+    ref.load_state_dict(sd)
+    ora = oicip.FlowGuidedB().eval()
+    ora.load_state_dict(sd)
+    schema = sorted((k, tuple(v.shape)) for k, v in ref.state_dict().items())
+    with open(os.path.join(outdir, "icip2024_state_schema.txt"), "w") as f:
+        f.write("\n".join(f"{k} {list(s)}" for k, s in schema) + "\n")
+    y0, x0, h, w = 300, 640, 128, 192
+    c = crop(frames, y0, x0, h, w)
+    x1, xc, x2 = to_tensor(c["ref_1"]), to_tensor(c["current"]), to_tensor(c["ref_2"])
+    store = dict(seed=np.int64(seed), ref_1=c["ref_1"], current=c["current"], ref_2=c["ref_2"])
+    with torch.no_grad():
+        for tag, (s1, s2, lvl, dr) in {"a": (0.5, 0.5, 1, 1), "b": (0.25, 0.75, 2.5, 2), "c": (0.5, 0.5, 4, 4)}.items():
+            print(f"  ICIP2024 forward fixture {tag}: scales=({s1},{s2}) s={lvl} down_ratio={dr}")
+            rr = ref(xref1=x1, xref2=x2, scale1=s1, scale2=s2, xcur=xc, s=lvl, down_ratio=dr)
+            ro = ora(x1, x2, s1, s2, xc, lvl, dr)
+            check("FlowGuidedB x_hat", ro["x_hat"], rr["x_hat"])
+            check("FlowGuidedB size", ro["size"], rr["size"])
+            check("FlowGuidedB rate", ro["rate"], rr["rate"])
+            check("estimate_flow", ora.estimate_flow(x1, x2, dr), ref.estimate_flow(x1, x2, dr))
+            store[f"cfg_{tag}"] = np.array([s1, s2, lvl, dr], dtype=np.float64)
+            store[f"x_hat_{tag}"] = rr["x_hat"].numpy()
+            store[f"flow_{tag}"] = ref.estimate_flow(x1, x2, dr).numpy()
+            store[f"size_{tag}"] = np.float64(rr["size"].item())
+            store[f"rate_{tag}"] = np.float64(rr["rate"].item())
+        for dr in (1, 2, 4, 8, 16):
+            pr = ref_opt.prediction_flowonly(ref, xc, x1, x2, 0.5, 0.5, dr)
+            check(f"prediction_flowonly dr={dr}", oicip.prediction_flowonly(ora, xc, x1, x2, 0.5, 0.5, dr), pr)
+            store[f"pred_dr{dr}"] = pr.numpy()
+        best_r, psnr_r = ref_opt.get_best_down_ratio_prediction(ref, x1, x2, 0.5, 0.5, xc, 1, None)
+        best_o, psnr_o = oicip.get_best_down_ratio_prediction(ora, x1, x2, 0.5, 0.5, xc)
+        check("best down ratio", best_o, best_r)
+        check("best prediction psnr", psnr_o, psnr_r)
+        store["best_down_ratio"] = np.int64(best_r)
+        store["best_pred_psnr"] = np.float64(psnr_r.item())
+    np.savez_compressed(os.path.join(outdir, "icip2024_forward_a.npz"), **store)
+
+    book = {"order_typ": {}, "refs": {}}
+    for n_frames in (17, 33, 40, 300, 600):
+        o_r, t_r = ref_utils.get_order_typ_list(16, n_frames)
+        o_o, t_o = oicip.get_order_typ_list(16, n_frames)
+        if list(o_r) != list(o_o) or list(t_r) != list(t_o):
+            raise SystemExit(f"oracle get_order_typ_list differs from the reference for {n_frames} frames")
+        book["order_typ"][str(n_frames)] = {"order": [int(v) for v in o_r], "typ": "".join(t_r)}
+        buf, buf_order, picks = [], [], []
+        for order in o_r:                       # the buffer discipline of src/test.py:56-96 on frame numbers alone
+            if t_r[order] == "B":
+                _, _, o1, o2 = ref_utils.select_references(None, order, buf, buf_order)
+                lo, hi = oicip.select_references(order, buf_order)
+                if (buf_order[lo], buf_order[hi]) != (o1, o2):
+                    raise SystemExit("oracle select_references differs from the reference")
+                s_r, s_o = ref_utils.get_scales(order, o1, o2), oicip.get_scales(order, o1, o2)
+                if tuple(s_r) != tuple(s_o):
+                    raise SystemExit("oracle get_scales differs from the reference")
+                picks.append([int(order), int(o1), int(o2), float(s_r[0]), float(s_r[1])])
+            buf, buf_order = ref_utils.update_buffer(buf, buf_order, order, order)
+        book["refs"][str(n_frames)] = picks
+    with open(os.path.join(outdir, "icip2024_gop16_bookkeeping.json"), "w") as f:
+        json.dump(book, f)
+    print("  ICIP2024 bookkeeping fixture:", {k: len(v) for k, v in book["refs"].items()})
+
+
 def gen_harness(outdir):
     """G5: item lists of the reference's own UVGTestDataset (LHBDC/test/utils.py:162-203 and the Flex twin)
     for synthetic directory listings -- natsort / imageio / glob are stubbed, the class body is the reference's."""
@@ -295,7 +374,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--only", choices=["lhbdc", "flex", "harness"], default=None)
+    ap.add_argument("--only", choices=["lhbdc", "flex", "harness", "icip2024"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         raise SystemExit("/root/reference is not present: fixtures can only be generated in the build container")
@@ -309,6 +388,8 @@ def main():
         gen_lhbdc(args.out, frames, args.seed)
     if args.only in (None, "flex"):
         gen_flex(args.out, frames, args.seed)
+    if args.only in (None, "icip2024"):
+        gen_icip2024(args.out, frames, args.seed)
     if args.only in (None, "harness"):
         gen_harness(args.out)
     print("fixtures written to", args.out)

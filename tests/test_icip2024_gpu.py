@@ -1,0 +1,163 @@
+"""-m gpu: the ICIP2024 FlowGuidedB path (deformable compensation, checkerboard + channel-context entropy model)
+over the HIP kernels, against the fixtures recorded from the reference and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import frame_tensor, load_fixture, psnr
+
+pytestmark = pytest.mark.gpu
+PSNR_TOL_DB = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    from oracle import icip2024 as oi
+    from vcamd import icip2024
+    from vcamd.seeding import seeded_state_dict
+    prod = icip2024.FlowGuidedB()
+    sd = seeded_state_dict(prod.state_dict(), seed=1234)
+    prod.load_state_dict(sd)
+    ora = oi.FlowGuidedB().eval()
+    ora.load_state_dict(sd)
+    return ora, prod.to(dev).eval()
+
+
+def _nhwc(x, dev):
+    from vcamd import hip
+    return hip.nchw_to_nhwc(x.to(dev))
+
+
+@pytest.mark.parametrize("c,groups,h,w", [(64, 16, 24, 40), (96, 16, 17, 23), (128, 16, 16, 16), (32, 8, 9, 11)])
+def test_deform_conv2d_matches_oracle(dev, c, groups, h, w):
+    """Generic operator: random offsets up to +-6 px (many samples leave the image) and random masks."""
+    from oracle import deform as od
+    from vcamd import hip
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(2, 2 * c, h, w, generator=g)
+    off = (torch.rand(2, groups * 18, h, w, generator=g) - 0.5) * 12
+    msk = torch.rand(2, groups * 9, h, w, generator=g)
+    wt = torch.randn(c, 2 * c // groups, 3, 3, generator=g) * 0.2
+    b = torch.randn(c, generator=g)
+    ref = od.deform_conv2d(x, off, wt, b, padding=(1, 1), mask=msk)
+    pk = hip.PackedDeform(wt, b, groups, dev)
+    out = hip.nhwc_to_nchw(pk.conv(_nhwc(x, dev), _nhwc(off, dev), _nhwc(msk, dev))).cpu()
+    assert ((out - ref).abs() / (1 + ref.abs())).max().item() < 2e-5
+    ref_nomask = od.deform_conv2d(x, off, wt, b, padding=(1, 1), mask=None)
+    out = hip.nhwc_to_nchw(pk.conv(_nhwc(x, dev), _nhwc(off, dev))).cpu()
+    assert ((out - ref_nomask).abs() / (1 + ref_nomask.abs())).max().item() < 2e-5
+
+
+@pytest.mark.parametrize("c,mag", [(64, 40), (96, 20), (128, 10)])
+def test_offset_diversity_matches_oracle(dev, c, mag):
+    """Fused OffsetDiversity.forward: tanh/sigmoid preparation + flipped flow + grouped deformable conv."""
+    from oracle import icip2024 as oi
+    from vcamd import icip2024
+    g = torch.Generator().manual_seed(c)
+    h, w = 20, 28
+    ora = oi.OffsetDiversity(c, mag)
+    prod = icip2024.OffsetDiversity(c, mag)
+    with torch.no_grad():
+        ora.fusion.weight.copy_(torch.randn(ora.fusion.weight.shape, generator=g) * 0.2)
+        ora.fusion.bias.copy_(torch.randn(c, generator=g))
+    prod.load_state_dict(ora.state_dict())
+    prod = prod.to(dev)
+    x1, x2 = torch.randn(1, c, h, w, generator=g), torch.randn(1, c, h, w, generator=g)
+    o1, o2 = torch.randn(1, 216, h, w, generator=g), torch.randn(1, 216, h, w, generator=g)
+    f1, f2 = torch.randn(1, 2, h, w, generator=g) * 3, torch.randn(1, 2, h, w, generator=g) * 3
+    f1[0, :, 0, 0] = float("inf")                       # a broken flow vector must not fault
+    with torch.no_grad():
+        ref = ora(x1, o1, f1, x2, o2, f2)
+    from vcamd import hip
+    out = hip.nhwc_to_nchw(prod.run(*[_nhwc(t, dev) for t in (x1, o1, f1, x2, o2, f2)])).cpu()
+    ok = torch.isfinite(ref)
+    assert ((out - ref).abs() / (1 + ref.abs()))[ok].max().item() < 5e-5
+
+
+def test_quantize_mask(dev):
+    from vcamd import hip
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 10, 7, 9, generator=g) * 3
+    x[0, 0, 0, :4] = torch.tensor([0.5, 1.5, 2.5, -0.5])     # half-to-even
+    gain = torch.rand(10, generator=g) + 0.5
+    t = _nhwc(x, dev)
+    yy, xx = torch.meshgrid(torch.arange(7), torch.arange(9), indexing="ij")
+    odd = ((yy + xx) % 2 == 1).float()
+    assert torch.equal(hip.nhwc_to_nchw(hip.quantize_mask(t)).cpu(), torch.round(x))
+    assert torch.equal(hip.nhwc_to_nchw(hip.quantize_mask(t, keep_parity=1)).cpu(), torch.round(x) * odd)
+    assert torch.equal(hip.nhwc_to_nchw(hip.quantize_mask(t, keep_parity=0, do_round=False)).cpu(), x * (1 - odd))
+    out = hip.nhwc_to_nchw(hip.quantize_mask(t, gain=gain.to(dev))).cpu()
+    assert torch.allclose(out, torch.round(x) * gain.view(1, -1, 1, 1), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("dr", [1, 2, 4, 8])
+def test_estimate_flow_matches_oracle(dev, models, dr):
+    ora, prod = models
+    fx = load_fixture("icip2024_forward_a.npz")
+    x1, x2 = (frame_tensor(fx[k]) for k in ("ref_1", "ref_2"))
+    with torch.no_grad():
+        ref = ora.estimate_flow(x1, x2, dr)
+    out = prod.estimate_flow(x1.to(dev), x2.to(dev), dr).cpu()
+    assert out.shape == ref.shape
+    assert ((out - ref).abs() / (1 + ref.abs())).max().item() < 2e-4
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_forward_matches_reference_fixture(dev, models, tag):
+    _, prod = models
+    fx = load_fixture("icip2024_forward_a.npz")
+    x1, xc, x2 = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    s1, s2, lvl, drr = (float(v) for v in fx[f"cfg_{tag}"])
+    with torch.no_grad():
+        out = prod(x1, x2, s1, s2, xc, lvl, int(drr))
+    ref = torch.from_numpy(fx[f"x_hat_{tag}"])
+    src = frame_tensor(fx["current"])
+    d_psnr = abs(psnr(out["x_hat"].cpu(), src) - psnr(ref, src))
+    rel = abs(out["size"].item() - float(fx[f"size_{tag}"])) / float(fx[f"size_{tag}"])
+    print(f"icip2024 {tag}: max|d|={(out['x_hat'].cpu() - ref).abs().max():.3e} dPSNR={d_psnr:.2e} size rel={rel:.2e}")
+    assert d_psnr < PSNR_TOL_DB and rel < 2e-3
+    assert abs(out["rate"].item() - float(fx[f"rate_{tag}"])) / float(fx[f"rate_{tag}"]) < 2e-3
+
+
+def test_forward_matches_oracle_on_other_frames(dev, models):
+    """A different crop (256x192, asymmetric scales, interpolated quality level) against the oracle run live."""
+    ora, prod = models
+    fx = load_fixture("lhbdc_forward_b.npz")
+    x1, xc, x2 = (frame_tensor(fx[k]) for k in ("ref_1", "current", "ref_2"))
+    with torch.no_grad():
+        ref = ora(x1, x2, 0.75, 0.25, xc, 1.5, 2)
+        out = prod(x1.to(dev), x2.to(dev), 0.75, 0.25, xc.to(dev), 1.5, 2)
+    d_psnr = abs(psnr(out["x_hat"].cpu(), xc) - psnr(ref["x_hat"], xc))
+    rel = abs(out["size"].item() - ref["size"].item()) / ref["size"].item()
+    print(f"icip2024 live: dPSNR={d_psnr:.2e} size rel={rel:.2e}")
+    assert d_psnr < PSNR_TOL_DB and rel < 2e-3
+
+
+def test_down_ratio_search_matches_fixture(dev, models):
+    from vcamd import icip2024
+    _, prod = models
+    fx = load_fixture("icip2024_forward_a.npz")
+    x1, xc, x2 = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    for dr in (1, 2, 4, 8, 16):
+        pred = icip2024.prediction_flowonly(prod, xc, x1, x2, 0.5, 0.5, dr).cpu()
+        assert (pred - torch.from_numpy(fx[f"pred_dr{dr}"])).abs().max().item() < 2e-4
+    best, best_psnr = icip2024.get_best_down_ratio_prediction(prod, x1, x2, 0.5, 0.5, xc)
+    assert best == int(fx["best_down_ratio"]) and abs(best_psnr.item() - float(fx["best_pred_psnr"])) < 1e-3
+
+
+def test_rejects_cpu_tensors_and_unpadded_frames(dev, models):
+    from vcamd import hip
+    _, prod = models
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(hip.VcError):
+        prod(x, x, 0.5, 0.5, x, 1, 1)
+    y = torch.zeros(1, 3, 72, 64, device=dev)
+    with pytest.raises(hip.VcError):
+        prod(y, y, 0.5, 0.5, y, 1, 1)

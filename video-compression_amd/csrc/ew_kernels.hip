@@ -284,6 +284,39 @@ extern "C" int vc_channel_scale(vc_stream s, vc_view a, const float *gain, vc_vi
 }
 
 // ------------------------------------------------------------------------------------------------
+// quantise + checkerboard mask (ICIP2024 compression_bottlenecks.py:237-246,268-269)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_quantize_mask(vc_view in, vc_view out, const float *__restrict__ gain, int keep_parity, int do_round)
+{
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        float v = 0.0f;
+        if (keep_parity < 0 || ((x + y) & 1) == keep_parity) {
+            v = in.p[view_off(in, n, y, x) + c];
+            if (do_round) v = rintf(v);
+            if (gain) v *= gain[c];
+        }
+        out.p[view_off(out, n, y, x) + c] = v;
+    }
+}
+
+extern "C" int vc_quantize_mask(vc_stream s, vc_view in, vc_view out, const float *gain, int keep_parity, int do_round)
+{
+    if (!in.p || !out.p || in.c < out.c || in.h != out.h || in.w != out.w || in.n != out.n) return VC_EINVAL;
+    if (keep_parity < -1 || keep_parity > 1) return VC_EINVAL;
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_quantize_mask, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out, gain,
+                       keep_parity, do_round);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // warping: torch.grid_sample(bilinear, align_corners=False) behind the reference's two grid recipes
 // ------------------------------------------------------------------------------------------------
 // torch.linspace(start, end, steps)[i] in fp32 (symmetric evaluation from both ends)

@@ -122,6 +122,10 @@ def lib():
     sig("vc_lhbdc_blend", ci, vp, View, View, View, View, View)
     sig("vc_flex_blend", ci, vp, View, View, View, View, View, View)
     sig("vc_flex_motion_split", ci, vp, View, View, View, cf)
+    sig("vc_quantize_mask", ci, vp, View, View, vp, ci, ci)
+    sig("vc_deform_pack_weights", ci, vp, ci, ci, ci, vp)
+    sig("vc_deform_conv2d", ci, vp, View, View, View, vp, vp, ci, View)
+    sig("vc_offset_diversity", ci, vp, View, View, View, View, View, View, cf, vp, vp, ci, View)
     sig("vc_eb_forward", ci, vp, View, vp, vp, vp, View, vp, vp, ci)
     sig("vc_eb_dequant", ci, vp, vp, vp, vp, View)
     sig("vc_gc_forward", ci, vp, View, View, View, vp, vp, View, vp, ci, vp, vp, vp, vp, ci)
@@ -143,7 +147,8 @@ EXPORTED_SYMBOLS = [
     "vc_conv_pack_weights_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
-    "vc_flex_motion_split", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
+    "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity",
+    "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
     "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes",
 ]
@@ -392,6 +397,62 @@ def warp(convention, img, flow, out=None):
         out = T.empty(img.n, flow.h, flow.w, img.c, img.buf.device)
     check(lib().vc_warp(stream(), convention, img.view(), flow.view(), out.view()), "vc_warp")
     return out
+
+
+def channel_scale(x, gain, out=None):
+    if out is None:
+        out = T.empty(x.n, x.h, x.w, x.c, x.buf.device)
+    check(lib().vc_channel_scale(stream(), x.view(), gain.data_ptr(), out.view()), "vc_channel_scale")
+    return out
+
+
+def quantize_mask(x, out=None, gain=None, keep_parity=-1, do_round=True):
+    """ICIP2024 entropy-model glue: out = keep ? round(x) * gain : 0 (see vc_quantize_mask)."""
+    if out is None:
+        out = T.empty(x.n, x.h, x.w, x.c, x.buf.device)
+    check(lib().vc_quantize_mask(stream(), x.view(), out.view(), None if gain is None else gain.data_ptr(),
+                                 keep_parity, int(do_round)), "vc_quantize_mask")
+    return out
+
+
+class PackedDeform:
+    """Weights of a torchvision DeformConv2d(k=3, padding=1, groups=G) re-laid out per group for vc_deform_conv2d."""
+
+    def __init__(self, weight, bias, groups, device):
+        w = weight.detach().to("cpu", torch.float32).contiguous().numpy()
+        cout, cg, kh, kw = w.shape
+        if (kh, kw) != (3, 3) or cout % groups:
+            raise VcError("only 3x3 grouped deformable convolutions are supported")
+        dst = np.empty(groups * 9 * cg * (cout // groups), dtype=np.float32)
+        check(lib().vc_deform_pack_weights(w.ctypes.data, cout, cg, groups, dst.ctypes.data), "vc_deform_pack_weights")
+        self.wpk = torch.from_numpy(dst).to(device)
+        self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+        self.groups, self.cout, self.cin = groups, cout, cg * groups
+
+    def _bias_ptr(self):
+        return None if self.bias is None else self.bias.data_ptr()
+
+    def conv(self, x, offset, mask=None, out=None):
+        if out is None:
+            out = T.empty(x.n, x.h, x.w, self.cout, x.buf.device)
+        check(lib().vc_deform_conv2d(stream(), x.view(), offset.view(), NULL_VIEW if mask is None else mask.view(),
+                                     self.wpk.data_ptr(), self._bias_ptr(), self.groups, out.view()), "vc_deform_conv2d")
+        return out
+
+    def offset_diversity(self, x1, raw1, flow1, x2, raw2, flow2, magnitude, out=None):
+        if out is None:
+            out = T.empty(x1.n, x1.h, x1.w, self.cout, x1.buf.device)
+
+        def launch():
+            check(lib().vc_offset_diversity(stream(), x1.view(), raw1.view(), flow1.view(), x2.view(), raw2.view(),
+                                            flow2.view(), float(magnitude), self.wpk.data_ptr(), self._bias_ptr(),
+                                            self.groups, out.view()), "vc_offset_diversity")
+        if timer is None:
+            launch()
+        else:
+            flops = 2.0 * x1.n * x1.h * x1.w * self.cout * (self.cin // self.groups) * 9
+            timer.bracket(f"deform k3 {self.cin}->{self.cout} g{self.groups} @{x1.n}x{x1.h}x{x1.w}", flops, launch)
+        return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,602 @@
+"""ICIP2024 flow-guided deformable B-frame codec on MI355X -- host-side mirror of the reference surface.
+
+Drop-in for (under /root/reference/ICIP2024/src):
+  model/m.py:31-282                        FlowGuidedB                      -> :class:`FlowGuidedB`
+  model/helpers.py:35-259                  OffsetDiversity, MS_Feature, FlowNET, OffsetTemproalEnc,
+                                           ResidualTemproalEnc, Reconstuctor -> same names
+  model/elic.py:69-83                      ResidualBottleneckBlock          -> same name
+  model/layers.py:6-29                     CheckerboardContext              -> same name
+  model/compression_bottlenecks.py:72-551  Offset_ELIC / Res_ELIC           -> same names
+  opt_helpers.py:23-51                     prediction_flowonly, get_best_down_ratio_prediction
+  utils.py:153-250                         select_references, update_buffer, get_order_typ_list, get_scales
+Attribute names reproduce the reference's state_dict keys (1126 entries, tests/golden/icip2024_state_schema.txt),
+including the never-executed g_a / g_s / context_prediction members the compressors inherit from CompressAI's
+JointAutoregressiveHierarchicalPriors.  The modules only hold parameters; compute goes through libvc_hip.so.
+
+torch.cat of the reference is never materialised at 1/2 and 1/4 resolution: producers write straight into channel
+slices of the concat buffers, and a convolution over ``cat([a, b])`` whose operands live in different buffers runs
+as two launches (weights split along the input channels, the second accumulating through the residual input).
+The reference has no compress() for this model (rate = likelihood estimate only).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .hip import T
+from .layers import (GDN, BitCounter, EntropyBottleneck, GaussianConditional, _Prepared, conv1x1, conv3x3, pack_conv,
+                     run_sequential, subpel_conv3x3)
+from .lhbdc import _require_cuda, _require_frames
+
+
+def conv(in_channels, out_channels, kernel_size=5, stride=2):
+    return nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=kernel_size // 2)
+
+
+def deconv(in_channels, out_channels, kernel_size=5, stride=2):
+    return nn.ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                              output_padding=stride - 1, padding=kernel_size // 2)
+
+
+class ResidualBottleneckBlock(_Prepared):
+    """1x1 -> ReLU -> 3x3 -> ReLU -> 1x1, plus identity (elic.py:69-83); the add rides in the last epilogue."""
+    vc_block = True
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.BottleneckBlock = nn.Sequential(conv1x1(in_ch, out_ch), nn.ReLU(inplace=True), conv3x3(out_ch, out_ch),
+                                             nn.ReLU(inplace=True), conv1x1(out_ch, out_ch))
+
+    def run(self, x, out=None):
+        if self._packed is None:
+            b = self.BottleneckBlock
+            self._packed = (pack_conv(b[0]), pack_conv(b[2]), pack_conv(b[4]))
+        c1, c2, c3 = self._packed
+        return c3(c2(c1(x, act=hip.ACT_RELU), act=hip.ACT_RELU), res=x, out=out)
+
+
+def _rbb(c, n=3):
+    return [ResidualBottleneckBlock(c, c) for _ in range(n)]
+
+
+class CheckerboardContext(nn.Conv2d):
+    """layers.py:6-29: 5x5 convolution with the weights masked to the (row+col) odd taps (mask is a buffer)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.register_buffer("mask", torch.zeros_like(self.weight.data))
+        self.mask[:, :, 0::2, 1::2] = 1
+        self.mask[:, :, 1::2, 0::2] = 1
+
+
+class MaskedConv2d(nn.Conv2d):
+    """compressai.layers.MaskedConv2d: parameter/buffer holder only (dead member of the parent class)."""
+
+    def __init__(self, *args, mask_type="A", **kwargs):
+        super().__init__(*args, **kwargs)
+        self.register_buffer("mask", torch.ones_like(self.weight.data))
+        _, _, h, w = self.mask.size()
+        self.mask[:, :, h // 2, w // 2 + (mask_type == "B"):] = 0
+        self.mask[:, :, h // 2 + 1:] = 0
+
+
+class _Seq(_Prepared):
+    """Owner of the packed-weight caches of its nn.Sequential members."""
+
+    def __init__(self):
+        super().__init__()
+        self._caches = {}
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._caches = {}
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._caches = {}
+        return super()._apply(fn, *a, **k)
+
+    def seq(self, name, x, **kw):
+        return run_sequential(getattr(self, name), x, self._caches.setdefault(name, {}), **kw)
+
+    def seq_cat(self, name, parts, **kw):
+        """``getattr(self, name)(torch.cat(parts, 1))`` without the cat: the first layer (a Conv2d not followed
+        by an activation in every use of the reference) runs once per part on its slice of the weights."""
+        mods = list(getattr(self, name))
+        first = mods[0]
+        cache = self._caches.setdefault(name + ":split", {})
+        key = tuple(p.c for p in parts)
+        if key not in cache:
+            if sum(key) != first.in_channels:
+                raise hip.VcError(f"{name}: concat of {key} channels does not match the layer ({first.in_channels})")
+            packs, c0 = [], 0
+            for i, c in enumerate(key):
+                packs.append(hip.PackedConv(first.weight[:, c0:c0 + c], first.bias if i == 0 else None,
+                                            stride=first.stride[0], device=first.weight.device))
+                c0 += c
+            cache[key] = packs
+        acc = None
+        for pk, part in zip(cache[key], parts):
+            acc = pk(part, res=acc)
+        return run_sequential(nn.Sequential(*mods[1:]), acc, self._caches.setdefault(name + ":tail", {}), **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers.py
+# ------------------------------------------------------------------------------------------------
+class DeformConv2d(_Prepared):
+    """Parameter holder with torchvision's names; executed by vc_offset_diversity / vc_deform_conv2d."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, groups=1):
+        super().__init__()
+        if kernel_size != 3 or padding != 1:
+            raise hip.VcError("only DeformConv2d(kernel_size=3, padding=1) is on the path")
+        self.groups = groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, 3, 3))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        nn.init.uniform_(self.bias, -0.1, 0.1)
+
+    def packed(self):
+        if self._packed is None:
+            self._packed = hip.PackedDeform(self.weight, self.bias, self.groups, self.weight.device)
+        return self._packed
+
+
+class OffsetDiversity(nn.Module):
+    def __init__(self, in_channel, magnitude):
+        super().__init__()
+        self.in_channel, self.magnitude = in_channel, magnitude
+        self.fusion = DeformConv2d(in_channel * 2, in_channel, kernel_size=3, padding=1, groups=2 * 8)
+
+    def run(self, x1, offset1, flow1, x2, offset2, flow2, out=None):
+        """helpers.py:43-58 in one launch (offset preparation fused into the gather)."""
+        return self.fusion.packed().offset_diversity(x1, offset1, flow1, x2, offset2, flow2, self.magnitude, out=out)
+
+
+class MS_Feature(_Seq):
+    def __init__(self):
+        super().__init__()
+        self.layer1 = nn.Sequential(conv(3, 64, kernel_size=3, stride=2), *_rbb(64))
+        self.layer2 = nn.Sequential(conv(64, 96, kernel_size=3, stride=2), *_rbb(96))
+        self.layer3 = nn.Sequential(conv(96, 128, kernel_size=3, stride=2), *_rbb(128))
+
+    def run(self, x, outs=(None, None, None)):
+        l1 = self.seq("layer1", x, out=outs[0])
+        l2 = self.seq("layer2", l1, out=outs[1])
+        return l1, l2, self.seq("layer3", l2, out=outs[2])
+
+
+class FlowNET(_Seq):
+    def __init__(self):
+        super().__init__()
+        self.down0 = nn.Sequential(conv(6, 32, kernel_size=3, stride=2), *_rbb(32, 2))
+        self.down1 = nn.Sequential(conv(32, 64, kernel_size=3, stride=2), *_rbb(64, 2))
+        self.down2 = nn.Sequential(conv(64, 128, kernel_size=3, stride=2), *_rbb(128, 2))
+        self.down3 = nn.Sequential(conv(128, 192, kernel_size=3, stride=2), *_rbb(192, 2))
+        self.up0 = nn.Sequential(*_rbb(192, 2), subpel_conv3x3(192, 128, 2))
+        self.up1 = nn.Sequential(conv(256, 128, 1, 1), *_rbb(128, 2), subpel_conv3x3(128, 64, 2))
+        self.up2 = nn.Sequential(conv(128, 64, 1, 1), *_rbb(64, 2), subpel_conv3x3(64, 32, 2))
+        self.up3 = nn.Sequential(conv(64, 32, 1, 1), *_rbb(32, 2), subpel_conv3x3(32, 4, 2))
+
+    def run(self, inp):
+        """helpers.py:163-172; every skip tensor is written next to the slot the up-path fills (no cat)."""
+        dev, n = inp.buf.device, inp.n
+        if inp.h % 16 or inp.w % 16:
+            raise hip.VcError("FlowNET input must be a multiple of 16 (FlowGuidedB.pad_flow)")
+        cat3 = T.empty(n, inp.h // 2, inp.w // 2, 64, dev)       # [up2 out | s0]
+        cat2 = T.empty(n, inp.h // 4, inp.w // 4, 128, dev)      # [up1 out | s1]
+        cat1 = T.empty(n, inp.h // 8, inp.w // 8, 256, dev)      # [up0 out | s2]
+        s0 = self.seq("down0", inp, out=cat3.channels(32, 64))
+        s1 = self.seq("down1", s0, out=cat2.channels(64, 128))
+        s2 = self.seq("down2", s1, out=cat1.channels(128, 256))
+        s3 = self.seq("down3", s2)
+        self.seq("up0", s3, out=cat1.channels(0, 128))
+        self.seq("up1", cat1, out=cat2.channels(0, 64))
+        self.seq("up2", cat2, out=cat3.channels(0, 32))
+        return self.seq("up3", cat3)
+
+
+class _TemporalEnc(_Seq):
+    def __init__(self, mult, N=128, M=128):
+        super().__init__()
+        self.g_a1 = nn.Sequential(conv(64 * mult, N, kernel_size=5, stride=2), *_rbb(N))
+        self.g_a2 = nn.Sequential(conv(N + 96 * mult, N, kernel_size=5, stride=2), *_rbb(N))
+        self.g_a3 = nn.Sequential(conv(N + 128 * mult, M, kernel_size=5, stride=2), *_rbb(M))
+
+    def run(self, l1, l2, l3, out=None):
+        y = self.seq("g_a1", l1)
+        y = self.seq_cat("g_a2", [y, l2])
+        return self.seq_cat("g_a3", [y, l3], out=out)
+
+
+class OffsetTemproalEnc(_TemporalEnc):
+    def __init__(self, N=128, M=128):
+        super().__init__(4, N, M)
+
+
+class ResidualTemproalEnc(_TemporalEnc):
+    def __init__(self, N=128, M=128):
+        super().__init__(1, N, M)
+
+
+class Reconstuctor(_Seq):
+    def __init__(self):
+        super().__init__()
+        self.layer3 = nn.Sequential(*_rbb(128), subpel_conv3x3(128, 128, 2))
+        self.layer2 = nn.Sequential(conv(128 + 96, 96, 1, 1), *_rbb(96), subpel_conv3x3(96, 96, 2))
+        self.layer1 = nn.Sequential(conv(96 + 64, 64, 1, 1), *_rbb(64), subpel_conv3x3(64, 3, 2))
+
+    def run(self, x_comp_l1, x_comp_l2, x_comp_l3):
+        l3 = self.seq("layer3", x_comp_l3)
+        l2 = self.seq_cat("layer2", [x_comp_l2, l3])
+        return self.seq_cat("layer1", [x_comp_l1, l2])
+
+
+# ------------------------------------------------------------------------------------------------
+# compression_bottlenecks.py
+# ------------------------------------------------------------------------------------------------
+GROUPS = (0, 6, 12, 24, 48)
+
+
+class JointAutoregressiveHierarchicalPriors(_Seq):
+    """Members (and therefore state_dict keys) of compressai.models.JointAutoregressiveHierarchicalPriors(N, M);
+    the ICIP2024 subclasses replace h_a / h_s / entropy_parameters and never run g_a / g_s / context_prediction."""
+
+    def __init__(self, N=192, M=192):
+        super().__init__()
+        self.entropy_bottleneck = EntropyBottleneck(N)
+        self.g_a = nn.Sequential(conv(3, N), GDN(N), conv(N, N), GDN(N), conv(N, N), GDN(N), conv(N, M))
+        self.g_s = nn.Sequential(deconv(M, N), GDN(N, inverse=True), deconv(N, N), GDN(N, inverse=True),
+                                 deconv(N, N), GDN(N, inverse=True), deconv(N, 3))
+        self.h_a = nn.Sequential()
+        self.h_s = nn.Sequential()
+        self.entropy_parameters = nn.Sequential()
+        self.context_prediction = MaskedConv2d(M, 2 * M, kernel_size=5, padding=2, stride=1)
+        self.gaussian_conditional = GaussianConditional(None)
+        self.N, self.M = int(N), int(M)
+
+
+class _Elic(JointAutoregressiveHierarchicalPriors):
+    """Body shared by Offset_ELIC (enc_mult 5, dec_mult 4, three 432-channel offset heads) and Res_ELIC
+    (enc_mult 2, dec_mult 1, residual heads of 64/96/128 channels)."""
+
+    def __init__(self, enc_mult, dec_mult, outs, N=128, M=128):
+        super().__init__(N, M)
+        self.g_a1 = nn.Sequential(conv(64 * enc_mult, N, kernel_size=5, stride=2), *_rbb(N))
+        self.g_a2 = nn.Sequential(conv(N + 96 * enc_mult, N, kernel_size=5, stride=2), *_rbb(N))
+        self.g_a3 = nn.Sequential(conv(N + 128 * enc_mult, M, kernel_size=5, stride=2), *_rbb(M))
+        self.g_s3 = nn.Sequential(*_rbb(M), deconv(M, N, kernel_size=5, stride=2))
+        self.g_o3 = nn.Sequential(conv(N + 128 * dec_mult, N, kernel_size=3, stride=1), *_rbb(N),
+                                  conv(N, outs[2], kernel_size=3, stride=1))
+        self.g_s2 = nn.Sequential(conv(N + 128 * dec_mult, N, kernel_size=1, stride=1), *_rbb(N),
+                                  deconv(N, N, kernel_size=5, stride=2))
+        self.g_o2 = nn.Sequential(conv(N + 96 * dec_mult, N, kernel_size=3, stride=1), *_rbb(N),
+                                  conv(N, outs[1], kernel_size=3, stride=1))
+        self.g_s1 = nn.Sequential(conv(N + 96 * dec_mult, N, kernel_size=1, stride=1), *_rbb(N),
+                                  deconv(N, N, kernel_size=5, stride=2))
+        self.g_o1 = nn.Sequential(conv(N + 64 * dec_mult, N, kernel_size=3, stride=1), *_rbb(N),
+                                  conv(N, outs[0], kernel_size=3, stride=1))
+        self.h_a = nn.Sequential(conv(M, N, stride=1, kernel_size=3), nn.ReLU(inplace=True),
+                                 conv(N, N, stride=2, kernel_size=5), nn.ReLU(inplace=True),
+                                 conv(N, N, stride=2, kernel_size=5))
+        self.h_s = nn.Sequential(deconv(N, M, stride=2, kernel_size=5), nn.ReLU(inplace=True),
+                                 deconv(M, M, stride=2, kernel_size=5), nn.ReLU(inplace=True),
+                                 conv(M, M, stride=1, kernel_size=3))
+        self.prior_fusion = nn.Sequential(conv(2 * M, 2 * M, stride=1, kernel_size=3), *_rbb(2 * M),
+                                          conv(M * 2, M * 2, stride=1, kernel_size=3))
+        self.entropy_parameters = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(cin, M * 10 // 3, 1), nn.LeakyReLU(inplace=True),
+                          nn.Conv2d(M * 10 // 3, M * 8 // 3, 1), nn.LeakyReLU(inplace=True),
+                          nn.Conv2d(M * 8 // 3, cout * 6 // 3, 1))
+            for cin, cout in [(M * 4, 6), (M * 6, 6), (M * 6, 12), (M * 6, 24), (M * 6, M - 48)])
+        self.channel_context_models = nn.ModuleList(
+            nn.Sequential(conv(cin, N, kernel_size=5, stride=1), nn.ReLU(inplace=True),
+                          conv(N, N, kernel_size=5, stride=1), nn.ReLU(inplace=True),
+                          conv(N, M * 2, kernel_size=5, stride=1)) for cin in [6, 12, 24, 48])
+        self.context_prediction_models = nn.ModuleList(
+            CheckerboardContext(in_channels=cin, out_channels=M * 2, kernel_size=5, stride=1, padding=2)
+            for cin in [6, 6, 12, 24, M - 48])
+        self.levels = 5
+        self.Gain = nn.Parameter(torch.ones(self.levels, M))
+        self.InverseGain = nn.Parameter(torch.ones(self.levels, M))
+        self.HyperGain = nn.Parameter(torch.ones(self.levels, N))
+        self.InverseHyperGain = nn.Parameter(torch.ones(self.levels, N))
+        self._gain_cache = {}
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._gain_cache = {}
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *a, **k):
+        self._gain_cache = {}
+        return super()._apply(fn, *a, **k)
+
+    def interpolate_gain(self, s):
+        """compression_bottlenecks.py:296-318, evaluated on the host once per quality level (cached), fp32 like
+        the reference; returns device vectors (gain, hypergain, invhypergain, invgain)."""
+        s = max(min(s, self.levels - 1), 0)
+        if s not in self._gain_cache:
+            upper = int(min(math.ceil(s), self.levels - 1))
+            lower = int(max(math.floor(s), 0))
+            out = []
+            with torch.no_grad():
+                for m in (self.Gain, self.HyperGain, self.InverseHyperGain, self.InverseGain):
+                    m = m.detach().to("cpu", torch.float32)
+                    if upper == lower:
+                        v = torch.abs(m[int(s)])
+                    else:
+                        l = upper - s
+                        v = torch.abs(m[upper]) ** (1 - l) * torch.abs(m[lower]) ** l
+                    out.append(v.contiguous().to(self.Gain.device))
+            self._gain_cache[s] = tuple(out)
+        return self._gain_cache[s]
+
+    def _sub(self, name, i, x, **kw):
+        seq = getattr(self, name)[i]
+        return run_sequential(seq, x, self._caches.setdefault(f"{name}.{i}", {}), **kw)
+
+    def _ctx_conv(self, i):
+        key = f"ctx.{i}"
+        if key not in self._caches:
+            self._caches[key] = pack_conv(self.context_prediction_models[i])
+        return self._caches[key]
+
+    def code(self, enc1, enc2, enc3, f1d, f2d, f3d, temporal_into, s, bits, res=(None, None, None)):
+        """Encoder, entropy model and the three decoder heads.
+
+        enc1/enc2/enc3: lists of views whose concatenation the reference feeds to g_a1 / (after y) g_a2 / g_a3;
+        f*d: decoder-side conditioning views; temporal_into(view): callback that makes the temporal conditioner
+        write its output into the given slice of the prior-fusion input; res: optional views added to the three
+        heads' outputs (Res_ELIC: x_comp + res fused into the last convolution).  Returns (head1, head2, head3).
+        Appends 6 rows to ``bits``: z, y_0 .. y_4."""
+        L = hip.lib()
+        M = self.M
+        gain, hypergain, invhypergain, invgain = self.interpolate_gain(s)
+        y = self.seq_cat("g_a1", enc1) if len(enc1) > 1 else self.seq("g_a1", enc1[0])
+        y = self.seq_cat("g_a2", [y] + enc2)
+        y = self.seq_cat("g_a3", [y] + enc3)
+        dev, n, h, w = y.buf.device, y.n, y.h, y.w
+        y = hip.channel_scale(y, gain, out=y)
+        z = self.seq("h_a", y, final_chscale=hypergain)
+        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(), None, None,
+                                  hip.NULL_VIEW, None, bits.next_row_ptr(), bits.slots), "vc_eb_forward")
+        z_hat = hip.quantize_mask(z, gain=invhypergain)
+        fusion_in = T.empty(n, h, w, 2 * M, dev)                       # [h_s(z_hat) | temporal condition]
+        self.seq("h_s", z_hat, out=fusion_in.channels(0, M))
+        temporal_into(fusion_in.channels(M, 2 * M))
+        params_in = T.empty(n, h, w, 6 * M, dev)                       # [ctx | channel ctx | hyper]
+        hyper = self.seq("prior_fusion", fusion_in, out=params_in.channels(4 * M, 6 * M))
+        params_in0 = T.empty(n, h, w, 4 * M, dev)                      # group 0 has no channel context: [ctx | hyper]
+        hip.axpby(hyper, None, out=params_in0.channels(2 * M, 4 * M))
+        y_round = hip.quantize_mask(y)                                 # ste_round(y)
+        y_half = hip.quantize_mask(y, keep_parity=1)                   # anchors only (non-anchors zeroed)
+        bounds = GROUPS + (M,)
+        for i in range(5):
+            c0, c1 = bounds[i], bounds[i + 1]
+            pin = params_in0 if i == 0 else params_in
+            ctx = self._ctx_conv(i)(y_half.channels(c0, c1), out=pin.channels(0, 2 * M))
+            hip.quantize_mask(ctx, out=ctx, keep_parity=0, do_round=False)
+            if i > 0:
+                self._sub("channel_context_models", i - 1, y_round.channels(0, c0), out=pin.channels(2 * M, 4 * M))
+            gp = self._sub("entropy_parameters", i, pin)
+            half = (c1 - c0)
+            hip.check(L.vc_gc_forward(hip.stream(), y.channels(c0, c1).view(), gp.channels(0, half).view(),
+                                      gp.channels(half, 2 * half).view(), None, None, hip.NULL_VIEW,
+                                      bits.next_row_ptr(), bits.slots, None, None, None, None, 0), "vc_gc_forward")
+        y_hat = hip.quantize_mask(y, gain=invgain)
+        xhat3 = self.seq("g_s3", y_hat)
+        head3 = self._head("g_o3", [xhat3, f3d], res[2])
+        xhat2 = self.seq_cat("g_s2", [xhat3, f3d])
+        head2 = self._head("g_o2", [xhat2, f2d], res[1])
+        xhat1 = self.seq_cat("g_s1", [xhat2, f2d])
+        head1 = self._head("g_o1", [xhat1, f1d], res[0])
+        return head1, head2, head3
+
+    def _head(self, name, parts, res):
+        t = self.seq_cat(name, parts)
+        if res is None:
+            return t
+        return hip.axpby(t, res, out=t)
+
+
+class Offset_ELIC(_Elic):
+    def __init__(self, N=128, M=128, **kwargs):
+        super().__init__(5, 4, (27 * 8 * 2,) * 3, N, M)
+
+
+class Res_ELIC(_Elic):
+    def __init__(self, N=128, M=128, **kwargs):
+        super().__init__(2, 1, (64, 96, 128), N, M)
+
+
+# ------------------------------------------------------------------------------------------------
+# m.py
+# ------------------------------------------------------------------------------------------------
+def _f32_round2(v):
+    """convert_scales (m.py:71-82): fp32 value rounded to two decimals, as a python float."""
+    t = torch.tensor([v], dtype=torch.float32) if not torch.is_tensor(v) else v.reshape(-1)[:1].to("cpu", torch.float32)
+    return float((torch.round(t * 10 ** 2) / (10 ** 2)).item())
+
+
+class FlowGuidedB(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.feature_extractor = MS_Feature()
+        self.flow_estimator = FlowNET()
+        self.offset_temporal_conditioner = OffsetTemproalEnc()
+        self.offset_compressor = Offset_ELIC()
+        self.offset_diversity_l3 = OffsetDiversity(in_channel=128, magnitude=10)
+        self.offset_diversity_l2 = OffsetDiversity(in_channel=96, magnitude=20)
+        self.offset_diversity_l1 = OffsetDiversity(in_channel=64, magnitude=40)
+        self.residue_temporal_conditioner = ResidualTemproalEnc()
+        self.residual_compressor = Res_ELIC()
+        self.reconstructor = Reconstuctor()
+
+    # -- reference helpers with tensor arguments -----------------------------------------------------------
+    def convert_scales(self, scale1, scale2, x=None):
+        return _f32_round2(scale1), _f32_round2(scale2)
+
+    def warp(self, img, flow):
+        """m.py:262-282 on NCHW CUDA tensors."""
+        _require_cuda(img)
+        _require_cuda(flow)
+        return hip.nhwc_to_nchw(hip.warp(hip.WARP_W3, hip.nchw_to_nhwc(img), hip.nchw_to_nhwc(flow)))
+
+    def estimate_flow(self, xref1, xref2, down_ratio):
+        _require_cuda(xref1)
+        _require_cuda(xref2)
+        return hip.nhwc_to_nchw(self.estimate_flow_t(hip.nchw_to_nhwc(xref1), hip.nchw_to_nhwc(xref2), down_ratio))
+
+    # -- device path -----------------------------------------------------------------------------------------
+    def estimate_flow_t(self, r1, r2, down_ratio):
+        """m.py:84-102: both references pooled by 2*down_ratio into one zero-padded (x16) 6-channel buffer,
+        FlowNET, crop, bilinear x down_ratio with the vectors scaled by down_ratio."""
+        k = 2 * int(down_ratio)
+        if r1.h % k or r1.w % k:
+            raise hip.VcError(f"frame {r1.h}x{r1.w} is not divisible by 2*down_ratio={k}")
+        h, w = r1.h // k, r1.w // k
+        hp, wp = -(-h // 16) * 16, -(-w // 16) * 16
+        buf = torch.zeros(r1.n * hp * wp * 6, dtype=torch.float32, device=r1.buf.device)
+        pair = T(buf, r1.n, hp, wp, 6, hp * wp * 6, wp * 6, 6)
+        L = hip.lib()
+        for r, c0 in ((r1, 0), (r2, 3)):
+            hip.check(L.vc_avgpool_reflectpad(hip.stream(), r.view(), pair.crop(h, w).channels(c0, c0 + 3).view(), k, 1.0),
+                      "vc_avgpool_reflectpad")
+        flow = self.flow_estimator.run(pair).crop(h, w)
+        if down_ratio == 1:
+            return flow
+        return hip.upsample_bilinear(flow, int(down_ratio), align_corners=False, scale=float(down_ratio))
+
+    def forward_device(self, xref1, xref2, scale1, scale2, xcur, s, down_ratio, bits):
+        """Synchronisation-free body of :meth:`forward` on channels-last views; returns x_hat (T) and appends
+        12 rows to ``bits`` (offset: z, y_0..y_4; residual: z, y_0..y_4)."""
+        dev, n = xcur.buf.device, xcur.n
+        if xcur.h % 64 or xcur.w % 64:
+            raise hip.VcError("frame size must be a multiple of 64 (the reference pads with utils.pad)")
+        s1, s2 = self.convert_scales(scale1, scale2)
+        flow = self.estimate_flow_t(xref1, xref2, down_ratio)
+        chans = (64, 96, 128)
+        # per level one buffer [wref1 | wref2 | fref1 | fref2 | fcur]: f_cond_inp = first four, f_inp = all five
+        F_ = [T.empty(n, xcur.h >> (l + 1), xcur.w >> (l + 1), 5 * c, dev) for l, c in enumerate(chans)]
+        sl = lambda l, j: F_[l].channels(j * chans[l], (j + 1) * chans[l])  # noqa: E731
+        fref1 = self.feature_extractor.run(xref1, outs=[sl(l, 2) for l in range(3)])
+        fref2 = self.feature_extractor.run(xref2, outs=[sl(l, 3) for l in range(3)])
+        fcur = self.feature_extractor.run(xcur, outs=[sl(l, 4) for l in range(3)])
+        flows = []
+        for l in range(3):                                   # get_warpedrefs_at_layer (m.py:104-119)
+            fc1 = hip.axpby(flow.channels(0, 2), None, alpha=s1)
+            fc2 = hip.axpby(flow.channels(2, 4), None, alpha=s2)
+            flows.append((fc1, fc2))
+            hip.warp(hip.WARP_W3, fref1[l], fc1, out=sl(l, 0))
+            hip.warp(hip.WARP_W3, fref2[l], fc2, out=sl(l, 1))
+            if l < 2:                                        # F.interpolate(scale_factor=0.5, bilinear) * 0.5
+                flow = hip.avgpool_reflectpad(flow, 2, scale=0.5)
+        cond = [F_[l].channels(0, 4 * chans[l]) for l in range(3)]
+        oc = self.offset_compressor
+        o1, o2, o3 = oc.code([F_[0]], [F_[1]], [F_[2]], cond[0], cond[1], cond[2],
+                             lambda dst: self.offset_temporal_conditioner.run(cond[0], cond[1], cond[2], out=dst), s, bits)
+        comp = []
+        for l, (off, div) in enumerate(((o1, self.offset_diversity_l1), (o2, self.offset_diversity_l2),
+                                        (o3, self.offset_diversity_l3))):
+            hc = off.c // 2
+            comp.append(div.run(fref1[l], off.channels(0, hc), flows[l][0], fref2[l], off.channels(hc, 2 * hc), flows[l][1]))
+        rc = self.residual_compressor
+        x1, x2, x3 = rc.code([fcur[0], comp[0]], [fcur[1], comp[1]], [fcur[2], comp[2]], comp[0], comp[1], comp[2],
+                             lambda dst: self.residue_temporal_conditioner.run(comp[0], comp[1], comp[2], out=dst), s, bits,
+                             res=(comp[0], comp[1], comp[2]))
+        return self.reconstructor.run(x1, x2, x3)
+
+    def forward(self, xref1, xref2, scale1, scale2, xcur, s, down_ratio):
+        """m.py:181-260: NCHW CUDA tensors in, ``{"x_hat", "size", "rate"}`` out."""
+        _require_frames(xref1, xref2, xcur)
+        b, _, h, w = xcur.shape
+        bits = BitCounter(xcur.device, max_rows=16)
+        x_hat = self.forward_device(hip.nchw_to_nhwc(xref1), hip.nchw_to_nhwc(xref2), scale1, scale2,
+                                    hip.nchw_to_nhwc(xcur), s, down_ratio, bits)
+        rows = bits.totals()
+        size_offset, size_res = rows[:6].sum(), rows[6:12].sum()
+        num_pixels = h * w * b
+        return {"x_hat": hip.nhwc_to_nchw(x_hat), "size": (size_offset + size_res).float(),
+                "rate": (size_offset / num_pixels + size_res / num_pixels).float(),
+                "size_offset": size_offset, "size_residual": size_res}
+
+    # -- motion-adaptive flow resolution (opt_helpers.py:23-51) --------------------------------------------
+    def prediction_flowonly_t(self, xcur, xref1, xref2, scale1, scale2, down_ratio):
+        s1, s2 = self.convert_scales(scale1, scale2)
+        flow = self.estimate_flow_t(xref1, xref2, down_ratio)
+        f21 = hip.upsample_bilinear(flow.channels(0, 2), 2, align_corners=False, scale=2.0)
+        f12 = hip.upsample_bilinear(flow.channels(2, 4), 2, align_corners=False, scale=2.0)
+        f21 = hip.axpby(f21, None, alpha=s1, out=f21)
+        f12 = hip.axpby(f12, None, alpha=s2, out=f12)
+        w1 = hip.warp(hip.WARP_W3, xref1, f21)
+        w2 = hip.warp(hip.WARP_W3, xref2, f12)
+        return hip.axpby(w1, w2, alpha=0.5, beta=0.5, out=w1)
+
+
+def prediction_flowonly(model, xcur, xref1, xref2, scale1, scale2, down_ratio):
+    """opt_helpers.py:23-38 on NCHW CUDA tensors."""
+    _require_frames(xref1, xref2, xcur)
+    t = model.prediction_flowonly_t(hip.nchw_to_nhwc(xcur), hip.nchw_to_nhwc(xref1), hip.nchw_to_nhwc(xref2),
+                                    scale1, scale2, down_ratio)
+    return hip.nhwc_to_nchw(t)
+
+
+def get_best_down_ratio_prediction(model, xref1, xref2, scale1, scale2, xcur, level=None, beta=None):
+    """opt_helpers.py:41-51: the flow resolution whose warped-average prediction has the best PSNR.
+    The five candidate predictions are computed on the device; the five MSE scalars are compared on the host."""
+    _require_frames(xref1, xref2, xcur)
+    c, r1, r2 = hip.nchw_to_nhwc(xcur), hip.nchw_to_nhwc(xref1), hip.nchw_to_nhwc(xref2)
+    best, best_ratio = 0.0, None
+    for down_ratio in (1, 2, 4, 8, 16):
+        pred = hip.nhwc_to_nchw(model.prediction_flowonly_t(c, r1, r2, scale1, scale2, down_ratio))
+        psnr = 10 * torch.log10(1.0 / torch.mean((torch.clamp(pred, 0, 1) - xcur) ** 2))
+        if psnr > best:
+            best, best_ratio = psnr, down_ratio
+    return best_ratio, best
+
+
+# ------------------------------------------------------------------------------------------------
+# utils.py: GOP-16 bookkeeping of the test loop (src/test.py:37-101)
+# ------------------------------------------------------------------------------------------------
+def get_scales(order, order1, order2):
+    if order2 - order1 == 0:
+        return 0, 0
+    return (order - order1) / (order2 - order1), (order - order2) / (order1 - order2)
+
+
+def select_references(xcur, order, buffer, buffer_order):
+    """utils.py:153-177: the two buffered frames closest in display order (ties broken like torch.topk on the
+    |distance| list), returned as (past-side ref, future-side ref, their orders)."""
+    d = [abs(i - order) for i in buffer_order]
+    k = 1 if len(buffer) == 1 else 2
+    ind = list(torch.topk(torch.from_numpy(np.array(d)), k, largest=False).indices.numpy())
+    if k == 1:
+        return buffer[ind[0]], buffer[ind[0]], buffer_order[ind[0]], buffer_order[ind[0]]
+    lo, hi = ind[1], ind[0]
+    if buffer_order[ind[0]] < buffer_order[ind[1]]:
+        lo, hi = ind[0], ind[1]
+    return buffer[lo], buffer[hi], buffer_order[lo], buffer_order[hi]
+
+
+def update_buffer(buffer, buffer_order, new_frame, order, l=32):
+    nb, no = buffer + [new_frame], buffer_order + [order]
+    return (nb, no) if len(buffer) < l else (nb[1:], no[1:])
+
+
+def get_order_typ_list(intra_size, frame_number):
+    """utils.py:188-221 including the hard-coded tails for 300- and 600-frame UVG sequences."""
+    order = [16, 8, 4, 12, 2, 14, 6, 10, 1, 15, 3, 13, 5, 11, 7, 9]
+    o = [0] + [order[i % 16] + (i // 16) * 16 for i in range(frame_number - 1)]
+    ff = (frame_number - 1) % intra_size
+    if ff != 0:
+        m = max(o[:-ff])
+        o[-ff:] = [m + ff - i for i in range(ff)]
+    typ = ["I" if i % intra_size == 0 else "B" for i in range(frame_number)]
+    typ[-1] = "I"
+    if frame_number == 300:
+        o[-11:] = [299, 293, 290, 296, 289, 291, 292, 294, 295, 297, 298]
+    if frame_number == 600:
+        o[-7:] = [599, 595, 593, 597, 594, 596, 598]
+    return o, typ

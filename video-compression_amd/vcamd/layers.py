@@ -64,7 +64,10 @@ def _dev(module):
 
 
 def pack_conv(conv, pixelshuffle=False):
-    return hip.PackedConv(conv.weight, conv.bias, stride=conv.stride[0], pixelshuffle=pixelshuffle,
+    weight = conv.weight
+    if getattr(conv, "mask", None) is not None:       # masked convolutions multiply their weights by the mask buffer
+        weight = weight.detach() * conv.mask
+    return hip.PackedConv(weight, conv.bias, stride=conv.stride[0], pixelshuffle=pixelshuffle,
                           device=conv.weight.device)
 
 
@@ -188,9 +191,10 @@ def deconv_as_subpel_weights(deconv):
     return w3.reshape(cout * 4, cin, 3, 3), bias
 
 
-def run_sequential(seq, x, cache, final_chscale=None, final_act=None):
-    """Execute an nn.Sequential of {Conv2d, ConvTranspose2d, subpel Sequential, GDN, LeakyReLU, Residual*}
-    on the HIP path.  A LeakyReLU following a convolution is fused into that convolution's epilogue."""
+def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
+    """Execute an nn.Sequential of {Conv2d, ConvTranspose2d, subpel Sequential, GDN, (Leaky)ReLU, Residual*}
+    on the HIP path.  A (Leaky)ReLU following a convolution is fused into that convolution's epilogue.
+    ``out`` (optional view, e.g. a channel slice of a concat buffer) receives the result of the last layer."""
     mods = list(seq)
     if cache.get("seq") is None:
         cache["seq"] = {}
@@ -199,12 +203,10 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None):
     while i < len(mods):
         m = mods[i]
         last = i == len(mods) - 1
-        if isinstance(m, (ResidualBlock, ResidualBlockWithStride, ResidualBlockUpsample)):
-            x = m.run(x)
-            i += 1
-            continue
-        if isinstance(m, GDN):
-            x = m.run(x)
+        if isinstance(m, (ResidualBlock, ResidualBlockWithStride, ResidualBlockUpsample, GDN)) or getattr(m, "vc_block", False):
+            if last and (final_chscale is not None or final_act is not None):
+                raise hip.VcError("a block cannot take the sequence's final gain/activation")
+            x = m.run(x, out=out) if (last and out is not None) else m.run(x)
             i += 1
             continue
         is_subpel = isinstance(m, nn.Sequential)
@@ -220,13 +222,15 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None):
         else:
             raise hip.VcError(f"unsupported layer in sequential: {type(m).__name__}")
         act, slope = hip.ACT_NONE, 0.0
-        if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
-            act, slope = hip.ACT_LRELU, mods[i + 1].negative_slope
+        if i + 1 < len(mods) and isinstance(mods[i + 1], (nn.LeakyReLU, nn.ReLU)):
+            nxt = mods[i + 1]
+            act, slope = (hip.ACT_LRELU, nxt.negative_slope) if isinstance(nxt, nn.LeakyReLU) else (hip.ACT_RELU, 0.0)
             i += 1
             last = i == len(mods) - 1
         if last and final_act is not None:
             act = final_act
-        x = packed[key](x, act=act, slope=slope, chscale=final_chscale if last else None)
+        x = packed[key](x, act=act, slope=slope, chscale=final_chscale if last else None,
+                        out=out if last else None)
         i += 1
     return x
 

@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 _SKIP_SUFFIXES = ("pedestal", "bound", "target", "scale_table", "scale_bound",
-                  "_offset", "_quantized_cdf", "_cdf_length")
+                  "_offset", "_quantized_cdf", "_cdf_length", "mask")
+_GAIN_LEAVES = ("gain_matrix", "Gain", "InverseGain", "HyperGain", "InverseHyperGain")
 
 
 def _rng(seed, key):
@@ -33,7 +34,7 @@ def seeded_state_dict(template, seed=1234, conv_gain=1.0):
             continue
         g = _rng(seed, key)
         shape = tuple(ref.shape)
-        if leaf == "gain_matrix":
+        if leaf in _GAIN_LEAVES:
             val = g.uniform(0.5, 2.0, size=shape)
         elif leaf == "gamma":  # re-parametrised: stored value = sqrt(gamma_eff + pedestal)
             c = shape[0]
