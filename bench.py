@@ -81,8 +81,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", choices=["lhbdc", "flex"], default="lhbdc",
-                    help="lhbdc = BASELINE.json configs[1] (headline); flex = configs[2] (Flex-Rate, 4 rate points)")
+    ap.add_argument("--model", choices=["lhbdc", "flex", "icip2024"], default="lhbdc",
+                    help="lhbdc = BASELINE.json configs[1] (headline); flex = configs[2] (Flex-Rate, 4 rate points); "
+                         "icip2024 = configs[4]'s model (FlowGuidedB, GOP-16, flow-resolution search, 5 quality levels)")
     ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32",
                     help="fp32 = exact path (headline); fp16 = half-precision MFMA conv path of BASELINE configs[4]")
     ap.add_argument("--resolution", choices=["1080p", "2160p"], default="1080p")
@@ -113,14 +114,19 @@ def main():
     hip.set_conv_precision(args.precision)
     f16 = args.precision == "fp16"
     is_flex = args.model == "flex"
-    model = flex.BidirFlowRef(n=4) if is_flex else lhbdc.Model()
+    is_icip = args.model == "icip2024"
+    if is_icip:
+        from vcamd import icip2024
+        model = icip2024.FlowGuidedB()
+    else:
+        model = flex.BidirFlowRef(n=4) if is_flex else lhbdc.Model()
     sd = seeded_state_dict(model.state_dict(), seed=1234)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
-    per_gop = 15 if is_flex else 7
+    per_gop = 15 if (is_flex or is_icip) else 7
 
     # every rank codes its own GOP (GOP index = rank): weak scaling, per-GPU work fixed
-    frames = synthetic_gop(1234, rank, dev, 17 if is_flex else 9, (H, W))
+    frames = synthetic_gop(1234, rank, dev, 17 if (is_flex or is_icip) else 9, (H, W))
     records = []
     # Flex: 4 rate points selected purely through the gain units (n = 0..3, l = 1), one per step in turn
     rate_points = [{lvl: (n, 1.0) for lvl in range(4)} for n in range(4)]
@@ -130,7 +136,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if is_flex:
+    if is_icip:                     # quality levels 0..4 in turn; the per-frame flow-resolution search runs on the device
+        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="icip2024", quality=lvl) for lvl in range(5)]
+    elif is_flex:
         runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="flex", quality=q) for q in rate_points]
     else:
         runners = [None if args.no_graph else vgop.GopGraph(model, H, W)]
@@ -142,6 +150,8 @@ def main():
         recs = records if keep else None
         if runners[i] is not None:
             runners[i].code(frames, gop_index=rank, records=recs)
+        elif is_icip:
+            vgop.code_gop_icip2024(model, frames, frames[0], frames[16], H, W, i, recs, video=0, gop_index=rank)
         elif is_flex:
             vgop.code_gop_flex(model, frames, frames[0], frames[16], H, W, rate_points[i], recs, video=0, gop_index=rank)
         else:
@@ -167,7 +177,8 @@ def main():
     result = {
         # BASELINE.json: "frames/sec + bpp/PSNR on UVG 1080p GOP-8"; value = B-frames/s of the codec hot path,
         # bpp/PSNR of the same frames in "quality" (UVG is not available offline -> synthetic video)
-        "metric": (f"frames/sec + bpp/PSNR on {args.resolution} GOP-16 (Flex-Rate B-frame path, 4 rate points)" if is_flex else
+        "metric": (f"frames/sec + bpp/PSNR on {args.resolution} GOP-16 (ICIP2024 FlowGuidedB B-frame path, 5 quality levels)" if is_icip else
+                   f"frames/sec + bpp/PSNR on {args.resolution} GOP-16 (Flex-Rate B-frame path, 4 rate points)" if is_flex else
                    f"frames/sec + bpp/PSNR on {args.resolution} GOP-8 (LHBDC B-frame codec path)"),
         "value": b_frames / elapsed,
         "unit": "frames/s",
@@ -180,10 +191,12 @@ def main():
         "vs_baseline": None,
         "dtype": "f16 operands / f32 accumulate (eligible convolutions), f32 elsewhere" if f16 else "f32",
         "data": f"synthetic (band-limited texture + global translation + 2% noise, {H}x{W} reflection-padded to x64); seeded random weights",
-        "config": {"workload": (f"Flex-Rate b_model {args.resolution} GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
+        "config": {"workload": (f"ICIP2024 FlowGuidedB {args.resolution} GOP-16: 15 B-frames per GOP via FlowGuidedB.forward with the "
+                                "per-frame flow-resolution search (5 flow+warp passes), quality level s=step%5, one GOP per GPU per step"
+                                if is_icip else f"Flex-Rate b_model {args.resolution} GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
                                 "n=step%4 through the gain units, one GOP per GPU per step" if is_flex else
                                 f"LHBDC {args.resolution} GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
-                                "one GOP per GPU per step"), "frames_per_step_per_gpu": per_gop, "gop": 16 if is_flex else 8,
+                                "one GOP per GPU per step"), "frames_per_step_per_gpu": per_gop, "gop": 16 if (is_flex or is_icip) else 8,
                    "resolution": f"{W}x{H}", "precision": args.precision, "parallelism": f"gop-shard x{world}",
                    "launch": "eager" if args.no_graph else "hip-graph per GOP"},
     }
@@ -195,7 +208,9 @@ def main():
         # ---- roofline of the dominant kernel: HIP events on the launch stream, one instrumented B-frame ----
         with torch.no_grad():
             hip.timer = hip.KernelTimer()
-            if is_flex:
+            if is_icip:
+                model(frames[0], frames[16], 0.5, 0.5, frames[8], 2, 1)
+            elif is_flex:
                 model(frames[0], frames[8], frames[16], n=[1], l=1.0)
             else:
                 model(frames[0], frames[4], frames[8], False)
@@ -237,7 +252,7 @@ def main():
             with open(args.kernel_table, "w") as f:
                 json.dump({k: v for k, v in ranked}, f, indent=1)
 
-        if not is_flex and args.resolution == "1080p":
+        if not is_flex and not is_icip and args.resolution == "1080p":
             # ---- whole GOP as testing.py codes it: 1 I-frame (mbt2018_mean q7 architecture) + 7 B-frames ----
             from vcamd import iframe
             i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
@@ -261,20 +276,30 @@ def main():
         if not args.no_cpu_baseline and args.resolution == "1080p":
             from oracle import flex as oracle_flex
             from oracle import lhbdc as oracle_lhbdc
-            ora = (oracle_flex.FlexModel(n=4) if is_flex else oracle_lhbdc.LhbdcModel()).eval()
+            if is_icip:
+                from oracle import icip2024 as oracle_icip
+                ora = oracle_icip.FlowGuidedB().eval()
+            else:
+                ora = (oracle_flex.FlexModel(n=4) if is_flex else oracle_lhbdc.LhbdcModel()).eval()
             ora.load_state_dict(sd)
             torch.set_num_threads(pick_cpu_threads())
-            mid = 8 if is_flex else 4
+            mid = 8 if (is_flex or is_icip) else 4
             xb, xc, xa = frames[0].cpu(), frames[mid].cpu(), frames[2 * mid].cpu()
             with torch.no_grad():
                 t1 = time.perf_counter()
-                if is_flex:
+                if is_icip:
+                    o = ora(xb, xa, 0.5, 0.5, xc, 2, 1)
+                    ref_hat, ref_bits = o["x_hat"], float(o["size"].item())
+                elif is_flex:
                     o = ora(xb, xc, xa, n=[1], l=1.0, train=False)
                     ref_hat, ref_bits = o["x_hat"], float(o["size"].item())
                 else:
                     ref_hat, _, ref_bits = ora(xb, xc, xa, False)
                 cpu_s = time.perf_counter() - t1
-                if is_flex:
+                if is_icip:
+                    g = model(frames[0], frames[16], 0.5, 0.5, frames[8], 2, 1)
+                    gpu_hat, gpu_bits = g["x_hat"], float(g["size"].item())
+                elif is_flex:
                     g = model(frames[0], frames[mid], frames[2 * mid], n=[1], l=1.0)
                     gpu_hat, gpu_bits = g["x_hat"], float(g["size"].item())
                 else:

@@ -177,6 +177,15 @@ int vc_deform_conv2d(vc_stream s, vc_view in, vc_view offset, vc_view mask, cons
 int vc_offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2,
                         float magnitude, const float *wpk, const float *bias, int groups, vc_view out);
 
+/* Motion-adaptive flow resolution (ICIP2024/src/opt_helpers.py:41-51) without leaving the device:
+ * vc_sse_clamp01 writes workgroup partial sums of (clamp(pred,0,1) - cur)^2 (fold them with vc_bits_reduce);
+ * vc_select_flow evaluates psnr_i = 10*log10(1/(sse[i]/n_elems)) in fp32 and copies the candidate with the
+ * first strictly greatest positive PSNR (the reference's `if psnr > best` loop) into `out`, its index into
+ * *choice (candidate 0 when no PSNR is positive).  count <= 8; all candidates have out's shape. */
+int vc_sse_clamp01(vc_stream s, vc_view pred, vc_view cur, double *sse_partial, int slots);
+int vc_select_flow(vc_stream s, const double *sse, int count, double n_elems, const vc_view *candidates, vc_view out,
+                   int32_t *choice);
+
 /* ------------------------------------------------------------------------------------------
  * Entropy models (CompressAI EntropyBottleneck / GaussianConditional)
  * ---------------------------------------------------------------------------------------- */

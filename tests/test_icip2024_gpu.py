@@ -161,3 +161,91 @@ def test_rejects_cpu_tensors_and_unpadded_frames(dev, models):
     y = torch.zeros(1, 3, 72, 64, device=dev)
     with pytest.raises(hip.VcError):
         prod(y, y, 0.5, 0.5, y, 1, 1)
+
+
+def test_device_search_matches_host_search(dev, models):
+    """search_flow_t: same choice as the reference's host loop (fixture) and the chosen flow is estimate_flow(best)."""
+    from vcamd import hip
+    _, prod = models
+    fx = load_fixture("icip2024_forward_a.npz")
+    x1, xc, x2 = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    t1, tc, t2 = (hip.nchw_to_nhwc(x) for x in (x1, xc, x2))
+    ratios = (1, 2, 4, 8, 16)
+    flow, choice, sse = prod.search_flow_t(tc, t1, t2, 0.5, 0.5, ratios)
+    best = ratios[int(choice.item())]
+    assert best == int(fx["best_down_ratio"])
+    psnr_dev = 10 * np.log10(1.0 / (sse.cpu().numpy() / xc.numel()))
+    assert abs(psnr_dev.max() - float(fx["best_pred_psnr"])) < 1e-3
+    ref = prod.estimate_flow(x1, x2, best)
+    assert torch.equal(hip.nhwc_to_nchw(flow), ref)
+    # a forward fed with the searched flow equals a forward that recomputes it
+    with torch.no_grad():
+        a = prod(x1, x2, 0.5, 0.5, xc, 1, best)
+        from vcamd.layers import BitCounter
+        bits = BitCounter(dev, max_rows=16)
+        b = hip.nhwc_to_nchw(prod.forward_device(t1, t2, 0.5, 0.5, tc, 1, None, bits, flow=flow))
+    assert torch.equal(a["x_hat"], b)
+
+
+def _synthetic_gop16(dev, h=128, w=192):
+    g = torch.Generator().manual_seed(7)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, h + 64, w + 64, generator=g), 5, 1, 2)
+    frames = []
+    for t in range(17):
+        dx, dy = int(round(1.5 * t)), int(round(0.75 * t))
+        f = base[:, :, dy:dy + h, dx:dx + w] + 0.01 * torch.randn(1, 3, h, w, generator=g)
+        frames.append(f.clamp(0, 1).contiguous())
+    return frames
+
+
+def test_gop16_coder_modes_agree_and_follow_oracle(dev, models):
+    """code_gop_icip2024: device search == host search, cached reference features == recomputed ones (bit-equal),
+    and the first hierarchy levels follow the oracle's GOP loop (src/test.py:37-101 restated with oracle calls)."""
+    from oracle import icip2024 as oi
+    from vcamd import gop as vgop
+    ora, prod = models
+    frames = _synthetic_gop16(dev)
+    dframes = [f.to(dev) for f in frames]
+    h, w = frames[0].shape[2:]
+    with torch.no_grad():
+        recs_d, recs_h, recs_n = [], [], []
+        dec_d, pick_d = vgop.code_gop_icip2024(prod, dframes, dframes[0], dframes[16], h, w, 2, recs_d, search="device")
+        dec_h, pick_h = vgop.code_gop_icip2024(prod, dframes, dframes[0], dframes[16], h, w, 2, recs_h, search="host")
+        dec_n, _ = vgop.code_gop_icip2024(prod, dframes, dframes[0], dframes[16], h, w, 2, recs_n, search="host",
+                                          cache_features=False)
+    ratios = (1, 2, 4, 8, 16)
+    for o in vgop.ICIP_ORDER_16[1:]:
+        assert ratios[int(pick_d[o].item())] == pick_h[o]
+        assert torch.equal(dec_d[o], dec_h[o]) and torch.equal(dec_h[o], dec_n[o])
+    assert [r[1] for r in recs_d] == vgop.ICIP_ORDER_16[1:] and len(recs_d) == 15
+    # oracle loop for the first three coded B-frames (8, 4, 12): errors compound down the hierarchy, so compare early
+    buf, buf_order = [frames[0], frames[16]], [0, 16]
+    with torch.no_grad():
+        for i, order in enumerate(vgop.ICIP_ORDER_16[1:4]):
+            lo, hi = oi.select_references(order, buf_order)
+            s1, s2 = oi.get_scales(order, buf_order[lo], buf_order[hi])
+            best, _ = oi.get_best_down_ratio_prediction(ora, buf[lo], buf[hi], s1, s2, frames[order])
+            out = ora(buf[lo], buf[hi], s1, s2, frames[order], 2, best)
+            assert best == pick_h[order]
+            d_psnr = abs(psnr(dec_h[order].cpu(), frames[order]) - psnr(out["x_hat"], frames[order]))
+            rel = abs(recs_h[i][4].item() - out["size"].item()) / out["size"].item()
+            print(f"gop16 frame {order}: down_ratio={best} dPSNR={d_psnr:.2e} size rel={rel:.2e}")
+            assert d_psnr < 5e-3 and rel < 5e-3
+            buf.append(torch.clamp(out["x_hat"], 0, 1))
+            buf_order.append(order)
+
+
+def test_gop16_graph_replay_equals_eager(dev, models):
+    from vcamd import gop as vgop
+    _, prod = models
+    dframes = [f.to(dev) for f in _synthetic_gop16(dev)]
+    h, w = dframes[0].shape[2:]
+    with torch.no_grad():
+        recs_e, recs_g = [], []
+        dec_e, _ = vgop.code_gop_icip2024(prod, dframes, dframes[0], dframes[16], h, w, 3, recs_e, search="device")
+        runner = vgop.GopGraph(prod, h, w, kind="icip2024", quality=3)
+        runner.code(dframes, records=None)
+        dec_g = runner.code(dframes, records=recs_g)
+    for o in vgop.ICIP_ORDER_16[1:]:
+        assert torch.equal(dec_e[o], dec_g[o])
+    assert torch.equal(torch.stack([r[4] for r in recs_e]), torch.stack([r[4] for r in recs_g]))

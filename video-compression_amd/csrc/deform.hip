@@ -1,8 +1,8 @@
 // Modulated deformable 3x3 convolution (torchvision.ops.deform_conv2d semantics) for the ICIP2024 OffsetDiversity
 // fusion (ICIP2024/src/model/helpers.py:35-58).  Gather-bound, not matrix-bound: per output pixel and group the
 // kernel samples 9 taps x 4 corners x cg channels (cg = 8..16 contiguous floats in NHWC) and contracts them with
-// 9*cg*og weights held in LDS, so one lane owns one (pixel, group) pair and the group index is uniform per
-// workgroup (broadcast LDS reads of the weights).  The offset/mask preparation of OffsetDiversity.prep (tanh *
+// 9*cg*og weights held in LDS; one lane owns one (pixel, group) pair and the group index is uniform per wave
+// (broadcast LDS reads of the weights).  The offset/mask preparation of OffsetDiversity.prep (tanh *
 // magnitude + flipped flow, sigmoid) is folded into the offset fetch in the fused entry point.
 #include "common.h"
 
@@ -19,26 +19,33 @@ struct DeformArgs {
     int groups;
 };
 
-constexpr int DEF_BLOCK = 256;
-
+// One workgroup = one 8x8 pixel tile x all G/2 groups of ONE reference (wave w <-> group w of that half): the
+// waves of a workgroup then consume every channel of the 128-byte lines they pull in (a group alone uses only
+// cg of the C channels of a pixel), and the per-pixel offset/mask record of that reference is read completely
+// by the workgroup.  Lanes of a wave are the 64 pixels of the tile, so the group (and its weights) is wave-uniform.
 template <int CG, int OG, bool FUSED, bool VEC>
-__global__ void __launch_bounds__(DEF_BLOCK) k_deform(DeformArgs a)
+__global__ void __launch_bounds__(1024) k_deform(DeformArgs a)
 {
-    __shared__ float wsm[9 * CG * OG];
-    const int g = blockIdx.y, n = blockIdx.z;
-    for (int i = threadIdx.x; i < 9 * CG * OG; i += DEF_BLOCK) wsm[i] = a.wpk[(long long)g * 9 * CG * OG + i];
-    __syncthreads();
+    extern __shared__ float wsm_all[];
     const int half = a.groups / 2;
-    const bool second = g >= half;
-    const int gl = second ? g - half : g;             // group index inside its half
+    const bool second = blockIdx.y != 0;
+    const int n = blockIdx.z;
+    const int nthreads = 64 * half;
+    const float *wsrc = a.wpk + (long long)(second ? half : 0) * 9 * CG * OG;
+    for (int i = threadIdx.x; i < half * 9 * CG * OG; i += nthreads) wsm_all[i] = wsrc[i];
+    __syncthreads();
+    const int gl = threadIdx.x >> 6;                  // group inside its half == wave index
+    const int g = second ? gl + half : gl;
+    const int lane = threadIdx.x & 63;
+    const float *wsm = wsm_all + gl * 9 * CG * OG;
     const vc_view &X = second ? a.x2 : a.x1;
     const vc_view &O = second ? a.off2 : a.off1;
     const vc_view &M = second ? a.msk2 : a.msk1;
     const vc_view &FL = second ? a.flow2 : a.flow1;
     const int H = a.out.h, W = a.out.w;
-    const long long pix = (long long)blockIdx.x * DEF_BLOCK + threadIdx.x;
-    if (pix >= (long long)H * W) return;
-    const int y = (int)(pix / W), x = (int)(pix % W);
+    const int tiles_x = (W + 7) >> 3;
+    const int y = (blockIdx.x / tiles_x) * 8 + (lane >> 3), x = (blockIdx.x % tiles_x) * 8 + (lane & 7);
+    if (y >= H || x >= W) return;
 
     float acc[OG];
 #pragma unroll
@@ -55,7 +62,7 @@ __global__ void __launch_bounds__(DEF_BLOCK) k_deform(DeformArgs a)
     }
     const float *xbase = X.p + (long long)n * X.sn + gl * CG;
 
-#pragma unroll 1
+#pragma unroll 3
     for (int k = 0; k < 9; ++k) {
         float dy = op[2 * k], dx = op[2 * k + 1];
         float m = 1.0f;
@@ -114,12 +121,15 @@ inline bool aligned16(const vc_view &v)
 
 template <int CG, int OG, bool FUSED> int launch(hipStream_t st, const DeformArgs &a, bool vec)
 {
-    const long long pixels = (long long)a.out.h * a.out.w;
-    const dim3 grid((unsigned)((pixels + DEF_BLOCK - 1) / DEF_BLOCK), (unsigned)a.groups, (unsigned)a.out.n);
+    const int half = a.groups / 2;
+    if (half > 16) return VC_EINVAL;                       // one wave per group of a half, 1024 threads at most
+    const unsigned tiles = (unsigned)(((a.out.h + 7) / 8) * ((a.out.w + 7) / 8));
+    const dim3 grid(tiles, 2u, (unsigned)a.out.n), block((unsigned)(64 * half));
+    const size_t lds = (size_t)half * 9 * CG * OG * sizeof(float);
     if (vec)
-        hipLaunchKernelGGL((k_deform<CG, OG, FUSED, true>), grid, dim3(DEF_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((k_deform<CG, OG, FUSED, true>), grid, block, lds, st, a);
     else
-        hipLaunchKernelGGL((k_deform<CG, OG, FUSED, false>), grid, dim3(DEF_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((k_deform<CG, OG, FUSED, false>), grid, block, lds, st, a);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
 }
 

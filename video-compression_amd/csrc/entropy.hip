@@ -253,3 +253,81 @@ extern "C" int vc_bits_reduce(vc_stream s, const double *partial, int slots, int
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// ICIP2024 flow-resolution search on the device (opt_helpers.py:41-51)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ENT_BLOCK) k_sse_clamp01(vc_view pred, vc_view cur, double *__restrict__ partial)
+{
+    __shared__ double sm[ENT_BLOCK / 64];
+    double acc = 0.0;
+    const long long total = (long long)pred.n * pred.h * pred.w * pred.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % pred.c);
+        long long t = i / pred.c;
+        const int x = (int)(t % pred.w); t /= pred.w;
+        const int y = (int)(t % pred.h);
+        const int n = (int)(t / pred.h);
+        const float p = fminf(fmaxf(pred.p[view_off(pred, n, y, x) + c], 0.0f), 1.0f);
+        const float d = p - cur.p[view_off(cur, n, y, x) + c];
+        acc += (double)(d * d);
+    }
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+extern "C" int vc_sse_clamp01(vc_stream s, vc_view pred, vc_view cur, double *sse_partial, int slots)
+{
+    if (!pred.p || !cur.p || !sse_partial || slots != ENT_SLOTS) return VC_EINVAL;
+    if (pred.n != cur.n || pred.h != cur.h || pred.w != cur.w || pred.c != cur.c) return VC_EINVAL;
+    hipLaunchKernelGGL(k_sse_clamp01, dim3(ENT_SLOTS), dim3(ENT_BLOCK), 0, as_stream(s), pred, cur, sse_partial);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+struct FlowCandidates {
+    vc_view v[8];
+};
+
+__global__ void k_select_flow(const double *__restrict__ sse, int count, double n_elems, FlowCandidates cands, vc_view out,
+                              int32_t *__restrict__ choice)
+{
+    int pick = 0;
+    float best = 0.0f;
+    for (int i = 0; i < count; ++i) {
+        const float mse = (float)(sse[i] / n_elems);
+        const float psnr = 10.0f * log10f(1.0f / mse);
+        if (psnr > best) {
+            best = psnr;
+            pick = i;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && choice) *choice = pick;
+    const vc_view src = cands.v[pick];
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        out.p[view_off(out, n, y, x) + c] = src.p[view_off(src, n, y, x) + c];
+    }
+}
+
+extern "C" int vc_select_flow(vc_stream s, const double *sse, int count, double n_elems, const vc_view *candidates,
+                              vc_view out, int32_t *choice)
+{
+    if (!sse || !candidates || !out.p || count < 1 || count > 8 || !(n_elems > 0.0)) return VC_EINVAL;
+    FlowCandidates c = {};
+    for (int i = 0; i < count; ++i) {
+        const vc_view &v = candidates[i];
+        if (!v.p || v.n != out.n || v.h != out.h || v.w != out.w || v.c != out.c) return VC_EINVAL;
+        c.v[i] = v;
+    }
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_select_flow, dim3(ew_grid(total, ENT_BLOCK)), dim3(ENT_BLOCK), 0, as_stream(s), sse, count, n_elems,
+                       c, out, choice);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}

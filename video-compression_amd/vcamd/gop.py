@@ -84,6 +84,75 @@ def code_gop_flex(model, gop, dec_first, dec_last, h, w, quality, records=None, 
     return decoded
 
 
+# ICIP2024 GOP-16 (ICIP2024/src/utils.py:188-221, src/test.py:37-101): frame 16 is intra-coded first, then the
+# B-frames in this order, each predicted from the two buffered frames closest in display order.
+ICIP_ORDER_16 = [16, 8, 4, 12, 2, 14, 6, 10, 1, 15, 3, 13, 5, 11, 7, 9]
+ICIP_LEVELS_16 = {8: 0, 4: 1, 12: 1, 2: 2, 6: 2, 10: 2, 14: 2, 1: 3, 3: 3, 5: 3, 7: 3, 9: 3, 11: 3, 13: 3, 15: 3}
+
+
+def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None, video=0, gop_index=0,
+                      search="device", down_ratio=1, cache_features=True):
+    """Code the 15 B-frames of one ICIP2024 GOP-16 at quality ``level`` (0..4, fractional values interpolate the
+    gain vectors), following src/test.py:37-101.
+
+    ``search``: "device" scores the five flow resolutions of get_best_down_ratio_prediction (opt_helpers.py:41-51)
+    and picks the winner without leaving the GPU (no host sync in the whole GOP: capturable as one HIP graph);
+    "host" compares the five PSNRs on the host like the reference loop (one sync per frame); None uses ``down_ratio``.
+    ``cache_features``: a decoded frame's feature pyramid is computed once and reused for every B-frame it serves
+    as reference.  Decoded frames are clamped to [0,1] before they enter the reference buffer (src/test.py:94).
+    Returns ({order: decoded}, {order: chosen down_ratio -- device int32 index into (1,2,4,8,16) for "device"})."""
+    from . import hip, icip2024
+    from .layers import BitCounter
+    ratios = (1, 2, 4, 8, 16)
+    buffer, buffer_order = [dec_first, dec_last], [0, 16]
+    decoded, picked, feats = {0: dec_first, 16: dec_last}, {}, {}
+    nhwc = {0: hip.nchw_to_nhwc(dec_first), 16: hip.nchw_to_nhwc(dec_last)}
+
+    def features(o):
+        if not cache_features:
+            return None
+        if o not in feats:
+            feats[o] = model.feature_extractor.run(nhwc[o])
+        return feats[o]
+
+    for order in ICIP_ORDER_16[1:]:
+        _, _, o1, o2 = icip2024.select_references(None, order, buffer, buffer_order)
+        s1, s2 = icip2024.get_scales(order, o1, o2)
+        cur = gop[order]
+        t1, t2, tc = nhwc[o1], nhwc[o2], hip.nchw_to_nhwc(cur)
+        flow, dr = None, down_ratio
+        if search == "device":
+            flow, choice, _ = model.search_flow_t(tc, t1, t2, s1, s2, ratios)
+            picked[order] = choice
+        elif search == "host":
+            mses = []
+            for cand in ratios:
+                pred = hip.nhwc_to_nchw(model.prediction_flowonly_t(tc, t1, t2, s1, s2, cand))
+                mses.append(torch.mean((torch.clamp(pred, 0, 1) - cur) ** 2))
+            psnrs = (10 * torch.log10(1.0 / torch.stack(mses))).cpu()
+            best, dr = 0.0, None
+            for cand, p in zip(ratios, psnrs.tolist()):     # strict '>' keeps the first maximum, like the reference
+                if p > best:
+                    best, dr = p, cand
+            if dr is None:
+                raise hip.VcError("flow-resolution search found no finite PSNR")
+            picked[order] = dr
+        else:
+            picked[order] = dr
+        bits = BitCounter(cur.device, max_rows=16)
+        x_hat = hip.nhwc_to_nchw(model.forward_device(t1, t2, s1, s2, tc, level, dr, bits, flow=flow,
+                                                      feats1=features(o1), feats2=features(o2)))
+        size = bits.totals().sum()
+        decoded[order] = x_hat
+        clamped = torch.clamp(x_hat, 0, 1)
+        nhwc[order] = hip.nchw_to_nhwc(clamped)
+        buffer, buffer_order = icip2024.update_buffer(buffer, buffer_order, clamped, order)
+        if records is not None:
+            records.append((video, gop_index * 16 + order, ICIP_LEVELS_16[order], psnr_uint8(x_hat, cur, h, w), size,
+                            float(h * w)))
+    return decoded, picked
+
+
 class GopGraph:
     """One GOP of B-frame coding captured ONCE as a HIP graph and replayed per GOP.
 
@@ -94,8 +163,8 @@ class GopGraph:
 
     def __init__(self, model, h, w, video=0, kind="lhbdc", quality=None):
         self.model, self.h, self.w, self.video, self.kind, self.quality = model, h, w, video, kind, quality
-        self.orders = CODING_ORDER[2:] if kind == "lhbdc" else CODING_ORDER_16[2:]
-        self.levels = HIER_LEVELS if kind == "lhbdc" else HIER_LEVELS_16
+        self.orders = {"lhbdc": CODING_ORDER[2:], "flex": CODING_ORDER_16[2:], "icip2024": ICIP_ORDER_16[1:]}[kind]
+        self.levels = {"lhbdc": HIER_LEVELS, "flex": HIER_LEVELS_16, "icip2024": ICIP_LEVELS_16}[kind]
         self.span = 8 if kind == "lhbdc" else 16
         self.graph = None
         self.static_in = None
@@ -106,6 +175,9 @@ class GopGraph:
         recs = []
         if self.kind == "lhbdc":
             dec = code_gop_lhbdc(self.model, frames, frames[0], frames[8], self.h, self.w, recs, self.video, 0)
+        elif self.kind == "icip2024":       # quality = level; flow-resolution search on the device
+            dec, _ = code_gop_icip2024(self.model, frames, frames[0], frames[16], self.h, self.w, self.quality, recs,
+                                       self.video, 0, search="device")
         else:
             dec = code_gop_flex(self.model, frames, frames[0], frames[16], self.h, self.w, self.quality, recs, self.video, 0)
         psnr = torch.stack([r[3] for r in recs])

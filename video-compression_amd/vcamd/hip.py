@@ -126,6 +126,8 @@ def lib():
     sig("vc_deform_pack_weights", ci, vp, ci, ci, ci, vp)
     sig("vc_deform_conv2d", ci, vp, View, View, View, vp, vp, ci, View)
     sig("vc_offset_diversity", ci, vp, View, View, View, View, View, View, cf, vp, vp, ci, View)
+    sig("vc_sse_clamp01", ci, vp, View, View, vp, ci)
+    sig("vc_select_flow", ci, vp, vp, ci, ctypes.c_double, ctypes.POINTER(View), View, vp)
     sig("vc_eb_forward", ci, vp, View, vp, vp, vp, View, vp, vp, ci)
     sig("vc_eb_dequant", ci, vp, vp, vp, vp, View)
     sig("vc_gc_forward", ci, vp, View, View, View, vp, vp, View, vp, ci, vp, vp, vp, vp, ci)
@@ -148,7 +150,7 @@ EXPORTED_SYMBOLS = [
     "vc_nhwc_to_nchw", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity",
-    "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
+    "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
     "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes",
 ]

@@ -469,20 +469,31 @@ class FlowGuidedB(nn.Module):
             return flow
         return hip.upsample_bilinear(flow, int(down_ratio), align_corners=False, scale=float(down_ratio))
 
-    def forward_device(self, xref1, xref2, scale1, scale2, xcur, s, down_ratio, bits):
+    def forward_device(self, xref1, xref2, scale1, scale2, xcur, s, down_ratio, bits, flow=None, feats1=None, feats2=None):
         """Synchronisation-free body of :meth:`forward` on channels-last views; returns x_hat (T) and appends
-        12 rows to ``bits`` (offset: z, y_0..y_4; residual: z, y_0..y_4)."""
+        12 rows to ``bits`` (offset: z, y_0..y_4; residual: z, y_0..y_4).
+
+        ``flow`` (optional): the 4-channel half-resolution flow already chosen by :meth:`search_flow_t` (the
+        reference recomputes estimate_flow(best down_ratio), the same function of the same inputs).
+        ``feats1`` / ``feats2`` (optional): ``feature_extractor`` outputs of the references computed earlier --
+        a decoded frame serves several B-frames of a GOP as reference and its features do not change."""
         dev, n = xcur.buf.device, xcur.n
         if xcur.h % 64 or xcur.w % 64:
             raise hip.VcError("frame size must be a multiple of 64 (the reference pads with utils.pad)")
         s1, s2 = self.convert_scales(scale1, scale2)
-        flow = self.estimate_flow_t(xref1, xref2, down_ratio)
+        if flow is None:
+            flow = self.estimate_flow_t(xref1, xref2, down_ratio)
         chans = (64, 96, 128)
         # per level one buffer [wref1 | wref2 | fref1 | fref2 | fcur]: f_cond_inp = first four, f_inp = all five
         F_ = [T.empty(n, xcur.h >> (l + 1), xcur.w >> (l + 1), 5 * c, dev) for l, c in enumerate(chans)]
         sl = lambda l, j: F_[l].channels(j * chans[l], (j + 1) * chans[l])  # noqa: E731
-        fref1 = self.feature_extractor.run(xref1, outs=[sl(l, 2) for l in range(3)])
-        fref2 = self.feature_extractor.run(xref2, outs=[sl(l, 3) for l in range(3)])
+        fref = []
+        for j, (x, feats) in enumerate(((xref1, feats1), (xref2, feats2))):
+            if feats is None:
+                fref.append(self.feature_extractor.run(x, outs=[sl(l, 2 + j) for l in range(3)]))
+            else:
+                fref.append([hip.axpby(feats[l], None, out=sl(l, 2 + j)) for l in range(3)])
+        fref1, fref2 = fref
         fcur = self.feature_extractor.run(xcur, outs=[sl(l, 4) for l in range(3)])
         flows = []
         for l in range(3):                                   # get_warpedrefs_at_layer (m.py:104-119)
@@ -523,9 +534,7 @@ class FlowGuidedB(nn.Module):
                 "size_offset": size_offset, "size_residual": size_res}
 
     # -- motion-adaptive flow resolution (opt_helpers.py:23-51) --------------------------------------------
-    def prediction_flowonly_t(self, xcur, xref1, xref2, scale1, scale2, down_ratio):
-        s1, s2 = self.convert_scales(scale1, scale2)
-        flow = self.estimate_flow_t(xref1, xref2, down_ratio)
+    def _predict_from_flow(self, flow, xref1, xref2, s1, s2):
         f21 = hip.upsample_bilinear(flow.channels(0, 2), 2, align_corners=False, scale=2.0)
         f12 = hip.upsample_bilinear(flow.channels(2, 4), 2, align_corners=False, scale=2.0)
         f21 = hip.axpby(f21, None, alpha=s1, out=f21)
@@ -533,6 +542,35 @@ class FlowGuidedB(nn.Module):
         w1 = hip.warp(hip.WARP_W3, xref1, f21)
         w2 = hip.warp(hip.WARP_W3, xref2, f12)
         return hip.axpby(w1, w2, alpha=0.5, beta=0.5, out=w1)
+
+    def prediction_flowonly_t(self, xcur, xref1, xref2, scale1, scale2, down_ratio):
+        s1, s2 = self.convert_scales(scale1, scale2)
+        return self._predict_from_flow(self.estimate_flow_t(xref1, xref2, down_ratio), xref1, xref2, s1, s2)
+
+    def search_flow_t(self, xcur, xref1, xref2, scale1, scale2, ratios=(1, 2, 4, 8, 16)):
+        """get_best_down_ratio_prediction (opt_helpers.py:41-51) without a host round trip: every candidate
+        flow is estimated and scored (MSE of the clamped warped-average prediction) on the device, and
+        vc_select_flow copies the winner.  Returns (flow T [n,H/2,W/2,4], choice int32[1] = index into
+        ``ratios``, sse float64[len(ratios)]); the flow feeds forward_device(flow=...)."""
+        s1, s2 = self.convert_scales(scale1, scale2)
+        L, dev = hip.lib(), xcur.buf.device
+        slots = L.vc_bits_slots()
+        partial = torch.empty(len(ratios) * slots, dtype=torch.float64, device=dev)
+        sse = torch.empty(len(ratios), dtype=torch.float64, device=dev)
+        flows = []
+        for i, dr in enumerate(ratios):
+            flow = self.estimate_flow_t(xref1, xref2, dr)
+            pred = self._predict_from_flow(flow, xref1, xref2, s1, s2)
+            hip.check(L.vc_sse_clamp01(hip.stream(), pred.view(), xcur.view(), partial.data_ptr() + 8 * i * slots, slots),
+                      "vc_sse_clamp01")
+            flows.append(flow)
+        hip.check(L.vc_bits_reduce(hip.stream(), partial.data_ptr(), slots, len(ratios), sse.data_ptr()), "vc_bits_reduce")
+        out = T.empty(flows[0].n, flows[0].h, flows[0].w, 4, dev)
+        choice = torch.empty(1, dtype=torch.int32, device=dev)
+        views = (hip.View * len(flows))(*[f.view() for f in flows])
+        hip.check(L.vc_select_flow(hip.stream(), sse.data_ptr(), len(flows), float(xcur.n * xcur.h * xcur.w * xcur.c), views,
+                                   out.view(), choice.data_ptr()), "vc_select_flow")
+        return out, choice, sse
 
 
 def prediction_flowonly(model, xcur, xref1, xref2, scale1, scale2, down_ratio):

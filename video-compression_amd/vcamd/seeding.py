@@ -11,6 +11,11 @@ import torch
 
 _SKIP_SUFFIXES = ("pedestal", "bound", "target", "scale_table", "scale_bound",
                   "_offset", "_quantized_cdf", "_cdf_length", "mask")
+# ICIP2024 offset heads (last convolution of Offset_ELIC.g_o1..3): a trained model predicts small refinements
+# around the optical flow; unit-variance outputs would saturate tanh(.)*magnitude into +-40 px of per-tap noise,
+# which no real checkpoint produces and which turns the deformable gather into a random-access benchmark.
+_SMALL_HEADS = ("offset_compressor.g_o1.4.", "offset_compressor.g_o2.4.", "offset_compressor.g_o3.4.")
+_HEAD_GAIN = 0.05
 _GAIN_LEAVES = ("gain_matrix", "Gain", "InverseGain", "HyperGain", "InverseHyperGain")
 
 
@@ -34,6 +39,7 @@ def seeded_state_dict(template, seed=1234, conv_gain=1.0):
             continue
         g = _rng(seed, key)
         shape = tuple(ref.shape)
+        gain = conv_gain * _HEAD_GAIN if any(h in key for h in _SMALL_HEADS) else conv_gain
         if leaf in _GAIN_LEAVES:
             val = g.uniform(0.5, 2.0, size=shape)
         elif leaf == "gamma":  # re-parametrised: stored value = sqrt(gamma_eff + pedestal)
@@ -55,9 +61,9 @@ def seeded_state_dict(template, seed=1234, conv_gain=1.0):
             val = np.concatenate([lo, med, hi], axis=2)
         elif ref.dim() == 4:
             fan_in = shape[1] * shape[2] * shape[3]
-            val = g.normal(0.0, conv_gain / np.sqrt(fan_in), size=shape)
+            val = g.normal(0.0, gain / np.sqrt(fan_in), size=shape)
         elif ref.dim() == 1:
-            val = g.normal(0.0, 0.05, size=shape)
+            val = g.normal(0.0, 0.05 * gain / conv_gain, size=shape)
         else:
             val = g.normal(0.0, 0.1, size=shape)
         out[key] = torch.from_numpy(np.asarray(val, dtype=np.float64)).to(ref.dtype)
