@@ -137,7 +137,9 @@ def main():
         torch.cuda.synchronize()
 
     if is_icip:                     # quality levels 0..4 in turn; the per-frame flow-resolution search runs on the device
-        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="icip2024", quality=lvl) for lvl in range(5)]
+        pool = None if args.no_graph else torch.cuda.graph_pool_handle()   # the five graphs replay in turn: one memory pool
+        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="icip2024", quality=lvl, pool=pool)
+                   for lvl in range(5)]
     elif is_flex:
         runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="flex", quality=q) for q in rate_points]
     else:

@@ -90,40 +90,68 @@ ICIP_ORDER_16 = [16, 8, 4, 12, 2, 14, 6, 10, 1, 15, 3, 13, 5, 11, 7, 9]
 ICIP_LEVELS_16 = {8: 0, 4: 1, 12: 1, 2: 2, 6: 2, 10: 2, 14: 2, 1: 3, 3: 3, 5: 3, 7: 3, 9: 3, 11: 3, 13: 3, 15: 3}
 
 
+def icip2024_gop_plan(batch_levels=True, max_batch=8):
+    """The reference loop (src/test.py:56-96) replayed on frame numbers only: for every B-frame of a GOP-16 its two
+    references and temporal scales, grouped into passes.  Frames of one hierarchy level never reference each other
+    (their bracketing references are strictly closer than any same-level frame), so a level whose frames share the
+    same scales runs as ONE batched pass ({8}, {4,12}, {2,14,6,10}, {1,15,...,9})."""
+    from . import icip2024
+    buffer_order, plan = [0, 16], []
+    for order in ICIP_ORDER_16[1:]:
+        _, _, o1, o2 = icip2024.select_references(None, order, buffer_order, buffer_order)
+        plan.append((order, o1, o2) + tuple(icip2024.get_scales(order, o1, o2)))
+        buffer_order, _ = icip2024.update_buffer(buffer_order, buffer_order, order, order)
+    groups = []
+    for item in plan:
+        key = (ICIP_LEVELS_16[item[0]], item[3], item[4])
+        if batch_levels and groups and groups[-1][0] == key and len(groups[-1][1]) < max_batch:
+            groups[-1][1].append(item)
+        else:
+            groups.append((key, [item]))
+    return [g for _, g in groups]
+
+
 def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None, video=0, gop_index=0,
-                      search="device", down_ratio=1, cache_features=True):
+                      search="device", down_ratio=1, cache_features=True, batch_levels=True, max_batch=None):
     """Code the 15 B-frames of one ICIP2024 GOP-16 at quality ``level`` (0..4, fractional values interpolate the
     gain vectors), following src/test.py:37-101.
 
     ``search``: "device" scores the five flow resolutions of get_best_down_ratio_prediction (opt_helpers.py:41-51)
     and picks the winner without leaving the GPU (no host sync in the whole GOP: capturable as one HIP graph);
-    "host" compares the five PSNRs on the host like the reference loop (one sync per frame); None uses ``down_ratio``.
-    ``cache_features``: a decoded frame's feature pyramid is computed once and reused for every B-frame it serves
-    as reference.  Decoded frames are clamped to [0,1] before they enter the reference buffer (src/test.py:94).
-    Returns ({order: decoded}, {order: chosen down_ratio -- device int32 index into (1,2,4,8,16) for "device"})."""
+    "host" compares the five PSNRs on the host like the reference loop (one sync per frame, no batching); None uses
+    ``down_ratio``.  ``cache_features``: a decoded frame's feature pyramid is computed once and reused for every
+    B-frame it serves as reference.  ``batch_levels`` / ``max_batch``: see :func:`icip2024_gop_plan` (default cap: eight 1080p frames' worth of pixels per pass).  Decoded frames are clamped to
+    [0,1] before they serve as references (src/test.py:94).  Records are appended in the reference's coding order.
+    Returns ({order: decoded}, {order: chosen down_ratio -- a device int32 index into (1,2,4,8,16) for "device"})."""
     from . import hip, icip2024
     from .layers import BitCounter
     ratios = (1, 2, 4, 8, 16)
-    buffer, buffer_order = [dec_first, dec_last], [0, 16]
-    decoded, picked, feats = {0: dec_first, 16: dec_last}, {}, {}
-    nhwc = {0: hip.nchw_to_nhwc(dec_first), 16: hip.nchw_to_nhwc(dec_last)}
+    decoded, picked, feats, stats = {0: dec_first, 16: dec_last}, {}, {}, {}
+    clamped = {0: dec_first, 16: dec_last}
+    nhwc = {}
 
     def features(o):
-        if not cache_features:
-            return None
         if o not in feats:
+            if o not in nhwc:
+                nhwc[o] = hip.nchw_to_nhwc(clamped[o])
             feats[o] = model.feature_extractor.run(nhwc[o])
         return feats[o]
 
-    for order in ICIP_ORDER_16[1:]:
-        _, _, o1, o2 = icip2024.select_references(None, order, buffer, buffer_order)
-        s1, s2 = icip2024.get_scales(order, o1, o2)
-        cur = gop[order]
-        t1, t2, tc = nhwc[o1], nhwc[o2], hip.nchw_to_nhwc(cur)
+    if max_batch is None:        # keep a batched pass at or below eight 1080p frames' worth of activations
+        max_batch = max(1, min(8, (8 * 1088 * 1920) // (gop[0].shape[2] * gop[0].shape[3])))
+    for group in icip2024_gop_plan(batch_levels and search != "host", max_batch):
+        orders = [g[0] for g in group]
+        s1, s2 = group[0][3], group[0][4]
+        n = len(group)
+        cur = gop[orders[0]] if n == 1 else torch.cat([gop[o] for o in orders], 0)
+        ref1 = clamped[group[0][1]] if n == 1 else torch.cat([clamped[g[1]] for g in group], 0)
+        ref2 = clamped[group[0][2]] if n == 1 else torch.cat([clamped[g[2]] for g in group], 0)
+        t1, t2, tc = hip.nchw_to_nhwc(ref1), hip.nchw_to_nhwc(ref2), hip.nchw_to_nhwc(cur)
         flow, dr = None, down_ratio
         if search == "device":
             flow, choice, _ = model.search_flow_t(tc, t1, t2, s1, s2, ratios)
-            picked[order] = choice
+            for i, o in enumerate(orders):
+                picked[o] = choice[i]
         elif search == "host":
             mses = []
             for cand in ratios:
@@ -136,19 +164,27 @@ def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None
                     best, dr = p, cand
             if dr is None:
                 raise hip.VcError("flow-resolution search found no finite PSNR")
-            picked[order] = dr
+            picked[orders[0]] = dr
         else:
-            picked[order] = dr
-        bits = BitCounter(cur.device, max_rows=16)
-        x_hat = hip.nhwc_to_nchw(model.forward_device(t1, t2, s1, s2, tc, level, dr, bits, flow=flow,
-                                                      feats1=features(o1), feats2=features(o2)))
-        size = bits.totals().sum()
-        decoded[order] = x_hat
-        clamped = torch.clamp(x_hat, 0, 1)
-        nhwc[order] = hip.nchw_to_nhwc(clamped)
-        buffer, buffer_order = icip2024.update_buffer(buffer, buffer_order, clamped, order)
-        if records is not None:
-            records.append((video, gop_index * 16 + order, ICIP_LEVELS_16[order], psnr_uint8(x_hat, cur, h, w), size,
+            for o in orders:
+                picked[o] = dr
+        f1 = [features(g[1]) for g in group] if cache_features else None
+        f2 = [features(g[2]) for g in group] if cache_features else None
+        bits = BitCounter(cur.device, max_rows=12 * n)
+        x_hat = hip.nhwc_to_nchw(model.forward_device(t1, t2, s1, s2, tc, level, dr, bits, flow=flow, feats1=f1, feats2=f2))
+        sizes = bits.totals().view(12, n).sum(0)
+        cl = torch.clamp(x_hat, 0, 1)
+        is_ref = cache_features and ICIP_LEVELS_16[orders[0]] < 3     # the deepest level is never referenced
+        if is_ref:
+            batch_nhwc = hip.nchw_to_nhwc(cl)
+            batch_feats = model.feature_extractor.run(batch_nhwc)
+        for i, o in enumerate(orders):
+            decoded[o], clamped[o], stats[o] = x_hat[i:i + 1], cl[i:i + 1], sizes[i]
+            if is_ref:
+                feats[o] = [f.images(i, i + 1) for f in batch_feats]
+    if records is not None:
+        for o in ICIP_ORDER_16[1:]:
+            records.append((video, gop_index * 16 + o, ICIP_LEVELS_16[o], psnr_uint8(decoded[o], gop[o], h, w), stats[o],
                             float(h * w)))
     return decoded, picked
 
@@ -161,8 +197,12 @@ class GopGraph:
     (7 B-frames for LHBDC GOP-8, 15 for Flex GOP-16) captures into one graph: static input slots for the
     frames, intermediates in the graph's private pool, per-frame PSNR/bits left in static device tensors."""
 
-    def __init__(self, model, h, w, video=0, kind="lhbdc", quality=None):
+    def __init__(self, model, h, w, video=0, kind="lhbdc", quality=None, pool=None):
+        """``pool``: a torch.cuda.graph_pool_handle() shared by several GopGraphs that are replayed one after the
+        other (e.g. one per quality level): their intermediates then reuse the same memory, and the tensors a
+        replay returns are only valid until the next replay of ANY graph of the pool."""
         self.model, self.h, self.w, self.video, self.kind, self.quality = model, h, w, video, kind, quality
+        self.pool = pool
         self.orders = {"lhbdc": CODING_ORDER[2:], "flex": CODING_ORDER_16[2:], "icip2024": ICIP_ORDER_16[1:]}[kind]
         self.levels = {"lhbdc": HIER_LEVELS, "flex": HIER_LEVELS_16, "icip2024": ICIP_LEVELS_16}[kind]
         self.span = 8 if kind == "lhbdc" else 16
@@ -191,8 +231,9 @@ class GopGraph:
             with torch.no_grad():
                 self._run(self.static_in)                      # eager warm-up: packs weights, fills caches
                 torch.cuda.synchronize()
+                torch.cuda.empty_cache()                     # hand the eager warm-up's blocks back before capturing
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, pool=self.pool):
                     self.decoded, self.out_psnr, self.out_bits = self._run(self.static_in)
             self.graph = g
         for dst, src in zip(self.static_in, frames):

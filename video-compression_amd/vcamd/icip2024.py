@@ -350,7 +350,7 @@ class _Elic(JointAutoregressiveHierarchicalPriors):
         f*d: decoder-side conditioning views; temporal_into(view): callback that makes the temporal conditioner
         write its output into the given slice of the prior-fusion input; res: optional views added to the three
         heads' outputs (Res_ELIC: x_comp + res fused into the last convolution).  Returns (head1, head2, head3).
-        Appends 6 rows to ``bits``: z, y_0 .. y_4."""
+        Appends 6 x n rows to ``bits`` (n = batch size): z of every image, then y_0 .. y_4 of every image."""
         L = hip.lib()
         M = self.M
         gain, hypergain, invhypergain, invgain = self.interpolate_gain(s)
@@ -360,8 +360,9 @@ class _Elic(JointAutoregressiveHierarchicalPriors):
         dev, n, h, w = y.buf.device, y.n, y.h, y.w
         y = hip.channel_scale(y, gain, out=y)
         z = self.seq("h_a", y, final_chscale=hypergain)
-        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(), None, None,
-                                  hip.NULL_VIEW, None, bits.next_row_ptr(), bits.slots), "vc_eb_forward")
+        for i in range(n):                                           # one counter row per image and tensor
+            hip.check(L.vc_eb_forward(hip.stream(), z.images(i, i + 1).view(), self.entropy_bottleneck.device_params().data_ptr(),
+                                      None, None, hip.NULL_VIEW, None, bits.next_row_ptr(), bits.slots), "vc_eb_forward")
         z_hat = hip.quantize_mask(z, gain=invhypergain)
         fusion_in = T.empty(n, h, w, 2 * M, dev)                       # [h_s(z_hat) | temporal condition]
         self.seq("h_s", z_hat, out=fusion_in.channels(0, M))
@@ -382,9 +383,11 @@ class _Elic(JointAutoregressiveHierarchicalPriors):
                 self._sub("channel_context_models", i - 1, y_round.channels(0, c0), out=pin.channels(2 * M, 4 * M))
             gp = self._sub("entropy_parameters", i, pin)
             half = (c1 - c0)
-            hip.check(L.vc_gc_forward(hip.stream(), y.channels(c0, c1).view(), gp.channels(0, half).view(),
-                                      gp.channels(half, 2 * half).view(), None, None, hip.NULL_VIEW,
-                                      bits.next_row_ptr(), bits.slots, None, None, None, None, 0), "vc_gc_forward")
+            for j in range(n):
+                hip.check(L.vc_gc_forward(hip.stream(), y.channels(c0, c1).images(j, j + 1).view(),
+                                          gp.channels(0, half).images(j, j + 1).view(),
+                                          gp.channels(half, 2 * half).images(j, j + 1).view(), None, None, hip.NULL_VIEW,
+                                          bits.next_row_ptr(), bits.slots, None, None, None, None, 0), "vc_gc_forward")
         y_hat = hip.quantize_mask(y, gain=invgain)
         xhat3 = self.seq("g_s3", y_hat)
         head3 = self._head("g_o3", [xhat3, f3d], res[2])
@@ -471,12 +474,14 @@ class FlowGuidedB(nn.Module):
 
     def forward_device(self, xref1, xref2, scale1, scale2, xcur, s, down_ratio, bits, flow=None, feats1=None, feats2=None):
         """Synchronisation-free body of :meth:`forward` on channels-last views; returns x_hat (T) and appends
-        12 rows to ``bits`` (offset: z, y_0..y_4; residual: z, y_0..y_4).
+        12 x n rows to ``bits`` (offset: z, y_0..y_4; residual: z, y_0..y_4; each for the n images of the batch --
+        independent frames of one hierarchy level can share a pass, see gop.code_gop_icip2024).
 
         ``flow`` (optional): the 4-channel half-resolution flow already chosen by :meth:`search_flow_t` (the
         reference recomputes estimate_flow(best down_ratio), the same function of the same inputs).
-        ``feats1`` / ``feats2`` (optional): ``feature_extractor`` outputs of the references computed earlier --
-        a decoded frame serves several B-frames of a GOP as reference and its features do not change."""
+        ``feats1`` / ``feats2`` (optional): per image of the batch the ``feature_extractor`` outputs (l1, l2, l3) of
+        its reference computed earlier -- a decoded frame serves several B-frames of a GOP as reference and its
+        features do not change."""
         dev, n = xcur.buf.device, xcur.n
         if xcur.h % 64 or xcur.w % 64:
             raise hip.VcError("frame size must be a multiple of 64 (the reference pads with utils.pad)")
@@ -491,8 +496,11 @@ class FlowGuidedB(nn.Module):
         for j, (x, feats) in enumerate(((xref1, feats1), (xref2, feats2))):
             if feats is None:
                 fref.append(self.feature_extractor.run(x, outs=[sl(l, 2 + j) for l in range(3)]))
-            else:
-                fref.append([hip.axpby(feats[l], None, out=sl(l, 2 + j)) for l in range(3)])
+            else:                                  # feats: per image a triple of single-image views
+                for i, triple in enumerate(feats):
+                    for l in range(3):
+                        hip.axpby(triple[l], None, out=sl(l, 2 + j).images(i, i + 1))
+                fref.append([sl(l, 2 + j) for l in range(3)])
         fref1, fref2 = fref
         fcur = self.feature_extractor.run(xcur, outs=[sl(l, 4) for l in range(3)])
         flows = []
@@ -523,11 +531,11 @@ class FlowGuidedB(nn.Module):
         """m.py:181-260: NCHW CUDA tensors in, ``{"x_hat", "size", "rate"}`` out."""
         _require_frames(xref1, xref2, xcur)
         b, _, h, w = xcur.shape
-        bits = BitCounter(xcur.device, max_rows=16)
+        bits = BitCounter(xcur.device, max_rows=12 * b)
         x_hat = self.forward_device(hip.nchw_to_nhwc(xref1), hip.nchw_to_nhwc(xref2), scale1, scale2,
                                     hip.nchw_to_nhwc(xcur), s, down_ratio, bits)
         rows = bits.totals()
-        size_offset, size_res = rows[:6].sum(), rows[6:12].sum()
+        size_offset, size_res = rows[:6 * b].sum(), rows[6 * b:].sum()
         num_pixels = h * w * b
         return {"x_hat": hip.nhwc_to_nchw(x_hat), "size": (size_offset + size_res).float(),
                 "rate": (size_offset / num_pixels + size_res / num_pixels).float(),
@@ -550,27 +558,32 @@ class FlowGuidedB(nn.Module):
     def search_flow_t(self, xcur, xref1, xref2, scale1, scale2, ratios=(1, 2, 4, 8, 16)):
         """get_best_down_ratio_prediction (opt_helpers.py:41-51) without a host round trip: every candidate
         flow is estimated and scored (MSE of the clamped warped-average prediction) on the device, and
-        vc_select_flow copies the winner.  Returns (flow T [n,H/2,W/2,4], choice int32[1] = index into
-        ``ratios``, sse float64[len(ratios)]); the flow feeds forward_device(flow=...)."""
+        vc_select_flow copies the winner (per image of the batch).  Returns (flow T [n,H/2,W/2,4], choice int32[n] =
+        index into ``ratios``, sse float64[n, len(ratios)]); the flow feeds forward_device(flow=...)."""
         s1, s2 = self.convert_scales(scale1, scale2)
         L, dev = hip.lib(), xcur.buf.device
         slots = L.vc_bits_slots()
         partial = torch.empty(len(ratios) * slots, dtype=torch.float64, device=dev)
         sse = torch.empty(len(ratios), dtype=torch.float64, device=dev)
+        n, nr = xcur.n, len(ratios)
+        partial = torch.empty(n * nr * slots, dtype=torch.float64, device=dev)
+        sse = torch.empty(n * nr, dtype=torch.float64, device=dev)         # [image][ratio]
         flows = []
         for i, dr in enumerate(ratios):
             flow = self.estimate_flow_t(xref1, xref2, dr)
             pred = self._predict_from_flow(flow, xref1, xref2, s1, s2)
-            hip.check(L.vc_sse_clamp01(hip.stream(), pred.view(), xcur.view(), partial.data_ptr() + 8 * i * slots, slots),
-                      "vc_sse_clamp01")
+            for j in range(n):                                                # every frame of the batch decides for itself
+                hip.check(L.vc_sse_clamp01(hip.stream(), pred.images(j, j + 1).view(), xcur.images(j, j + 1).view(),
+                                           partial.data_ptr() + 8 * (j * nr + i) * slots, slots), "vc_sse_clamp01")
             flows.append(flow)
-        hip.check(L.vc_bits_reduce(hip.stream(), partial.data_ptr(), slots, len(ratios), sse.data_ptr()), "vc_bits_reduce")
-        out = T.empty(flows[0].n, flows[0].h, flows[0].w, 4, dev)
-        choice = torch.empty(1, dtype=torch.int32, device=dev)
-        views = (hip.View * len(flows))(*[f.view() for f in flows])
-        hip.check(L.vc_select_flow(hip.stream(), sse.data_ptr(), len(flows), float(xcur.n * xcur.h * xcur.w * xcur.c), views,
-                                   out.view(), choice.data_ptr()), "vc_select_flow")
-        return out, choice, sse
+        hip.check(L.vc_bits_reduce(hip.stream(), partial.data_ptr(), slots, n * nr, sse.data_ptr()), "vc_bits_reduce")
+        out = T.empty(n, flows[0].h, flows[0].w, 4, dev)
+        choice = torch.empty(n, dtype=torch.int32, device=dev)
+        for j in range(n):
+            views = (hip.View * nr)(*[f.images(j, j + 1).view() for f in flows])
+            hip.check(L.vc_select_flow(hip.stream(), sse.data_ptr() + 8 * j * nr, nr, float(xcur.h * xcur.w * xcur.c), views,
+                                       out.images(j, j + 1).view(), choice.data_ptr() + 4 * j), "vc_select_flow")
+        return out, choice, sse.view(n, nr)
 
 
 def prediction_flowonly(model, xcur, xref1, xref2, scale1, scale2, down_ratio):
