@@ -72,6 +72,13 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
  * path" of BASELINE.json configs[4].  32-wide tile configurations with cin % 8 == 0 only; not bit-comparable with
  * the fp32 reference (judged on PSNR/bpp tolerance). */
 #define VC_CFG_F16 0x200
+/* With VC_CFG_F16 only: `in` (VC_CFG_IN_F16) / `out` (VC_CFG_OUT_F16) are HALF-precision tensors (pointer to
+ * _Float16, strides counted in elements).  An fp16-path layer rounds its input to half while staging anyway, so an
+ * activation whose only consumers are such layers can live in HBM as half without changing a single result bit:
+ * the producer's epilogue performs the identical round-to-nearest conversion.  Halves the traffic of those tensors.
+ * `res`, `mul`, `chscale` and `bias` stay fp32. */
+#define VC_CFG_IN_F16 0x400
+#define VC_CFG_OUT_F16 0x800
 
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */

@@ -65,3 +65,55 @@ def test_fp16_layers_are_actually_half(dev):
                 packs += [q for q in (v if isinstance(v, (list, tuple)) else [v]) if isinstance(q, hip.PackedConv)]
     half = [p for p in packs if p.wpk16 is not None]
     assert len(half) >= 40 and len(half) < len(packs)       # heavy layers in half, tiny-channel layers stay fp32
+
+
+def test_half_precision_activations_do_not_change_a_bit(dev):
+    """VC_CFG_IN_F16 / VC_CFG_OUT_F16: an activation consumed only by fp16-path convolutions is stored as half;
+    the consumer rounds to half while staging anyway, so the result must equal the fp32-storage run exactly --
+    LHBDC (SPyNet chains, residual blocks), Flex-Rate (U-Nets) and ICIP2024 (bottleneck blocks, conv chains)."""
+    from vcamd import flex, hip, icip2024, lhbdc
+    from vcamd.seeding import seeded_state_dict
+    fx = load_fixture("lhbdc_forward_a.npz")
+    xb, xc, xa = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    builders = {
+        "lhbdc": (lhbdc.Model, lambda m: m(xb, xc, xa, False)[0]),
+        "flex": (lambda: flex.BidirFlowRef(n=4), lambda m: m(xb, xc, xa, n=[1], l=1.0)["x_hat"]),
+        "icip2024": (icip2024.FlowGuidedB, lambda m: m(xb, xa, 0.5, 0.5, xc, 2, 1)["x_hat"]),
+    }
+    hip.set_conv_precision("fp16")
+    try:
+        for name, (build, run) in builders.items():
+            m = build()
+            m.load_state_dict(seeded_state_dict(m.state_dict(), seed=1234))
+            m = m.to(dev).eval()
+            outs, halves = [], []
+            for flag in (True, False):
+                hip.HALF_ACTIVATIONS = flag
+                made = []
+                orig = hip.T.empty
+
+                def counting(n, h, w, c, device, dtype="f32", _made=made, _orig=orig):
+                    _made.append(dtype)
+                    return _orig(n, h, w, c, device, dtype)
+                hip.T.empty = staticmethod(counting)
+                try:
+                    with torch.no_grad():
+                        outs.append(run(m))
+                finally:
+                    hip.T.empty = staticmethod(orig)
+                halves.append(made.count("f16"))
+            print(f"{name}: {halves[0]} half-precision activations per frame, max|d| = {(outs[0] - outs[1]).abs().max().item():.1e}")
+            assert halves[0] > 0 and halves[1] == 0
+            assert torch.equal(outs[0], outs[1])
+    finally:
+        hip.HALF_ACTIVATIONS = True
+        hip.set_conv_precision("fp32")
+
+
+def test_half_activation_never_reaches_other_kernels(dev):
+    from vcamd import hip
+    t = hip.T.empty(1, 8, 8, 16, dev, "f16")
+    with pytest.raises(hip.VcError):
+        hip.axpby(t, None)
+    with pytest.raises(hip.VcError):
+        hip.nhwc_to_nchw(t)

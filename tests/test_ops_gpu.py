@@ -92,7 +92,7 @@ def test_tile_configs_are_bit_identical(dev):
     pc = hip.PackedConv(_rand((128, 128, 3, 3), 32, 0.03), _rand((128,), 33, 0.1), device=dev)
     outs = []
     for cfg in (0, 1, 2, 5):
-        pc.tuned = {(x.n, x.h, x.w, False): cfg | hip.CFG_EXACT}
+        pc.tuned = {(x.n, x.h, x.w, 0): cfg | hip.CFG_EXACT}
         outs.append(hip.nhwc_to_nchw(pc(x, act=hip.ACT_LRELU)))
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 

@@ -36,7 +36,8 @@ def main():
         pc = hip.PackedConv(wt, b, stride=s, device=dev)
         if len(fields) > 7:            # optional 8th field: force a (layout-compatible) narrower tile config
             f16 = pc.wpk16 is not None
-            pc.tuned = {(n, h, w, f16): fields[7] | hip.CFG_EXACT | (hip.CFG_F16 if f16 else 0)}
+            fl = hip.CFG_F16 if f16 else 0
+            pc.tuned = {(n, h, w, fl): fields[7] | hip.CFG_EXACT | fl}
         x = hip.T.empty(n, h, w, cin, dev)
         x.buf.normal_()
         ho, wo, co = pc.out_shape(h, w)

@@ -186,6 +186,9 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.chscale = d->chscale;
     const bool f16 = (d->cfg & VC_CFG_F16) != 0;
     if (f16 && (!cfg_f16_ok(d->cfg & 0xff, a.Cin) || d->in_xform != VC_IN_NONE)) return VC_EINVAL;
+    a.in_f16 = (d->cfg & VC_CFG_IN_F16) ? 1 : 0;
+    a.out_f16 = (d->cfg & VC_CFG_OUT_F16) ? 1 : 0;
+    if ((a.in_f16 || a.out_f16) && !f16) return VC_EINVAL;   // half-precision tensors exist on the fp16 path only
     a.cin_pad = round_up(a.Cin, f16 ? 2 * ck : ck);
     const int th = 8, tw = ((d->cfg & 0xff) == VC_CFG_N4) ? 64 : 32;
     a.tiles_x = (a.Wo + tw - 1) / tw;
@@ -207,6 +210,9 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.epi = d->epi; a.in_xform = d->in_xform; a.out_mode = d->out_mode;
     a.vec4 = ((a.Cin % 4) == 0 && (a.in_sw % 4) == 0 && (a.in_sh % 4) == 0 && (a.in_sn % 4) == 0 &&
               ((uintptr_t)a.in % 16) == 0) ? 1 : 0;
+    if (a.in_f16)   // one 16-byte load = 8 halves
+        a.vec4 = ((a.Cin % 8) == 0 && (a.in_sw % 8) == 0 && (a.in_sh % 8) == 0 && (a.in_sn % 8) == 0 &&
+                  ((uintptr_t)a.in % 16) == 0) ? 1 : 0;
     {   // 16-byte epilogue accesses: every view that is touched must keep groups of 4 channels aligned
         auto ok = [](const void *ptr, long long sn, long long sh, long long sw) {
             return !ptr || (((uintptr_t)ptr % 16) == 0 && (sn % 4) == 0 && (sh % 4) == 0 && (sw % 4) == 0);

@@ -62,6 +62,7 @@ struct ConvArgs {
     float slope;
     int epi, in_xform, out_mode, vec4;
     int vec_out;   // out / res / mul / chscale allow 16-byte accesses on groups of 4 consecutive output channels
+    int in_f16, out_f16;   // fp16 path only: `in` / `out` point at half-precision tensors (strides in elements)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -165,7 +166,9 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
     return v;
 }
 
-template <int KH, int KW, int S, int CK, class C, bool VEC, bool F16>
+// INH: the input tensor itself is stored in half precision (VC_CFG_IN_F16): an item is ONE 16-byte load of 8
+// channels and needs no conversion -- the producer's epilogue already rounded exactly as this stage would have.
+template <int KH, int KW, int S, int CK, class C, bool VEC, bool F16, bool INH = false>
 __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const float *in_img, int c0, int oy0, int ox0,
                                             int iy0, int ix0)
 {
@@ -175,10 +178,10 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
     constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
     constexpr int IPT = (ITEMS + 255) / 256;                    // items per thread
     constexpr int BATCH0 = (IPT + 1) / 2 > 8 ? 8 : (IPT + 1) / 2;   // two rounds per chunk when registers allow
-    constexpr int BATCH = F16 ? (BATCH0 > 4 ? 4 : BATCH0) : BATCH0; // (an fp16 item is two 16-byte loads)
+    constexpr int BATCH = (F16 && !INH) ? (BATCH0 > 4 ? 4 : BATCH0) : BATCH0; // (an fp16 item from fp32 data is two 16-byte loads)
 #pragma unroll
     for (int b0 = 0; b0 < IPT; b0 += BATCH) {
-        f32x4 v[BATCH], v2[F16 ? BATCH : 1];
+        f32x4 v[BATCH], v2[(F16 && !INH) ? BATCH : 1];
         int dst[BATCH];
         bool ok[BATCH];
 #pragma unroll
@@ -198,7 +201,11 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
             // no branch anywhere in the staging code, so every round's loads issue back to back
             dst[j] = (idx < ITEMS) ? (row * G::COLS_L + pos) * G::CKP + c4 * 4 : G::LDS_FLOATS;
             const float *src = in_img + (long long)iyc * p.in_sh + (long long)ixc * p.in_sw;
-            if (F16) {   // Cin % 8 == 0 guaranteed by the host
+            if (INH) {   // in_img counts halves here (see the caller)
+                const _Float16 *q = reinterpret_cast<const _Float16 *>(in_img) + (long long)iyc * p.in_sh +
+                                    (long long)ixc * p.in_sw + min(ch, p.Cin - 8);
+                v[j] = *reinterpret_cast<const f32x4 *>(q);
+            } else if (F16) {   // Cin % 8 == 0 guaranteed by the host
                 const float *q = src + min(ch, p.Cin - 8);
                 v[j] = *reinterpret_cast<const f32x4 *>(q);
                 v2[j] = *reinterpret_cast<const f32x4 *>(q + 4);
@@ -219,7 +226,8 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
         for (int j = 0; j < BATCH; ++j) {
             if (b0 + j >= IPT) continue;
             f32x4 w = v[j];
-            if (F16) {   // 8 channels -> 8 halves = one 16-byte item
+            if (INH) {
+            } else if (F16) {   // 8 channels -> 8 halves = one 16-byte item
                 f16x8 h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -302,7 +310,10 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 
     const int pad_y = KH / 2, pad_x = KW / 2;
     const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
-    const float *in_img = p.in + (long long)img * p.in_sn;
+    // (a half-precision input is addressed in halves: the byte offset of image `img` is 2*img*in_sn)
+    const float *in_img = (F16 && p.in_f16)
+        ? reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(p.in) + (long long)img * p.in_sn)
+        : p.in + (long long)img * p.in_sn;
 
     VC_T(t_start);
     for (int c0 = 0; c0 < p.cin_pad; c0 += CKC) {
@@ -313,7 +324,9 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         // Two phases per batch: issue all global loads of the batch (addresses clamped into the image so
         // no load sits under a branch), then select-zero / transform and write LDS.  This keeps BATCH
         // independent 16-byte loads in flight per lane instead of one load -> wait -> ds_write at a time.
-        if (F16)
+        if (F16 && p.in_f16)
+            stage_chunk<KH, KW, S, CK, C, true, F16, F16>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+        else if (F16)
             stage_chunk<KH, KW, S, CK, C, true, true>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
         else if (p.vec4)
             stage_chunk<KH, KW, S, CK, C, true, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
@@ -444,7 +457,12 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                             }
                             if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
                             if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
-                            *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
+                            if (F16 && p.out_f16) {
+                                const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                                *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + o_off) = hv;
+                            } else {
+                                *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
+                            }
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -463,7 +481,9 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                                     const int ce = ps ? co + e - pe * cps : co + e;
                                     const int ye = sc * oy + (pe >> 1), xe = sc * ox + (pe & 1);
                                     if (p.res) w += p.res[(long long)img * p.res_sn + (long long)ye * p.res_sh + (long long)xe * p.res_sw + ce];
-                                    p.out[(long long)img * p.out_sn + (long long)ye * p.out_sh + (long long)xe * p.out_sw + ce] = w;
+                                    const long long oe = (long long)img * p.out_sn + (long long)ye * p.out_sh + (long long)xe * p.out_sw + ce;
+                                    if (F16 && p.out_f16) reinterpret_cast<_Float16 *>(p.out)[oe] = (_Float16)w;
+                                    else p.out[oe] = w;
                                 }
                             }
                         }

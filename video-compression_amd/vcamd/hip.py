@@ -178,39 +178,42 @@ def stream():
 # device tensors: channels-last fp32 buffers addressed through views
 # ------------------------------------------------------------------------------------------------
 class T:
-    """A [n,h,w,c] fp32 channels-last window into a torch buffer (channel slice / crop = new T)."""
+    """A channels-last window into a flat device buffer: shape (n,h,w,c), strides in ELEMENTS, element offset.
+    ``dtype`` is "f32" everywhere except for activations that only feed fp16-path convolutions ("f16", see
+    VC_CFG_IN_F16 / VC_CFG_OUT_F16): those are produced and consumed by vc_conv2d_nhwc alone."""
+    __slots__ = ("buf", "n", "h", "w", "c", "sn", "sh", "sw", "off", "dtype")
 
-    __slots__ = ("buf", "n", "h", "w", "c", "sn", "sh", "sw", "off")
-
-    def __init__(self, buf, n, h, w, c, sn, sh, sw, off=0):
+    def __init__(self, buf, n, h, w, c, sn, sh, sw, off=0, dtype="f32"):
         self.buf, self.n, self.h, self.w, self.c = buf, n, h, w, c
-        self.sn, self.sh, self.sw, self.off = sn, sh, sw, off
+        self.sn, self.sh, self.sw, self.off, self.dtype = sn, sh, sw, off, dtype
 
     @staticmethod
-    def empty(n, h, w, c, device):
-        buf = torch.empty(n * h * w * c, dtype=torch.float32, device=device)
-        return T(buf, n, h, w, c, h * w * c, w * c, c)
+    def empty(n, h, w, c, device, dtype="f32"):
+        buf = torch.empty(n * h * w * c, dtype=torch.float16 if dtype == "f16" else torch.float32, device=device)
+        return T(buf, n, h, w, c, h * w * c, w * c, c, 0, dtype)
 
     def channels(self, c0, c1):
-        return T(self.buf, self.n, self.h, self.w, c1 - c0, self.sn, self.sh, self.sw, self.off + c0)
+        return T(self.buf, self.n, self.h, self.w, c1 - c0, self.sn, self.sh, self.sw, self.off + c0, self.dtype)
 
     def crop(self, h, w):
-        return T(self.buf, self.n, h, w, self.c, self.sn, self.sh, self.sw, self.off)
+        return T(self.buf, self.n, h, w, self.c, self.sn, self.sh, self.sw, self.off, self.dtype)
 
     def images(self, n0, n1):
-        return T(self.buf, n1 - n0, self.h, self.w, self.c, self.sn, self.sh, self.sw, self.off + n0 * self.sn)
+        return T(self.buf, n1 - n0, self.h, self.w, self.c, self.sn, self.sh, self.sw, self.off + n0 * self.sn, self.dtype)
 
     @property
     def ptr(self):
-        return self.buf.data_ptr() + 4 * self.off
+        return self.buf.data_ptr() + (2 if self.dtype == "f16" else 4) * self.off
 
-    def view(self):
+    def view(self, allow_half=False):
+        if self.dtype != "f32" and not allow_half:
+            raise VcError("half-precision activations are private to the fp16 convolution path")
         return View(self.ptr, self.n, self.h, self.w, self.c, self.sn, self.sh, self.sw)
 
     def to_nchw(self):
         """Debug/inspection helper (torch indexing, not on the hot path)."""
         full = self.buf[self.off:]
-        return torch.as_strided(full, (self.n, self.c, self.h, self.w), (self.sn, 1, self.sh, self.sw)).contiguous()
+        return torch.as_strided(full, (self.n, self.c, self.h, self.w), (self.sn, 1, self.sh, self.sw)).contiguous().float()
 
 
 NULL_VIEW = View(None, 0, 0, 0, 0, 0, 0, 0)
@@ -235,10 +238,17 @@ def nhwc_to_nchw(t):
 # ------------------------------------------------------------------------------------------------
 CFG_EXACT = 0x100
 CFG_F16 = 0x200
+CFG_IN_F16 = 0x400
+CFG_OUT_F16 = 0x800
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
 # "fp32" (default, exact fp32 FMA chains like the reference) or "fp16" (BASELINE.json configs[4]: half-precision MFMA
 # with fp32 accumulate for every eligible layer; judged on PSNR/bpp tolerance, never the headline number).
 _PRECISION = os.environ.get("VC_CONV_PRECISION", "fp32")
+
+
+# fp16 path only: keep activations whose sole consumers are fp16-path convolutions as half in HBM (bit-identical
+# results, see VC_CFG_OUT_F16); VC_HALF_ACTIVATIONS=0 stores them as fp32 like every other tensor (A/B, tests).
+HALF_ACTIVATIONS = bool(int(os.environ.get("VC_HALF_ACTIVATIONS", "1")))
 
 
 def set_conv_precision(mode):
@@ -326,13 +336,30 @@ class PackedConv:
         ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
         return (2 * ho, 2 * wo, self.cout // 4) if self.ps else (ho, wo, self.cout)
 
+    @property
+    def half_ok(self):
+        """True when this layer runs on the fp16 path and can therefore read a half-precision activation."""
+        return self.wpk16 is not None
+
     def __call__(self, x, out=None, act=ACT_NONE, slope=0.01, res=None, epi=EPI_NONE, mul=None,
-                 in_xform=IN_NONE, chscale=None):
+                 in_xform=IN_NONE, chscale=None, out_f16=False):
+        """``out_f16``: a hint that every consumer of the result is an fp16-path convolution (``half_ok``), so the
+        result may be stored as half (bit-identical downstream, half the traffic).  Honoured only when this layer
+        itself runs on the fp16 path and allocates its own output; otherwise the result stays fp32."""
         ho, wo, co = self.out_shape(x.h, x.w)
+        half_in = x.dtype == "f16"
+        esz = 8 if half_in else 4
+        use16 = (self.wpk16 is not None and in_xform == IN_NONE and x.sw % esz == 0 and x.sh % esz == 0 and x.sn % esz == 0
+                 and x.ptr % 16 == 0)
+        if half_in and not use16:
+            raise VcError("a half-precision activation reached a layer that is not on the fp16 path")
         if out is None:
-            out = T.empty(x.n, ho, wo, co, x.buf.device)
+            out = T.empty(x.n, ho, wo, co, x.buf.device, "f16" if (out_f16 and HALF_ACTIVATIONS and use16 and co % 4 == 0) else "f32")
+        half_out = out.dtype == "f16"
+        if half_out and not use16:
+            raise VcError("a half-precision output needs the fp16 path")
         d = ConvDesc()
-        d.inp, d.out = x.view(), out.view()
+        d.inp, d.out = x.view(True), out.view(True)
         d.wpk, d.bias = self.wpk.data_ptr(), self.bias.data_ptr()
         if res is not None:
             d.res, d.res_sn, d.res_sh, d.res_sw = res.ptr, res.sn, res.sh, res.sw
@@ -346,11 +373,11 @@ class PackedConv:
         d.epi, d.in_xform = epi, in_xform
         d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
         d.cfg = self.cfg
-        use16 = (self.wpk16 is not None and in_xform == IN_NONE and x.sw % 4 == 0 and x.sh % 4 == 0 and x.sn % 4 == 0
-                 and x.ptr % 16 == 0)
+        flags = 0
         if use16:
             d.wpk = self.wpk16.data_ptr()
-        d.cfg = self._pick_cfg(d, (x.n, x.h, x.w, use16), CFG_F16 if use16 else 0)
+            flags = CFG_F16 | (CFG_IN_F16 if half_in else 0) | (CFG_OUT_F16 if half_out else 0)
+        d.cfg = self._pick_cfg(d, (x.n, x.h, x.w, flags), flags)
         what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})"
         if timer is None:
             check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)

@@ -54,7 +54,9 @@ class ResidualBottleneckBlock(_Prepared):
             b = self.BottleneckBlock
             self._packed = (pack_conv(b[0]), pack_conv(b[2]), pack_conv(b[4]))
         c1, c2, c3 = self._packed
-        return c3(c2(c1(x, act=hip.ACT_RELU), act=hip.ACT_RELU), res=x, out=out)
+        t = c1(x, act=hip.ACT_RELU, out_f16=c2.half_ok)        # both intermediates feed one convolution each:
+        t = c2(t, act=hip.ACT_RELU, out_f16=c3.half_ok)        # half-precision storage on the fp16 path
+        return c3(t, res=x, out=out)
 
 
 def _rbb(c, n=3):

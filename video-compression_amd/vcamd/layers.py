@@ -120,7 +120,7 @@ class ResidualBlockWithStride(_Prepared):
             self._packed = (pack_conv(self.conv1), pack_conv(self.conv2),
                             pack_conv(self.skip) if self.skip is not None else None)
         c1, c2, sk = self._packed
-        t = c1(x, act=hip.ACT_LRELU, slope=0.01)
+        t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok)
         u = c2(t)
         identity = x if sk is None else sk(x)
         return self.gdn.run(u, res=identity)
@@ -140,7 +140,7 @@ class ResidualBlockUpsample(_Prepared):
             self._packed = (pack_conv(self.subpel_conv[0], pixelshuffle=True), pack_conv(self.conv),
                             pack_conv(self.upsample[0], pixelshuffle=True))
         sp, cv, up = self._packed
-        t = sp(x, act=hip.ACT_LRELU, slope=0.01)   # LeakyReLU commutes with the pixel shuffle
+        t = sp(x, act=hip.ACT_LRELU, slope=0.01, out_f16=cv.half_ok)   # LeakyReLU commutes with the pixel shuffle
         u = cv(t)
         identity = up(x)
         return self.igdn.run(u, res=identity)
@@ -159,7 +159,7 @@ class ResidualBlock(_Prepared):
             self._packed = (pack_conv(self.conv1), pack_conv(self.conv2),
                             pack_conv(self.skip) if self.skip is not None else None)
         c1, c2, sk = self._packed
-        t = c1(x, act=hip.ACT_LRELU, slope=0.01)
+        t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok)
         identity = x if sk is None else sk(x)
         return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity)
 
@@ -199,6 +199,22 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
     if cache.get("seq") is None:
         cache["seq"] = {}
     packed = cache["seq"]
+
+    def pack_of(m):
+        """PackedConv of a Conv2d / ConvTranspose2d / subpel Sequential member (None for anything else)."""
+        is_subpel = isinstance(m, nn.Sequential)
+        conv = m[0] if is_subpel else m
+        key = id(conv)
+        if key not in packed:
+            if isinstance(conv, nn.ConvTranspose2d):
+                w3, b3 = deconv_as_subpel_weights(conv)
+                packed[key] = hip.PackedConv(w3, b3, stride=1, pixelshuffle=True, device=conv.weight.device)
+            elif isinstance(conv, nn.Conv2d):
+                packed[key] = pack_conv(conv, pixelshuffle=is_subpel)
+            else:
+                return None
+        return packed[key]
+
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -209,17 +225,8 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
             x = m.run(x, out=out) if (last and out is not None) else m.run(x)
             i += 1
             continue
-        is_subpel = isinstance(m, nn.Sequential)
-        conv = m[0] if is_subpel else m
-        key = id(conv)
-        if isinstance(conv, nn.ConvTranspose2d):
-            if key not in packed:
-                w3, b3 = deconv_as_subpel_weights(conv)
-                packed[key] = hip.PackedConv(w3, b3, stride=1, pixelshuffle=True, device=conv.weight.device)
-        elif isinstance(conv, nn.Conv2d):
-            if key not in packed:
-                packed[key] = pack_conv(conv, pixelshuffle=is_subpel)
-        else:
+        pk = pack_of(m)
+        if pk is None:
             raise hip.VcError(f"unsupported layer in sequential: {type(m).__name__}")
         act, slope = hip.ACT_NONE, 0.0
         if i + 1 < len(mods) and isinstance(mods[i + 1], (nn.LeakyReLU, nn.ReLU)):
@@ -229,8 +236,13 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
             last = i == len(mods) - 1
         if last and final_act is not None:
             act = final_act
-        x = packed[key](x, act=act, slope=slope, chscale=final_chscale if last else None,
-                        out=out if last else None)
+        # a result consumed by the next convolution alone may be kept as half on the fp16 path
+        nxt_pk = None
+        if not last and not isinstance(mods[i + 1], (ResidualBlock, ResidualBlockWithStride, ResidualBlockUpsample, GDN)) \
+                and not getattr(mods[i + 1], "vc_block", False):
+            nxt_pk = pack_of(mods[i + 1])
+        x = pk(x, act=act, slope=slope, chscale=final_chscale if last else None, out=out if last else None,
+               out_f16=bool(nxt_pk is not None and nxt_pk.half_ok))
         i += 1
     return x
 

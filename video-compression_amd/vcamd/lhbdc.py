@@ -92,10 +92,11 @@ class Network(_Prepared):
                                               flow.view() if flow is not None else _zero_flow_view(f1),
                                               feat.view(), up.view()), "vc_spynet_level_input")
             c = self._convs(lvl)
-            x = c[0](feat, act=hip.ACT_RELU)
-            x = c[1](x, act=hip.ACT_RELU)
-            x = c[2](x, act=hip.ACT_RELU)
-            x = c[3](x, act=hip.ACT_RELU)
+            # (each intermediate feeds exactly one convolution: on the fp16 path it is kept as half in HBM)
+            x = c[0](feat, act=hip.ACT_RELU, out_f16=c[1].half_ok)
+            x = c[1](x, act=hip.ACT_RELU, out_f16=c[2].half_ok)
+            x = c[2](x, act=hip.ACT_RELU, out_f16=c[3].half_ok)
+            x = c[3](x, act=hip.ACT_RELU, out_f16=c[4].half_ok)
             flow = c[4](x, res=up)
         return flow
 
