@@ -115,3 +115,13 @@ def test_no_cpu_path():
     x = torch.zeros(1, 3, 64, 64)
     with pytest.raises(Exception):
         m(x, x, 0.5, 0.5, x, 1, 1)
+
+
+def test_reference_import_paths_resolve():
+    """`from src.model import m` (ICIP2024/main.py -> src/test.py:31-32) resolves to the HIP-backed classes."""
+    from src.model import compression_bottlenecks, helpers, m
+    from src import opt_helpers, utils
+    assert m.FlowGuidedB is icip2024.FlowGuidedB and helpers.OffsetDiversity is icip2024.OffsetDiversity
+    assert compression_bottlenecks.Offset_ELIC is icip2024.Offset_ELIC
+    assert opt_helpers.get_best_down_ratio_prediction is icip2024.get_best_down_ratio_prediction
+    assert utils.get_order_typ_list(16, 17)[0][:3] == [0, 16, 8]
