@@ -62,7 +62,10 @@ enum { VC_OUT_PLAIN = 0, VC_OUT_PIXELSHUFFLE2 = 1 };         /* nn.PixelShuffle(
 
 /* Tile configurations (output-channel block / MFMA shape).  Chosen by vc_conv_select_cfg. */
 enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N4 = 4 /* 64 px x 4 ch, 4x4x1 MFMA */,
-       VC_CFG_N128B = 5 /* 128 channels, waves 2x2 (3x3 stride-1 only; same packed weights as N128) */ };
+       VC_CFG_N128B = 5 /* 128 channels, waves 2x2 (3x3 stride-1 only; same packed weights as N128) */,
+       VC_CFG_PW = 6 /* streaming 1x1 stride-1 kernel: weights resident in LDS, activations global -> registers with
+                        next-tile prefetch; 32 <= cin <= 128, cout <= 128, plain/ReLU/LeakyReLU epilogue (+ gain,
+                        residual); reads the packed weights of N128/N64/N32 and gives bit-identical results */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
  * same packed weights and produces bit-identical results); without it the library narrows the block for
  * small feature maps by itself. */

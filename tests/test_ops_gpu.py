@@ -377,3 +377,53 @@ def test_entropy_kernels_exact_inputs(dev):
     assert torch.equal(idx.cpu().view(y.shape), idx_ref)
     rb = (-torch.log2(lik)).sum().item()
     assert abs(bits.totals()[0].item() - rb) / rb < 1e-5
+
+
+PW_CASES = [(128, 128, 37, 75, 2), (64, 64, 33, 64, 1), (96, 96, 20, 50, 1), (32, 32, 16, 96, 3), (128, 64, 18, 40, 1),
+            (96, 64, 9, 31, 1), (128, 96, 12, 33, 1), (64, 32, 8, 129, 1)]
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", PW_CASES)
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_pointwise_streaming_kernel_is_bit_identical(dev, cin, cout, h, w, n, precision):
+    """VC_CFG_PW (streaming 1x1 kernel, csrc/conv_pw.hip) against the general kernel on the same packed weights:
+    plain and ReLU epilogues, channel gain + residual, inputs/outputs that are channel slices of wider buffers,
+    widths that are not a multiple of the 32-pixel tile, batches; on the fp16 path also half-precision in/out."""
+    from vcamd import hip
+    hip.set_conv_precision(precision)
+    try:
+        pc = hip.PackedConv(_rand((cout, cin, 1, 1), 51, 1.0 / np.sqrt(cin)), _rand((cout,), 52, 0.1), device=dev)
+    finally:
+        hip.set_conv_precision("fp32")
+    assert 6 in pc.candidates
+    fl = hip.CFG_F16 if precision == "fp16" else 0
+    wide_in = hip.nchw_to_nhwc(_rand((n, cin + 32, h, w), 53).to(dev))
+    x = wide_in.channels(16, 16 + cin)                      # 64-byte aligned slice of a wider buffer
+    res = hip.nchw_to_nhwc(_rand((n, cout, h, w), 54).to(dev))
+    gain = (_rand((cout,), 55).abs() + 0.5).to(dev)
+
+    def run(cfg, **kw):
+        pc.tuned = {}
+        outs = []
+        for flags in (fl, fl | hip.CFG_IN_F16, fl | hip.CFG_OUT_F16, fl | hip.CFG_IN_F16 | hip.CFG_OUT_F16):
+            pc.tuned[(n, h, w, flags)] = cfg | hip.CFG_EXACT | flags
+        wide_out = hip.T.empty(n, h, w, cout + 8, dev)
+        wide_out.buf.zero_()
+        a = pc(x, act=hip.ACT_RELU)
+        b = pc(x, out=wide_out.channels(4, 4 + cout), res=res, chscale=gain)
+        outs += [hip.nhwc_to_nchw(a), hip.nhwc_to_nchw(wide_out)]
+        if precision == "fp16":                               # half intermediate: producer and consumer both on cfg
+            t = pc(x, act=hip.ACT_LRELU, slope=0.1, out_f16=True)
+            assert t.dtype == "f16"
+            if cin == cout:
+                outs.append(hip.nhwc_to_nchw(pc(t, res=res)))
+            outs.append(t.to_nchw())
+        return outs
+
+    base = run(pc.cfg if pc.cfg <= 2 else 2)
+    pw = run(6)
+    for a, b in zip(base, pw):
+        assert torch.equal(a, b)
+    # and against torch on the exact path
+    ref = F.relu(F.conv2d(hip.nhwc_to_nchw(x).cpu(), _rand((cout, cin, 1, 1), 51, 1.0 / np.sqrt(cin)), _rand((cout,), 52, 0.1)))
+    _close(pw[0], ref, 2e-5 if precision == "fp32" else 5e-3, "pointwise kernel vs torch")

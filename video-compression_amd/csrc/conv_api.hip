@@ -104,8 +104,8 @@ extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout,
 // ---- fp16 path: same fragment order with 8 halves (16 B) per lane = 16 input channels per k-step ----
 static inline bool cfg_f16_ok(int cfg, int cin)
 {
-    return (cfg == VC_CFG_N128 || cfg == VC_CFG_N64 || cfg == VC_CFG_N32 || cfg == VC_CFG_N128B || cfg == VC_CFG_N16) &&
-           (cin % 8) == 0;
+    return (cfg == VC_CFG_N128 || cfg == VC_CFG_N64 || cfg == VC_CFG_N32 || cfg == VC_CFG_N128B || cfg == VC_CFG_N16 ||
+            cfg == VC_CFG_PW) && (cin % 8) == 0;
 }
 
 extern "C" size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride)
@@ -224,6 +224,10 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     if (a.total_blocks <= 0) return VC_EINVAL;
     if (f16 && !a.vec4) return VC_EINVAL;   // the fp16 staging path reads 2 x 16 bytes per item
     hipStream_t stream = as_stream(s);
+    if (cfg == VC_CFG_PW) {                 // streaming 1x1 kernel: only ever chosen explicitly (autotuner)
+        if (!conv_pw_eligible(a, k, st, f16)) return VC_EINVAL;
+        return conv_dispatch_pw(stream, a, f16);
+    }
     switch (k) {
     case 1: return f16 ? conv_dispatch_k1_f16(stream, a, st, cfg, ck) : conv_dispatch_k1_f32(stream, a, st, cfg, ck);
     case 3: return f16 ? conv_dispatch_k3_f16(stream, a, st, cfg, ck) : conv_dispatch_k3_f32(stream, a, st, cfg, ck);

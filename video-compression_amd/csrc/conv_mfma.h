@@ -548,6 +548,9 @@ template <int KH, int KW, int S, int CK> int launch_conv_n4(hipStream_t st, cons
 #define VC_DECLARE_DISPATCH(k)                                                             \
     int conv_dispatch_##k##_f32(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck); \
     int conv_dispatch_##k##_f16(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
+// streaming 1x1 kernel (conv_pw.hip): same packed weights as the 32-wide configurations
+bool conv_pw_eligible(const ConvArgs &a, int k, int stride, bool f16);
+int conv_dispatch_pw(hipStream_t st, const ConvArgs &a, bool f16);
 VC_DECLARE_DISPATCH(k1)
 VC_DECLARE_DISPATCH(k3)
 VC_DECLARE_DISPATCH(k5)
