@@ -427,3 +427,21 @@ def test_pointwise_streaming_kernel_is_bit_identical(dev, cin, cout, h, w, n, pr
     # and against torch on the exact path
     ref = F.relu(F.conv2d(hip.nhwc_to_nchw(x).cpu(), _rand((cout, cin, 1, 1), 51, 1.0 / np.sqrt(cin)), _rand((cout,), 52, 0.1)))
     _close(pw[0], ref, 2e-5 if precision == "fp32" else 5e-3, "pointwise kernel vs torch")
+
+
+@pytest.mark.parametrize("convention", [1, 2, 3])
+def test_warp_feature_maps_vectorised(dev, convention):
+    """multi-channel feature maps (ICIP2024 warps 64/96/128-channel pyramids) take the 16-byte path; it must give
+    the scalar path's values (checked against grid_sample) also for views that are channel slices"""
+    from oracle.flex import warp_w2
+    from oracle.lhbdc import warp_w1
+    from vcamd import hip
+    img = torch.randn(2, 24, 30, 44, generator=torch.Generator().manual_seed(61))
+    flow = _rand((2, 2, 30, 44), 62, 5.0)
+    flow[:, :, :3, :3] = 80.0
+    ref = {1: warp_w1, 2: warp_w2, 3: _warp_w3}[convention](img, flow)
+    wide = hip.nchw_to_nhwc(torch.cat([torch.zeros(2, 8, 30, 44), img], 1).to(dev))
+    dst = hip.T.empty(2, 30, 44, 40, dev)
+    hip.warp(convention, wide.channels(8, 32), hip.nchw_to_nhwc(flow.to(dev)), out=dst.channels(12, 36))
+    out = hip.nhwc_to_nchw(dst.channels(12, 36))
+    _close(out, ref, 2e-5, f"vectorised warp W{convention}")

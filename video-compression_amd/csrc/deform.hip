@@ -33,7 +33,6 @@ __global__ void __launch_bounds__(1024) k_deform(DeformArgs a)
     const int nthreads = 64 * half;
     const float *wsrc = a.wpk + (long long)(second ? half : 0) * 9 * CG * OG;
     for (int i = threadIdx.x; i < half * 9 * CG * OG; i += nthreads) wsm_all[i] = wsrc[i];
-    __syncthreads();
     const int gl = threadIdx.x >> 6;                  // group inside its half == wave index
     const int g = second ? gl + half : gl;
     const int lane = threadIdx.x & 63;
@@ -44,15 +43,30 @@ __global__ void __launch_bounds__(1024) k_deform(DeformArgs a)
     const vc_view &FL = second ? a.flow2 : a.flow1;
     const int H = a.out.h, W = a.out.w;
     const int tiles_x = (W + 7) >> 3;
-    const int y = (blockIdx.x / tiles_x) * 8 + (lane >> 3), x = (blockIdx.x % tiles_x) * 8 + (lane & 7);
+    const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 8;
+    const int y = ty0 + (lane >> 3), x = tx0 + (lane & 7);
+    // FUSED: the 27*half-float offset/mask record of each of the 64 pixels is fetched ONCE by the workgroup with
+    // coalesced loads (a lane reading its own 18+9 values straight from global touches 27 separate 4-byte words
+    // 1.7 KB apart from its neighbours': 1.4 of 3.2 ms at 544x960) and parked in LDS at an odd pixel stride.
+    const int RS = 27 * half + 1;                      // record stride in floats (odd for half = 8: 217)
+    float *rec = wsm_all + half * 9 * CG * OG;
+    if (FUSED) {
+        const int per_px = 27 * half;
+        for (int i = threadIdx.x; i < 64 * per_px; i += nthreads) {
+            const int px = i / per_px, c = i - px * per_px;
+            const int yy = min(ty0 + (px >> 3), H - 1), xx = min(tx0 + (px & 7), W - 1);
+            rec[px * RS + c] = O.p[view_off(O, n, yy, xx) + c];
+        }
+    }
+    __syncthreads();
     if (y >= H || x >= W) return;
 
     float acc[OG];
 #pragma unroll
     for (int o = 0; o < OG; ++o) acc[o] = a.bias ? a.bias[g * OG + o] : 0.0f;
 
-    const float *op = O.p + view_off(O, n, y, x) + gl * 18;
-    const float *mp = FUSED ? O.p + view_off(O, n, y, x) + half * 18 + gl * 9
+    const float *op = FUSED ? rec + lane * RS + gl * 18 : O.p + view_off(O, n, y, x) + gl * 18;
+    const float *mp = FUSED ? rec + lane * RS + half * 18 + gl * 9
                             : (M.p ? M.p + view_off(M, n, y, x) + gl * 9 : nullptr);
     float fu = 0.0f, fv = 0.0f;
     if (FUSED) {
@@ -125,12 +139,15 @@ template <int CG, int OG, bool FUSED> int launch(hipStream_t st, const DeformArg
     if (half > 16) return VC_EINVAL;                       // one wave per group of a half, 1024 threads at most
     const unsigned tiles = (unsigned)(((a.out.h + 7) / 8) * ((a.out.w + 7) / 8));
     const dim3 grid(tiles, 2u, (unsigned)a.out.n), block((unsigned)(64 * half));
-    const size_t lds = (size_t)half * 9 * CG * OG * sizeof(float);
-    if (vec)
-        hipLaunchKernelGGL((k_deform<CG, OG, FUSED, true>), grid, block, lds, st, a);
-    else
-        hipLaunchKernelGGL((k_deform<CG, OG, FUSED, false>), grid, block, lds, st, a);
-    return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
+    const size_t lds = ((size_t)half * 9 * CG * OG + (FUSED ? 64 * (27 * half + 1) : 0)) * sizeof(float);
+    auto launch_one = [&](auto kern) {
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VC_ELAUNCH;
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+        return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
+    };
+    return vec ? launch_one(k_deform<CG, OG, FUSED, true>) : launch_one(k_deform<CG, OG, FUSED, false>);
 }
 
 template <bool FUSED> int dispatch(hipStream_t st, const DeformArgs &a, int cg, int og)
