@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
 H, W = 1080, 1920
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # BF16/FP16 matrix peak, dense
+PEAK_HBM_GBPS = 8000.0           # HBM3E peak (same guide)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -222,14 +223,24 @@ def main():
         ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
         key, dom = ranked[0]
         per_launch_flop = dom["flops"] / dom["launches"]
+        per_launch_bytes = dom["bytes"] / dom["launches"]
         avg_ms = dom["ms"] / dom["launches"]
-        achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
         peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
-        result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak,
-                              "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                              "launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
-                              "share_of_conv_time": dom["ms"] / total_ms,
-                              "algorithmic_flop_per_launch": per_launch_flop}
+        # which roofline bounds the dominant kernel: arithmetic intensity against the ridge peak_flops / peak_bandwidth
+        intensity = per_launch_flop / max(per_launch_bytes, 1.0)
+        if intensity >= peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
+            achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                                  "frac": achieved / peak, "traffic": None}
+        else:
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            result["roofline"] = {"bound": "hbm", "kernel": key, "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                  "frac": achieved / PEAK_HBM_GBPS, "traffic": None,
+                                  "algorithmic_bytes_per_launch": per_launch_bytes}
+        result["roofline"].update({"launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
+                                   "share_of_conv_time": dom["ms"] / total_ms,
+                                   "algorithmic_flop_per_launch": per_launch_flop,
+                                   "flop_per_byte": intensity})
         # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/r01/traffic.json:
         # FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 correction)
         try:

@@ -58,22 +58,25 @@ class KernelTimer:
     def __init__(self):
         self.items = []
 
-    def bracket(self, key, flops, launch):
+    def bracket(self, key, flops, launch, nbytes=0.0):
+        """``flops`` / ``nbytes``: algorithmic work of the launch (bytes = each operand read once + the result
+        written once, in the dtypes actually stored)."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = launch()
         e1.record()
-        self.items.append((key, flops, e0, e1))
+        self.items.append((key, flops, e0, e1, nbytes))
         return out
 
     def table(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, flops, e0, e1 in self.items:
-            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for key, flops, e0, e1, nbytes in self.items:
+            a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += flops
+            a["bytes"] += nbytes
         return agg
 
 
@@ -387,7 +390,10 @@ class PackedConv:
             hq, wq = (ho // 2, wo // 2) if self.ps else (ho, wo)
             flops = 2.0 * x.n * hq * wq * self.cout * self.cin * self.k * self.k
             key = f"conv k{self.k} s{self.stride} {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
-            timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what))
+            nbytes = (x.n * x.h * x.w * self.cin * (2 if half_in else 4) + x.n * ho * wo * co * (2 if half_out else 4)
+                      + self.cout * self.cin * self.k * self.k * (2 if use16 else 4)
+                      + (x.n * ho * wo * co * 4 if res is not None else 0) + (x.n * ho * wo * co * 4 if mul is not None else 0))
+            timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
         return out
 
 
@@ -482,7 +488,8 @@ class PackedDeform:
             launch()
         else:
             flops = 2.0 * x1.n * x1.h * x1.w * self.cout * (self.cin // self.groups) * 9
-            timer.bracket(f"deform k3 {self.cin}->{self.cout} g{self.groups} @{x1.n}x{x1.h}x{x1.w}", flops, launch)
+            nbytes = 4.0 * x1.n * x1.h * x1.w * (self.cin + raw1.c + raw2.c + 4 + self.cout)
+            timer.bracket(f"deform k3 {self.cin}->{self.cout} g{self.groups} @{x1.n}x{x1.h}x{x1.w}", flops, launch, nbytes)
         return out
 
 
