@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Where does a convolution wave spend its life?  Diagnostic companion of `make -C video-compression_amd/csrc stamps`.
+
+    VC_HIP_LIB=video-compression_amd/libvc_hip_stamps.so python tools/stamps.py [cin,cout,k,stride,n,h,w[,cfg] ...]
+The stamps build accumulates shader-clock (s_memtime) intervals per wave around the phases of conv_mfma_kernel for the
+fp32 3x3 and 7x7 instances; this script runs each shape a few times and prints the share of every phase in the waves'
+lifetime.  Intervals are wall-clock per wave: a phase looks long both when it does much work and when the wave waits
+for a co-resident wave that holds the matrix pipe -- read them together with the achieved TFLOP/s."""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
+from vcamd import hip  # noqa: E402
+
+PHASES = ["barrier-before-stage", "staging", "barrier-after-stage", "mfma loop", "epilogue", "lifetime"]
+
+
+def main():
+    shapes = sys.argv[1:] or ["64,32,7,1,4,1088,1920", "128,128,3,1,1,544,960,5", "128,128,3,1,1,544,960,1"]
+    L = hip.lib()
+    if not hasattr(L, "vc_debug_read_stamps"):
+        raise SystemExit("this library has no stamps: build `make -C video-compression_amd/csrc stamps` and set VC_HIP_LIB")
+    L.vc_debug_read_stamps.argtypes = [ctypes.c_void_p]
+    dev = torch.device("cuda:0")
+    buf = (ctypes.c_ulonglong * 8)()
+    for spec in shapes:
+        f = [int(v) for v in spec.split(",")]
+        cin, cout, k, s, n, h, w = f[:7]
+        g = torch.Generator().manual_seed(0)
+        pc = hip.PackedConv(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.zeros(cout), stride=s, device=dev)
+        if len(f) > 7:
+            pc.tuned = {(n, h, w, 0): f[7] | hip.CFG_EXACT}
+        x = hip.T.empty(n, h, w, cin, dev)
+        x.buf.normal_()
+        out = hip.T.empty(n, *pc.out_shape(h, w), dev)
+        pc(x, out=out)
+        L.vc_debug_read_stamps(buf)                      # discard warm-up / autotune launches
+        reps = 5
+        for _ in range(reps):
+            pc(x, out=out, act=hip.ACT_LRELU)
+        L.vc_debug_read_stamps(buf)
+        waves = buf[6] / reps
+        print(f"conv k{k} {cin}->{cout} @{n}x{h}x{w} cfg={f[7] if len(f) > 7 else 'auto'}: waves/launch={waves:.0f}")
+        for i, name in enumerate(PHASES):
+            print(f"   {name:22s} {buf[i] / buf[6]:12.0f} cycles/wave  {100.0 * buf[i] / buf[5]:5.1f}% of lifetime")
+
+
+if __name__ == "__main__":
+    main()
