@@ -249,3 +249,34 @@ def test_gop16_graph_replay_equals_eager(dev, models):
     for o in vgop.ICIP_ORDER_16[1:]:
         assert torch.equal(dec_e[o], dec_g[o])
     assert torch.equal(torch.stack([r[4] for r in recs_e]), torch.stack([r[4] for r in recs_g]))
+
+
+def test_select_flow_follows_the_reference_comparison(dev):
+    """vc_select_flow: first strictly greatest POSITIVE PSNR wins (opt_helpers.py:44-49 starts from best = 0 and
+    compares with '>'); ties keep the earlier candidate; when no PSNR is positive (MSE >= 1) candidate 0 is used;
+    NaN never wins."""
+    import ctypes
+    from vcamd import hip
+    L = hip.lib()
+    cands = [hip.T.empty(1, 4, 6, 4, dev) for _ in range(5)]
+    for i, c in enumerate(cands):
+        c.buf.fill_(float(i + 1))
+    views = (hip.View * 5)(*[c.view() for c in cands])
+    n_elems = 100.0
+
+    def pick(mses):
+        sse = torch.tensor([m * n_elems for m in mses], dtype=torch.float64, device=dev)
+        out = hip.T.empty(1, 4, 6, 4, dev)
+        choice = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        hip.check(L.vc_select_flow(hip.stream(), sse.data_ptr(), 5, n_elems, views, out.view(), choice.data_ptr()), "vc_select_flow")
+        c = int(choice.item())
+        assert torch.equal(out.buf, cands[c].buf)
+        return c
+    assert pick([0.01, 0.002, 0.002, 0.5, 0.003]) == 1          # tie between 1 and 2 -> the earlier one
+    assert pick([0.5, 0.4, 0.3, 0.2, 0.1]) == 4
+    assert pick([2.0, 3.0, 1.5, 1.0, 7.0]) == 0                 # PSNR <= 0 everywhere: nothing beats best = 0
+    assert pick([float("nan"), 0.2, float("nan"), 0.1, 0.3]) == 3
+    assert pick([0.0, 0.2, 0.1, 0.1, 0.3]) == 0                 # MSE 0 -> PSNR +inf
+    bad = (hip.View * 5)(*[c.view() for c in cands[:4]], hip.T.empty(1, 4, 6, 2, dev).view())
+    assert L.vc_select_flow(hip.stream(), torch.zeros(5, dtype=torch.float64, device=dev).data_ptr(), 5, n_elems, bad,
+                            cands[0].view(), None) != 0
