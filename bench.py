@@ -285,6 +285,27 @@ def main():
             result["full_gop"] = {"frames_per_s": 8.0 / dt, "ms_per_gop": 1000.0 * dt,
                                   "what": "1 I-frame (mbt2018_mean q7 architecture, seeded) + 7 B-frames per GOP, eager launches"}
 
+        if is_icip and args.resolution == "1080p":
+            # ---- whole GOP-16 as src/test.py codes it: 1 intra frame (ELIC architecture, seeded) + 15 B-frames ----
+            from vcamd.layers import BitCounter
+            i_model = icip2024.ELIC()
+            i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=4321, conv_gain=0.7))
+            i_model = i_model.to(dev).eval()
+            with torch.no_grad():
+                def full_gop():
+                    dec_last = hip.nhwc_to_nchw(i_model.forward_device(hip.nchw_to_nhwc(frames[16]), BitCounter(dev, 6)))
+                    return vgop.code_gop_icip2024(model, frames, frames[0], torch.clamp(dec_last, 0, 1), H, W, 2)
+                full_gop()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    full_gop()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 2
+            result["full_gop"] = {"frames_per_s": 16.0 / dt, "ms_per_gop": 1000.0 * dt,
+                                  "what": "1 I-frame (ELIC architecture of src/model/elic.py, seeded) + 15 B-frames per GOP-16, "
+                                          "eager launches, quality level 2"}
+
         # ---- CPU baseline: the oracle (PyTorch-CPU restatement, tensor-equal to the reference) ----
         if not args.no_cpu_baseline and args.resolution == "1080p":
             from oracle import flex as oracle_flex

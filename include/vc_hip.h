@@ -82,6 +82,9 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
  * `res`, `mul`, `chscale` and `bias` stay fp32. */
 #define VC_CFG_IN_F16 0x400
 #define VC_CFG_OUT_F16 0x800
+/* OR into vc_conv_desc.cfg: add `res` BEFORE the (plain / ReLU / LeakyReLU) activation instead of after it --
+ * out = relu(conv(x) + res), the ResidualUnit of compressai.layers.AttentionBlock (ICIP2024/src/model/elic.py:97-121). */
+#define VC_CFG_RES_FIRST 0x1000
 
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */
@@ -186,6 +189,10 @@ int vc_deform_conv2d(vc_stream s, vc_view in, vc_view offset, vc_view mask, cons
  * the rest x2.  raw_r [n,h,w,27*G/2], flow_r [n,h,w,2] = (u,v), x_r [n,h,w,(G/2)*cg], out [n,h,w,G*og]. */
 int vc_offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2,
                         float magnitude, const float *wpk, const float *bias, int groups, vc_view out);
+
+/* Gate of compressai.layers.AttentionBlock (ELIC intra codec of ICIP2024, src/model/elic.py:97-121):
+ * out = a * sigmoid(b) + identity. */
+int vc_attention_gate(vc_stream s, vc_view a, vc_view b, vc_view identity, vc_view out);
 
 /* Motion-adaptive flow resolution (ICIP2024/src/opt_helpers.py:41-51) without leaving the device:
  * vc_sse_clamp01 writes workgroup partial sums of (clamp(pred,0,1) - cur)^2 (fold them with vc_bits_reduce);

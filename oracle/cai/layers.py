@@ -112,8 +112,26 @@ class ResidualBlock(nn.Module):
 
 
 class AttentionBlock(nn.Module):
-    """Imported by the reference (LHBDC/model/layers.py:9) but never instantiated on the path."""
+    """compressai.layers.AttentionBlock (v1.1.8), the simplified attention of Cheng et al. 2020:
+    out = conv_a(x) * sigmoid(conv_b(x)) + x with conv_a = 3 residual units, conv_b = 3 residual units + conv1x1;
+    residual unit: relu(conv1x1(N->N/2) -> ReLU -> conv3x3 -> ReLU -> conv1x1(N/2->N) + x).
+    Imported by LHBDC/Flex (never instantiated there); used by the ELIC intra codec of ICIP2024 (elic.py:97-121)."""
 
-    def __init__(self, *a, **k):
+    def __init__(self, N):
         super().__init__()
-        raise NotImplementedError("AttentionBlock is not on the hot path")
+
+        class ResidualUnit(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.conv = nn.Sequential(conv1x1(N, N // 2), nn.ReLU(inplace=True), conv3x3(N // 2, N // 2),
+                                          nn.ReLU(inplace=True), conv1x1(N // 2, N))
+                self.relu = nn.ReLU(inplace=True)
+
+            def forward(self, x):
+                return self.relu(self.conv(x) + x)
+
+        self.conv_a = nn.Sequential(ResidualUnit(), ResidualUnit(), ResidualUnit())
+        self.conv_b = nn.Sequential(ResidualUnit(), ResidualUnit(), ResidualUnit(), conv1x1(N, N))
+
+    def forward(self, x):
+        return self.conv_a(x) * torch.sigmoid(self.conv_b(x)) + x

@@ -32,10 +32,24 @@ sys.dont_write_bytecode = True
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "video-compression_amd"))
 
 from oracle import cai, deform as odeform, flex as oflex, icip2024 as oicip, lhbdc as olhbdc  # noqa: E402
-from vcamd.seeding import seeded_state_dict  # noqa: E402
+
+# The seeded-checkpoint generator is loaded by file: video-compression_amd/ must NOT be on sys.path here, it holds
+# packages named like the reference's (model/, b_model/, src/) that would shadow the modules this script pins against.
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("vc_seeding", os.path.join(REPO, "video-compression_amd", "vcamd", "seeding.py"))
+_seeding = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_seeding)
+seeded_state_dict = _seeding.seeded_state_dict
+
+
+def from_reference(*modules):
+    """Refuse to pin against anything that was not imported from /root/reference."""
+    for mod in modules:
+        origin = os.path.realpath(getattr(mod, "__file__", "") or "")
+        if not origin.startswith(os.path.realpath(REF) + os.sep):
+            raise SystemExit(f"{mod.__name__} was imported from {origin}, not from the reference")
 
 
 def install_standins():
@@ -69,6 +83,7 @@ def import_reference_lhbdc():
     sys.path.insert(0, os.path.join(REF, "LHBDC"))
     from model import m as ref_m  # noqa
     from model import flow as ref_flow  # noqa
+    from_reference(ref_m, ref_flow)
     ref_m.device = torch.device("cpu")
     ref_flow.device = torch.device("cpu")
     sys.path.pop(0)
@@ -80,6 +95,7 @@ def import_reference_lhbdc():
 def import_reference_flex():
     sys.path.insert(0, os.path.join(REF, "Flex-Rate-Hier-Bidir-Video-Compression"))
     from b_model import b_model as ref_b  # noqa
+    from_reference(ref_b)
     ref_b.device = torch.device("cpu")
     sys.path.pop(0)
     return ref_b
@@ -271,6 +287,8 @@ def gen_icip2024(outdir, frames, seed):
     from src.model import m as ref_m  # noqa
     from src import opt_helpers as ref_opt  # noqa
     from src import utils as ref_utils  # noqa
+    from src.model import elic as ref_elic  # noqa
+    from_reference(ref_m, ref_opt, ref_utils, ref_elic)
     sys.path.pop(0)
     torch.manual_seed(0)
     ref = ref_m.FlowGuidedB().eval()
@@ -310,6 +328,23 @@ def gen_icip2024(outdir, frames, seed):
         store["best_down_ratio"] = np.int64(best_r)
         store["best_pred_psnr"] = np.float64(psnr_r.item())
     np.savez_compressed(os.path.join(outdir, "icip2024_forward_a.npz"), **store)
+
+    # ELIC intra codec (src/model/elic.py) through utils.image_compress, as src/test.py:60 calls it
+    torch.manual_seed(0)
+    ref_i = ref_elic.ELIC().eval()
+    sd_i = seeded_state_dict(ref_i.state_dict(), seed=seed + 1, conv_gain=0.7)
+    ref_i.load_state_dict(sd_i)
+    ora_i = oicip.ELIC().eval()
+    ora_i.load_state_dict(sd_i)
+    with open(os.path.join(outdir, "icip2024_elic_state_schema.txt"), "w") as f:
+        f.write("\n".join(f"{k} {list(v.shape)}" for k, v in sorted(ref_i.state_dict().items())) + "\n")
+    with torch.no_grad():
+        dec_r, size_r = ref_utils.image_compress(xc, [ref_i], 0)
+        dec_o, size_o = oicip.image_compress(xc, [ora_i], 0)
+    check("ELIC x_hat", dec_o, dec_r)
+    check("ELIC size", size_o, size_r)
+    np.savez_compressed(os.path.join(outdir, "icip2024_elic_a.npz"), seed=np.int64(seed + 1), conv_gain=np.float64(0.7),
+                        current=c["current"], x_hat=dec_r.numpy(), size=np.float64(size_r.item()))
 
     book = {"order_typ": {}, "refs": {}}
     for n_frames in (17, 33, 40, 300, 600):

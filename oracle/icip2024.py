@@ -7,6 +7,7 @@ Follows (relative to /root/reference/ICIP2024/src):
   model/elic.py:69-83                    ResidualBottleneckBlock                         -> :class:`ResidualBottleneckBlock`
   model/layers.py:6-29                   CheckerboardContext                             -> :class:`CheckerboardContext`
   model/compression_bottlenecks.py:72-551  Offset_ELIC / Res_ELIC                        -> :class:`_Elic` (one body, two configs)
+  model/elic.py:85-260                   ELIC intra codec (forward only; src/test.py:60 via utils.image_compress) -> :class:`ELIC`
   opt_helpers.py:23-51                   prediction_flowonly, get_best_down_ratio_prediction
   utils.py:153-250                       select_references, update_buffer, get_order_typ_list, get_scales
 
@@ -23,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .cai.layers import conv1x1, conv3x3, subpel_conv3x3
+from .cai.layers import AttentionBlock, conv1x1, conv3x3, subpel_conv3x3
 from .cai.models import JointAutoregressiveHierarchicalPriors
 from .deform import DeformConv2d
 
@@ -261,6 +262,61 @@ class Res_ELIC(_Elic):
     def forward(self, f1, f2, f3, f1d, f2d, f3d, residual_temp, s):
         r1, r2, r3, lik = self.code(torch.cat([f1, f1d], 1), [f2, f2d], [f3, f3d], f1d, f2d, f3d, residual_temp, s)
         return {"res3": r3, "res2": r2, "res1": r1, "likelihoods": lik}
+
+
+ELIC_GROUPS = (0, 16, 32, 64, 128)
+
+
+class ELIC(JointAutoregressiveHierarchicalPriors):
+    """The I-frame codec of the ICIP2024 test loop (elic.py:85-260): 5x5 stride-2 transforms with bottleneck blocks and
+    attention, hyperprior + checkerboard + channel-context entropy model over the uneven groups 16/16/32/64/M-128."""
+
+    def __init__(self, N=192, M=320):
+        super().__init__(N, M)
+        self.g_a = nn.Sequential(_conv(3, N), *_rbb(N), _conv(N, N), *_rbb(N), AttentionBlock(N), _conv(N, N), *_rbb(N),
+                                 _conv(N, M), AttentionBlock(M))
+        self.g_s = nn.Sequential(AttentionBlock(M), _deconv(M, N), *_rbb(N), _deconv(N, N), AttentionBlock(N), *_rbb(N),
+                                 _deconv(N, N), *_rbb(N), _deconv(N, 3))
+        self.h_a = nn.Sequential(_conv(M, N, 3, 1), nn.ReLU(inplace=True), _conv(N, N), nn.ReLU(inplace=True), _conv(N, N))
+        self.h_s = nn.Sequential(_deconv(N, M), nn.ReLU(inplace=True), _deconv(M, M * 3 // 2), nn.ReLU(inplace=True),
+                                 _conv(M * 3 // 2, M * 2, 3, 1))
+        self.entropy_parameters = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(cin, M * 10 // 3, 1), nn.LeakyReLU(inplace=True),
+                          nn.Conv2d(M * 10 // 3, M * 8 // 3, 1), nn.LeakyReLU(inplace=True),
+                          nn.Conv2d(M * 8 // 3, cout * 6 // 3, 1))
+            for cin, cout in [(M * 4, 16), (M * 6, 16), (M * 6, 32), (M * 6, 64), (M * 6, M - 128)])
+        self.channel_context_models = nn.ModuleList(
+            nn.Sequential(_conv(cin, N, 5, 1), nn.ReLU(inplace=True), _conv(N, N, 5, 1), nn.ReLU(inplace=True),
+                          _conv(N, M * 2, 5, 1)) for cin in [16, 32, 64, 128])
+        self.context_prediction_models = nn.ModuleList(
+            CheckerboardContext(in_channels=cin, out_channels=M * 2, kernel_size=5, stride=1, padding=2)
+            for cin in [16, 16, 32, 64, M - 128])
+
+    def forward(self, x):
+        y = self.g_a(x)
+        z = self.h_a(y)
+        lik = {}
+        _, lik["z"] = self.entropy_bottleneck(z)
+        hyper = self.h_s(torch.round(z))
+        bounds = ELIC_GROUPS + (y.shape[1],)
+        for i in range(5):
+            cur = y[:, bounds[i]:bounds[i + 1]]
+            half = torch.round(cur).clone()
+            half[:, :, 0::2, 0::2] = 0
+            half[:, :, 1::2, 1::2] = 0
+            ctx = self.context_prediction_models[i](half)
+            ctx[:, :, 0::2, 1::2] = 0
+            ctx[:, :, 1::2, 0::2] = 0
+            parts = [ctx, hyper] if i == 0 else [ctx, self.channel_context_models[i - 1](torch.round(y[:, :bounds[i]])), hyper]
+            scales, means = self.entropy_parameters[i](torch.cat(parts, 1)).chunk(2, 1)
+            _, lik[f"y_{i}"] = self.gaussian_conditional(cur, scales, means=means)
+        return {"x_hat": self.g_s(torch.round(y)), "likelihoods": lik}
+
+
+def image_compress(im, compressors, n):
+    """utils.py:306-316: intra-code a frame at quality index n -> (reconstruction, estimated size in bits)."""
+    out = compressors[n].eval()(im)
+    return out["x_hat"], _bits(out["likelihoods"])
 
 
 def _bits(likelihoods):

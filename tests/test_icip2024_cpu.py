@@ -125,3 +125,23 @@ def test_reference_import_paths_resolve():
     assert compression_bottlenecks.Offset_ELIC is icip2024.Offset_ELIC
     assert opt_helpers.get_best_down_ratio_prediction is icip2024.get_best_down_ratio_prediction
     assert utils.get_order_typ_list(16, 17)[0][:3] == [0, 16, 8]
+
+
+def test_oracle_elic_matches_reference_fixture():
+    fx = load_fixture("icip2024_elic_a.npz")
+    m = oi.ELIC().eval()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed=int(fx["seed"]), conv_gain=float(fx["conv_gain"])))
+    with torch.no_grad():
+        dec, size = oi.image_compress(frame_tensor(fx["current"]), [m], 0)
+    ref = torch.from_numpy(fx["x_hat"])
+    assert ((dec - ref).abs() / (1 + ref.abs())).max().item() < 5e-3
+    assert abs(size.item() - float(fx["size"])) / float(fx["size"]) < 1e-3
+
+
+def test_product_elic_schema_equals_reference_schema():
+    ref = [l.strip() for l in open(os.path.join(GOLDEN, "icip2024_elic_state_schema.txt"))]
+    mine = sorted(f"{k} {list(v.shape)}" for k, v in icip2024.ELIC().state_dict().items())
+    assert mine == ref and len(mine) == 387
+    sd = seeded_state_dict(icip2024.ELIC().state_dict(), seed=5)
+    icip2024.ELIC().load_state_dict(sd, strict=True)
+    oi.ELIC().load_state_dict(sd, strict=True)

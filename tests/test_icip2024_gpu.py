@@ -280,3 +280,54 @@ def test_select_flow_follows_the_reference_comparison(dev):
     bad = (hip.View * 5)(*[c.view() for c in cands[:4]], hip.T.empty(1, 4, 6, 2, dev).view())
     assert L.vc_select_flow(hip.stream(), torch.zeros(5, dtype=torch.float64, device=dev).data_ptr(), 5, n_elems, bad,
                             cands[0].view(), None) != 0
+
+
+def test_residual_before_activation_and_attention_gate(dev):
+    """VC_CFG_RES_FIRST (relu(conv + res), compressai ResidualUnit) on the general and the streaming 1x1 kernel, and
+    vc_attention_gate, against torch."""
+    import torch.nn.functional as F
+    from vcamd import hip
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 18, 37, generator=g)
+    res = torch.randn(2, 96, 18, 37, generator=g)
+    for k in (1, 3):
+        wt = torch.randn(96, 64, k, k, generator=g) / (64 * k * k) ** 0.5
+        b = torch.randn(96, generator=g) * 0.1
+        ref = F.relu(F.conv2d(x, wt, b, padding=k // 2) + res)
+        pc = hip.PackedConv(wt, b, device=dev)
+        for cfg in ([pc.cfg, 6] if k == 1 else [pc.cfg]):
+            pc.tuned = {(2, 18, 37, hip.CFG_RES_FIRST): cfg | hip.CFG_EXACT | hip.CFG_RES_FIRST}
+            out = hip.nhwc_to_nchw(pc(hip.nchw_to_nhwc(x.to(dev)), act=hip.ACT_RELU, res=hip.nchw_to_nhwc(res.to(dev)), res_first=True))
+            assert ((out.cpu() - ref).abs() / (1 + ref.abs())).max().item() < 2e-5
+    a, bb, idt = (torch.randn(1, 24, 9, 11, generator=g) for _ in range(3))
+    out = hip.nhwc_to_nchw(hip.attention_gate(*[hip.nchw_to_nhwc(t.to(dev)) for t in (a, bb, idt)])).cpu()
+    assert (out - (a * torch.sigmoid(bb) + idt)).abs().max().item() < 1e-6
+
+
+def test_elic_intra_codec_matches_reference_fixture_and_oracle(dev):
+    from oracle import icip2024 as oi
+    from vcamd import icip2024
+    from vcamd.seeding import seeded_state_dict
+    fx = load_fixture("icip2024_elic_a.npz")
+    prod = icip2024.ELIC()
+    sd = seeded_state_dict(prod.state_dict(), seed=int(fx["seed"]), conv_gain=float(fx["conv_gain"]))
+    prod.load_state_dict(sd)
+    prod = prod.to(dev).eval()
+    x = frame_tensor(fx["current"])
+    with torch.no_grad():
+        dec, size = icip2024.image_compress(x.to(dev), [prod], 0)
+    ref = torch.from_numpy(fx["x_hat"])
+    d_psnr = abs(psnr(dec.cpu(), x) - psnr(ref, x))
+    rel = abs(size.item() - float(fx["size"])) / float(fx["size"])
+    print(f"ELIC: max|d|={(dec.cpu() - ref).abs().max():.3e} dPSNR={d_psnr:.2e} size rel={rel:.2e}")
+    assert d_psnr < PSNR_TOL_DB and rel < 2e-3
+    # a batch of two different frames against the oracle run live
+    fy = load_fixture("lhbdc_forward_b.npz")
+    xs = torch.cat([frame_tensor(fy["ref_1"]), frame_tensor(fy["current"])], 0)
+    ora = oi.ELIC().eval()
+    ora.load_state_dict(sd)
+    with torch.no_grad():
+        r = ora(xs)
+        o = prod(xs.to(dev))
+    assert abs(psnr(o["x_hat"].cpu(), xs) - psnr(r["x_hat"], xs)) < PSNR_TOL_DB
+    assert abs(o["size"].item() - oi._bits(r["likelihoods"]).item()) / o["size"].item() < 2e-3

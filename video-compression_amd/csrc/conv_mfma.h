@@ -63,6 +63,7 @@ struct ConvArgs {
     int epi, in_xform, out_mode, vec4;
     int vec_out;   // out / res / mul / chscale allow 16-byte accesses on groups of 4 consecutive output channels
     int in_f16, out_f16;   // fp16 path only: `in` / `out` point at half-precision tensors (strides in elements)
+    int res_first;         // add the residual BEFORE the activation (plain/ReLU/LeakyReLU epilogues only)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -449,6 +450,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                                 for (int e = 0; e < 4; ++e)   // IEEE sqrt and divide, like the CPU path's x * rsqrt(norm)
                                     v[e] = (MODE == 1) ? x[e] * (1.0f / sqrtf(v[e])) : x[e] * sqrtf(v[e]);
                             }
+                            if (MODE == 0 && p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 if constexpr (MODE == 3) v[e] = 1.0f / (1.0f + expf(-v[e]));
@@ -456,7 +458,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                                 else if constexpr (MODE == 0) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
                             }
                             if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
-                            if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                            if (p.res && !(MODE == 0 && p.res_first)) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
                             if (F16 && p.out_f16) {
                                 const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                                 *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + o_off) = hv;
@@ -472,15 +474,18 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                                         const float x = p.mul[mul_pix + co + e];
                                         w = (MODE == 1) ? x * (1.0f / sqrtf(w)) : x * sqrtf(w);
                                     }
-                                    if constexpr (MODE == 3) w = 1.0f / (1.0f + expf(-w));
-                                    else if constexpr (MODE == 4) w = fminf(fmaxf(w, 0.0f), 1.0f);
-                                    else if constexpr (MODE == 0) w = w >= 0.0f ? w : w * neg;
-                                    if (p.chscale) w *= p.chscale[co + e];
                                     // (pixel-shuffle: a quad may straddle two output positions when cout/4 % 4 != 0)
                                     const int pe = ps ? (co + e) / cps : 0;
                                     const int ce = ps ? co + e - pe * cps : co + e;
                                     const int ye = sc * oy + (pe >> 1), xe = sc * ox + (pe & 1);
-                                    if (p.res) w += p.res[(long long)img * p.res_sn + (long long)ye * p.res_sh + (long long)xe * p.res_sw + ce];
+                                    const long long re = (long long)img * p.res_sn + (long long)ye * p.res_sh + (long long)xe * p.res_sw + ce;
+                                    const bool first = MODE == 0 && p.res_first;
+                                    if (first) w += p.res[re];
+                                    if constexpr (MODE == 3) w = 1.0f / (1.0f + expf(-w));
+                                    else if constexpr (MODE == 4) w = fminf(fmaxf(w, 0.0f), 1.0f);
+                                    else if constexpr (MODE == 0) w = w >= 0.0f ? w : w * neg;
+                                    if (p.chscale) w *= p.chscale[co + e];
+                                    if (p.res && !first) w += p.res[re];
                                     const long long oe = (long long)img * p.out_sn + (long long)ye * p.out_sh + (long long)xe * p.out_sw + ce;
                                     if (F16 && p.out_f16) reinterpret_cast<_Float16 *>(p.out)[oe] = (_Float16)w;
                                     else p.out[oe] = w;

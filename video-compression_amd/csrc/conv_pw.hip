@@ -138,10 +138,11 @@ __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
                     const int co = t * 32 + 8 * g + 4 * h;
                     if (co < p.Cout) {
                         f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                        if (p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_pix + co);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
                         if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
-                        if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + r_pix + co);
+                        if (p.res && !p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_pix + co);
                         if (F16 && p.out_f16) {
                             const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                             *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + o_pix + co) = hv;

@@ -284,6 +284,35 @@ extern "C" int vc_channel_scale(vc_stream s, vc_view a, const float *gain, vc_vi
 }
 
 // ------------------------------------------------------------------------------------------------
+// compressai.layers.AttentionBlock gate: out = a * sigmoid(b) + identity (ICIP2024 ELIC intra codec, elic.py:97-121)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_attention_gate(vc_view a, vc_view b, vc_view identity, vc_view out)
+{
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        const float g = 1.0f / (1.0f + expf(-b.p[view_off(b, n, y, x) + c]));
+        out.p[view_off(out, n, y, x) + c] = a.p[view_off(a, n, y, x) + c] * g + identity.p[view_off(identity, n, y, x) + c];
+    }
+}
+
+extern "C" int vc_attention_gate(vc_stream s, vc_view a, vc_view b, vc_view identity, vc_view out)
+{
+    if (!a.p || !b.p || !identity.p || !out.p) return VC_EINVAL;
+    const vc_view *vs[] = {&a, &b, &identity};
+    for (const vc_view *v : vs)
+        if (v->n != out.n || v->h != out.h || v->w != out.w || v->c < out.c) return VC_EINVAL;
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_attention_gate, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, b, identity, out);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // quantise + checkerboard mask (ICIP2024 compression_bottlenecks.py:237-246,268-269)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_quantize_mask(vc_view in, vc_view out, const float *__restrict__ gain, int keep_parity, int do_round)

@@ -1,2 +1,2 @@
-"""``src.model.elic`` -- the block ICIP2024's B-frame codec takes from elic.py (the ELIC intra codec itself is out of scope)."""
-from vcamd.icip2024 import ResidualBottleneckBlock  # noqa: F401
+"""``src.model.elic`` -- ICIP2024/src/model/elic.py names (forward / rate estimate only)."""
+from vcamd.icip2024 import ELIC, ResidualBottleneckBlock  # noqa: F401

@@ -129,6 +129,7 @@ def lib():
     sig("vc_deform_pack_weights", ci, vp, ci, ci, ci, vp)
     sig("vc_deform_conv2d", ci, vp, View, View, View, vp, vp, ci, View)
     sig("vc_offset_diversity", ci, vp, View, View, View, View, View, View, cf, vp, vp, ci, View)
+    sig("vc_attention_gate", ci, vp, View, View, View, View)
     sig("vc_sse_clamp01", ci, vp, View, View, vp, ci)
     sig("vc_select_flow", ci, vp, vp, ci, ctypes.c_double, ctypes.POINTER(View), View, vp)
     sig("vc_eb_forward", ci, vp, View, vp, vp, vp, View, vp, vp, ci)
@@ -153,7 +154,7 @@ EXPORTED_SYMBOLS = [
     "vc_nhwc_to_nchw", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity",
-    "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
+    "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
     "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes",
 ]
@@ -243,6 +244,7 @@ CFG_EXACT = 0x100
 CFG_F16 = 0x200
 CFG_IN_F16 = 0x400
 CFG_OUT_F16 = 0x800
+CFG_RES_FIRST = 0x1000
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
 # "fp32" (default, exact fp32 FMA chains like the reference) or "fp16" (BASELINE.json configs[4]: half-precision MFMA
 # with fp32 accumulate for every eligible layer; judged on PSNR/bpp tolerance, never the headline number).
@@ -347,7 +349,7 @@ class PackedConv:
         return self.wpk16 is not None
 
     def __call__(self, x, out=None, act=ACT_NONE, slope=0.01, res=None, epi=EPI_NONE, mul=None,
-                 in_xform=IN_NONE, chscale=None, out_f16=False):
+                 in_xform=IN_NONE, chscale=None, out_f16=False, res_first=False):
         """``out_f16``: a hint that every consumer of the result is an fp16-path convolution (``half_ok``), so the
         result may be stored as half (bit-identical downstream, half the traffic).  Honoured only when this layer
         itself runs on the fp16 path and allocates its own output; otherwise the result stays fp32."""
@@ -378,10 +380,10 @@ class PackedConv:
         d.epi, d.in_xform = epi, in_xform
         d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
         d.cfg = self.cfg
-        flags = 0
+        flags = CFG_RES_FIRST if res_first else 0        # out = act(conv + res) instead of act(conv) + res
         if use16:
             d.wpk = self.wpk16.data_ptr()
-            flags = CFG_F16 | (CFG_IN_F16 if half_in else 0) | (CFG_OUT_F16 if half_out else 0)
+            flags |= CFG_F16 | (CFG_IN_F16 if half_in else 0) | (CFG_OUT_F16 if half_out else 0)
         d.cfg = self._pick_cfg(d, (x.n, x.h, x.w, flags), flags)
         what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})"
         if timer is None:
@@ -440,6 +442,14 @@ def channel_scale(x, gain, out=None):
     if out is None:
         out = T.empty(x.n, x.h, x.w, x.c, x.buf.device)
     check(lib().vc_channel_scale(stream(), x.view(), gain.data_ptr(), out.view()), "vc_channel_scale")
+    return out
+
+
+def attention_gate(a, b, identity, out=None):
+    """out = a * sigmoid(b) + identity (compressai AttentionBlock)."""
+    if out is None:
+        out = T.empty(a.n, a.h, a.w, a.c, a.buf.device)
+    check(lib().vc_attention_gate(stream(), a.view(), b.view(), identity.view(), out.view()), "vc_attention_gate")
     return out
 
 

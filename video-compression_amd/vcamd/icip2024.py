@@ -7,6 +7,7 @@ Drop-in for (under /root/reference/ICIP2024/src):
   model/elic.py:69-83                      ResidualBottleneckBlock          -> same name
   model/layers.py:6-29                     CheckerboardContext              -> same name
   model/compression_bottlenecks.py:72-551  Offset_ELIC / Res_ELIC           -> same names
+  model/elic.py:85-260                     ELIC intra codec (forward / rate estimate, via utils.image_compress) -> :class:`ELIC`
   opt_helpers.py:23-51                     prediction_flowonly, get_best_down_ratio_prediction
   utils.py:153-250                         select_references, update_buffer, get_order_typ_list, get_scales
 Attribute names reproduce the reference's state_dict keys (1126 entries, tests/golden/icip2024_state_schema.txt),
@@ -414,6 +415,129 @@ class Offset_ELIC(_Elic):
 class Res_ELIC(_Elic):
     def __init__(self, N=128, M=128, **kwargs):
         super().__init__(2, 1, (64, 96, 128), N, M)
+
+
+# ------------------------------------------------------------------------------------------------
+# elic.py: the intra codec of the ICIP2024 test loop
+# ------------------------------------------------------------------------------------------------
+class _ResidualUnit(_Prepared):
+    """compressai AttentionBlock.ResidualUnit: relu(conv1x1 -> ReLU -> conv3x3 -> ReLU -> conv1x1 + x)."""
+
+    def __init__(self, N):
+        super().__init__()
+        self.conv = nn.Sequential(conv1x1(N, N // 2), nn.ReLU(inplace=True), conv3x3(N // 2, N // 2), nn.ReLU(inplace=True),
+                                  conv1x1(N // 2, N))
+        self.relu = nn.ReLU(inplace=True)
+
+    def run(self, x):
+        if self._packed is None:
+            self._packed = (pack_conv(self.conv[0]), pack_conv(self.conv[2]), pack_conv(self.conv[4]))
+        c1, c2, c3 = self._packed
+        t = c1(x, act=hip.ACT_RELU, out_f16=c2.half_ok)
+        t = c2(t, act=hip.ACT_RELU, out_f16=c3.half_ok)
+        return c3(t, act=hip.ACT_RELU, res=x, res_first=True)        # the ReLU comes AFTER the skip addition
+
+
+class AttentionBlock(_Prepared):
+    """compressai.layers.AttentionBlock: conv_a(x) * sigmoid(conv_b(x)) + x (elic.py:97-121 uses it four times)."""
+    vc_block = True
+
+    def __init__(self, N):
+        super().__init__()
+        self.conv_a = nn.Sequential(_ResidualUnit(N), _ResidualUnit(N), _ResidualUnit(N))
+        self.conv_b = nn.Sequential(_ResidualUnit(N), _ResidualUnit(N), _ResidualUnit(N), conv1x1(N, N))
+
+    def run(self, x, out=None):
+        if self._packed is None:
+            self._packed = pack_conv(self.conv_b[3])
+        a = b = x
+        for u in self.conv_a:
+            a = u.run(a)
+        for u in list(self.conv_b)[:3]:
+            b = u.run(b)
+        return hip.attention_gate(a, self._packed(b), x, out=out)
+
+
+ELIC_GROUPS = (0, 16, 32, 64, 128)
+
+
+class ELIC(JointAutoregressiveHierarchicalPriors):
+    """elic.py:85-260, forward (rate estimate) only -- what utils.image_compress calls for the I-frames."""
+
+    def __init__(self, N=192, M=320, **kwargs):
+        super().__init__(N, M)
+        self.g_a = nn.Sequential(conv(3, N), *_rbb(N), conv(N, N), *_rbb(N), AttentionBlock(N), conv(N, N), *_rbb(N),
+                                 conv(N, M), AttentionBlock(M))
+        self.g_s = nn.Sequential(AttentionBlock(M), deconv(M, N), *_rbb(N), deconv(N, N), AttentionBlock(N), *_rbb(N),
+                                 deconv(N, N), *_rbb(N), deconv(N, 3))
+        self.h_a = nn.Sequential(conv(M, N, stride=1, kernel_size=3), nn.ReLU(inplace=True), conv(N, N), nn.ReLU(inplace=True),
+                                 conv(N, N))
+        self.h_s = nn.Sequential(deconv(N, M), nn.ReLU(inplace=True), deconv(M, M * 3 // 2), nn.ReLU(inplace=True),
+                                 conv(M * 3 // 2, M * 2, stride=1, kernel_size=3))
+        self.entropy_parameters = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(cin, M * 10 // 3, 1), nn.LeakyReLU(inplace=True),
+                          nn.Conv2d(M * 10 // 3, M * 8 // 3, 1), nn.LeakyReLU(inplace=True),
+                          nn.Conv2d(M * 8 // 3, cout * 6 // 3, 1))
+            for cin, cout in [(M * 4, 16), (M * 6, 16), (M * 6, 32), (M * 6, 64), (M * 6, M - 128)])
+        self.channel_context_models = nn.ModuleList(
+            nn.Sequential(conv(cin, N, kernel_size=5, stride=1), nn.ReLU(inplace=True),
+                          conv(N, N, kernel_size=5, stride=1), nn.ReLU(inplace=True),
+                          conv(N, M * 2, kernel_size=5, stride=1)) for cin in [16, 32, 64, 128])
+        self.context_prediction_models = nn.ModuleList(
+            CheckerboardContext(in_channels=cin, out_channels=M * 2, kernel_size=5, stride=1, padding=2)
+            for cin in [16, 16, 32, 64, M - 128])
+
+    def _sub(self, name, i, x, **kw):
+        return run_sequential(getattr(self, name)[i], x, self._caches.setdefault(f"{name}.{i}", {}), **kw)
+
+    def forward_device(self, x, bits):
+        """x: T [n,H,W,3] (H, W multiples of 64) -> x_hat T; appends 6 x n rows to ``bits`` (z, y_0..y_4 per image)."""
+        L, M = hip.lib(), self.M
+        y = self.seq("g_a", x)
+        z = self.seq("h_a", y)
+        dev, n, h, w = y.buf.device, y.n, y.h, y.w
+        for i in range(n):
+            hip.check(L.vc_eb_forward(hip.stream(), z.images(i, i + 1).view(), self.entropy_bottleneck.device_params().data_ptr(),
+                                      None, None, hip.NULL_VIEW, None, bits.next_row_ptr(), bits.slots), "vc_eb_forward")
+        params_in = T.empty(n, h, w, 6 * M, dev)                       # [ctx | channel ctx | hyper]
+        hyper = self.seq("h_s", hip.quantize_mask(z), out=params_in.channels(4 * M, 6 * M))
+        params_in0 = T.empty(n, h, w, 4 * M, dev)                      # group 0: [ctx | hyper]
+        hip.axpby(hyper, None, out=params_in0.channels(2 * M, 4 * M))
+        y_round = hip.quantize_mask(y)
+        y_half = hip.quantize_mask(y, keep_parity=1)
+        bounds = ELIC_GROUPS + (M,)
+        for i in range(5):
+            c0, c1 = bounds[i], bounds[i + 1]
+            pin = params_in0 if i == 0 else params_in
+            key = f"ctx.{i}"
+            if key not in self._caches:
+                self._caches[key] = pack_conv(self.context_prediction_models[i])
+            ctx = self._caches[key](y_half.channels(c0, c1), out=pin.channels(0, 2 * M))
+            hip.quantize_mask(ctx, out=ctx, keep_parity=0, do_round=False)
+            if i > 0:
+                self._sub("channel_context_models", i - 1, y_round.channels(0, c0), out=pin.channels(2 * M, 4 * M))
+            gp = self._sub("entropy_parameters", i, pin)
+            half = c1 - c0
+            for j in range(n):
+                hip.check(L.vc_gc_forward(hip.stream(), y.channels(c0, c1).images(j, j + 1).view(),
+                                          gp.channels(0, half).images(j, j + 1).view(),
+                                          gp.channels(half, 2 * half).images(j, j + 1).view(), None, None, hip.NULL_VIEW,
+                                          bits.next_row_ptr(), bits.slots, None, None, None, None, 0), "vc_gc_forward")
+        return self.seq("g_s", y_round)
+
+    def forward(self, x):
+        """NCHW CUDA tensor in; ``{"x_hat", "size"}`` out (``size`` = the -log2 likelihood sum the reference's
+        image_compress derives from the likelihood tensors, which are not materialised here)."""
+        _require_frames(x)
+        bits = BitCounter(x.device, max_rows=6 * x.shape[0])
+        x_hat = hip.nhwc_to_nchw(self.forward_device(hip.nchw_to_nhwc(x), bits))
+        return {"x_hat": x_hat, "size": bits.totals().sum().float()}
+
+
+def image_compress(im, compressors, n):
+    """utils.py:306-316: (reconstruction, estimated size in bits) of an intra-coded frame at quality index n."""
+    out = compressors[n](im)
+    return out["x_hat"], out["size"]
 
 
 # ------------------------------------------------------------------------------------------------
