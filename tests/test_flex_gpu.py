@@ -1,7 +1,6 @@
 """-m gpu: the Flex-Rate B-frame path (BidirFlowRef surface over the HIP kernels) against the golden
 fixtures recorded from the reference and against the CPU oracle; gain units, interpolated rate point,
 un-gained-y / clamp quirks included."""
-import numpy as np
 import pytest
 import torch
 

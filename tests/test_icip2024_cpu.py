@@ -3,7 +3,6 @@ from the reference, and the host side of the product path (state_dict schema, GO
 import json
 import os
 
-import numpy as np
 import pytest
 import torch
 

@@ -255,7 +255,6 @@ def test_select_flow_follows_the_reference_comparison(dev):
     """vc_select_flow: first strictly greatest POSITIVE PSNR wins (opt_helpers.py:44-49 starts from best = 0 and
     compares with '>'); ties keep the earlier candidate; when no PSNR is positive (MSE >= 1) candidate 0 is used;
     NaN never wins."""
-    import ctypes
     from vcamd import hip
     L = hip.lib()
     cands = [hip.T.empty(1, 4, 6, 4, dev) for _ in range(5)]

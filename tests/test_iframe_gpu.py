@@ -1,6 +1,5 @@
 """-m gpu: I-frame codec (mbt2018_mean architecture) and the sequence-level GOP loop
 (8(f)-3) on the HIP path against the CPU oracle."""
-import numpy as np
 import pytest
 import torch
 

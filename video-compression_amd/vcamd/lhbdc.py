@@ -18,7 +18,7 @@ import torch.nn as nn
 from . import hip
 from .hip import T
 from .layers import (BitCounter, MeanScaleHyperprior, ResidualBlock, ResidualBlockUpsample, ResidualBlockWithStride,
-                     _Prepared, conv3x3, pack_conv, run_sequential, subpel_conv3x3)
+                     _Prepared, conv3x3, pack_conv, subpel_conv3x3)
 
 
 def _require_cuda(x):
