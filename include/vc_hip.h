@@ -65,7 +65,9 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
        VC_CFG_N128B = 5 /* 128 channels, waves 2x2 (3x3 stride-1 only; same packed weights as N128) */,
        VC_CFG_PW = 6 /* streaming 1x1 stride-1 kernel: weights resident in LDS, activations global -> registers with
                         next-tile prefetch; 32 <= cin <= 128, cout <= 128, plain/ReLU/LeakyReLU epilogue (+ gain,
-                        residual); reads the packed weights of N128/N64/N32 and gives bit-identical results */ };
+                        residual); reads the packed weights of N128/N64/N32 and gives bit-identical results */,
+       VC_CFG_N32T16 = 7 /* 7x7 stride 1: 16-row tiles of 32 channels (22 x 38 input footprint per 16 x 32 outputs
+                        instead of 14 x 38 per 8 x 32); same packed weights as N32, bit-identical results */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
  * same packed weights and produces bit-identical results); without it the library narrows the block for
  * small feature maps by itself. */

@@ -97,6 +97,29 @@ def test_tile_configs_are_bit_identical(dev):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_tile_configs_7x7_including_16_row_tiles(dev, precision):
+    """VC_CFG_N32T16 (16-row tiles) on SPyNet-shaped 7x7 layers: heights that are not a multiple of 16, a batch,
+    ReLU / residual epilogues -- bit-identical to the 8-row configurations on the same packed weights"""
+    from vcamd import hip
+    hip.set_conv_precision(precision)
+    try:
+        pcs = [hip.PackedConv(_rand((co, ci, 7, 7), 70 + co, 0.02), _rand((co,), 71, 0.1), device=dev) for ci, co in ((64, 32), (32, 64))]
+    finally:
+        hip.set_conv_precision("fp32")
+    fl = hip.CFG_F16 if precision == "fp16" else 0
+    for pc in pcs:
+        assert 7 in pc.candidates
+        x = hip.nchw_to_nhwc(_rand((2, pc.cin, 43, 70), 72).to(dev))
+        res = hip.nchw_to_nhwc(_rand((2, pc.cout, 43, 70), 73).to(dev))
+        outs = []
+        for cfg in (pc.cfg, 2, 7):
+            pc.tuned = {(x.n, x.h, x.w, fl): cfg | hip.CFG_EXACT | fl}
+            outs.append((hip.nhwc_to_nchw(pc(x, act=hip.ACT_RELU)), hip.nhwc_to_nchw(pc(x, res=res))))
+        for a, b in outs[1:]:
+            assert torch.equal(outs[0][0], a) and torch.equal(outs[0][1], b)
+
+
 F16_CASES = [(128, 128, 3, 1, 40, 72, "lrelu", False), (128, 512, 3, 1, 17, 30, "lrelu", True), (64, 32, 7, 1, 34, 60, "relu", False),
              (32, 64, 7, 1, 34, 60, "relu", False), (192, 64, 5, 1, 16, 32, "relu", False), (128, 128, 3, 2, 34, 66, "none", False),
              (256, 128, 3, 1, 16, 32, "relu", False), (128, 128, 1, 2, 32, 64, "none", False), (512, 512, 3, 1, 8, 16, "lrelu", False),

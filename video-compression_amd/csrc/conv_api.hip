@@ -11,7 +11,8 @@ static inline int cfg_bn(int cfg)
     case VC_CFG_N128:
     case VC_CFG_N128B: return 128;
     case VC_CFG_N64: return 64;
-    case VC_CFG_N32: return 32;
+    case VC_CFG_N32:
+    case VC_CFG_N32T16: return 32;
     case VC_CFG_N4: return 4;
     default: return 16;
     }
@@ -105,7 +106,7 @@ extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout,
 static inline bool cfg_f16_ok(int cfg, int cin)
 {
     return (cfg == VC_CFG_N128 || cfg == VC_CFG_N64 || cfg == VC_CFG_N32 || cfg == VC_CFG_N128B || cfg == VC_CFG_N16 ||
-            cfg == VC_CFG_PW) && (cin % 8) == 0;
+            cfg == VC_CFG_PW || cfg == VC_CFG_N32T16) && (cin % 8) == 0;
 }
 
 extern "C" size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride)
@@ -192,7 +193,8 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.res_first = (d->cfg & VC_CFG_RES_FIRST) ? 1 : 0;
     if (a.res_first && (!d->res || d->epi != VC_EPI_NONE || d->act == VC_ACT_SIGMOID || d->act == VC_ACT_CLAMP01)) return VC_EINVAL;
     a.cin_pad = round_up(a.Cin, f16 ? 2 * ck : ck);
-    const int th = 8, tw = ((d->cfg & 0xff) == VC_CFG_N4) ? 64 : 32;
+    const int cfg0 = d->cfg & 0xff;
+    const int th = (cfg0 == VC_CFG_N32T16) ? 16 : 8, tw = (cfg0 == VC_CFG_N4) ? 64 : 32;
     a.tiles_x = (a.Wo + tw - 1) / tw;
     a.tiles_y = (a.Ho + th - 1) / th;
     // Small feature maps (hyper-networks, MV codec, coarse pyramid levels): a 128-channel block would

@@ -7,6 +7,7 @@ int VC_DISPATCH(k7)(hipStream_t st, const ConvArgs &a, int stride, int cfg, int 
     if (ck == 8 && cfg == VC_CFG_N32) return launch_conv_p<7, 7, 1, 8, CfgN32>(st, a);
     if (ck != 16) return VC_EINVAL;
     switch (cfg) {
+    case VC_CFG_N32T16: return launch_conv_p<7, 7, 1, 16, CfgN32T16>(st, a);
     case VC_CFG_N128: return launch_conv_p<7, 7, 1, 16, CfgN128>(st, a);
     case VC_CFG_N64: return launch_conv_p<7, 7, 1, 16, CfgN64>(st, a);
     case VC_CFG_N32: return launch_conv_p<7, 7, 1, 16, CfgN32>(st, a);

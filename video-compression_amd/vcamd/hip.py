@@ -312,6 +312,8 @@ class PackedConv:
             self.candidates.append(5)          # VC_CFG_N128B: 128-channel block with the waves arranged 2x2
         if self.candidates and kh == 1 and stride == 1 and not self.ps and 32 <= cin <= 128 and cout <= 128 and cin % 8 == 0:
             self.candidates.append(6)          # VC_CFG_PW: streaming 1x1 kernel (skipped by the tuner when the call is not eligible)
+        if self.candidates and kh == 7 and stride == 1:
+            self.candidates.append(7)          # VC_CFG_N32T16: 16-row tiles (less halo per output)
         # every alternative must read THIS packing: same channel chunk (the zero padding of cin depends on it)
         self.candidates = [c for c in self.candidates if L.vc_conv_chunk(c, kh, stride, cin) == ck]
 
