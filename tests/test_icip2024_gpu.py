@@ -330,3 +330,37 @@ def test_elic_intra_codec_matches_reference_fixture_and_oracle(dev):
         o = prod(xs.to(dev))
     assert abs(psnr(o["x_hat"].cpu(), xs) - psnr(r["x_hat"], xs)) < PSNR_TOL_DB
     assert abs(o["size"].item() - oi._bits(r["likelihoods"]).item()) / o["size"].item() < 2e-3
+
+
+def test_full_size_properties_1080p(dev, models):
+    """At BASELINE's size (1080x1920 padded to 1088x1920), size-independent properties instead of the CPU oracle:
+    a batch of two frames equals the two single passes bit for bit, the device-side flow-resolution search picks
+    what the host loop picks, feeding the searched flow equals recomputing it, and the rate rows add up."""
+    from vcamd import hip, icip2024
+    from vcamd.layers import BitCounter
+    _, prod = models
+    g = torch.Generator().manual_seed(11)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 1088 + 32, 1920 + 32, generator=g), 7, 1, 3)
+    fr = [(base[:, :, 2 * t:2 * t + 1088, 3 * t:3 * t + 1920] + 0.01 * torch.randn(1, 3, 1088, 1920, generator=g)).clamp(0, 1).to(dev)
+          for t in range(5)]
+    with torch.no_grad():
+        a = prod(fr[0], fr[2], 0.5, 0.5, fr[1], 2, 1)
+        b = prod(fr[2], fr[4], 0.5, 0.5, fr[3], 2, 1)
+        bits = BitCounter(dev, max_rows=24)
+        both = prod.forward_device(hip.nchw_to_nhwc(torch.cat([fr[0], fr[2]])), hip.nchw_to_nhwc(torch.cat([fr[2], fr[4]])),
+                                   0.5, 0.5, hip.nchw_to_nhwc(torch.cat([fr[1], fr[3]])), 2, 1, bits)
+        both = hip.nhwc_to_nchw(both)
+        rows = bits.totals().view(12, 2)
+        assert torch.equal(both[0:1], a["x_hat"]) and torch.equal(both[1:2], b["x_hat"])
+        assert abs(rows[:, 0].sum().item() - a["size"].item()) / a["size"].item() < 1e-6
+        assert abs((a["size_offset"] + a["size_residual"]).item() - a["size"].item()) / a["size"].item() < 1e-6
+        assert abs(a["rate"].item() - a["size"].item() / (1088 * 1920)) / a["rate"].item() < 1e-6
+        best_host, _ = icip2024.get_best_down_ratio_prediction(prod, fr[0], fr[2], 0.5, 0.5, fr[1])
+        t0, t1, t2 = (hip.nchw_to_nhwc(x) for x in (fr[0], fr[1], fr[2]))
+        flow, choice, _ = prod.search_flow_t(t1, t0, t2, 0.5, 0.5)
+        assert (1, 2, 4, 8, 16)[int(choice.item())] == best_host
+        bits2 = BitCounter(dev, max_rows=12)
+        again = hip.nhwc_to_nchw(prod.forward_device(t0, t2, 0.5, 0.5, t1, 2, None, bits2, flow=flow))
+        ref = prod(fr[0], fr[2], 0.5, 0.5, fr[1], 2, best_host)
+        assert torch.equal(again, ref["x_hat"])
+    assert torch.isfinite(a["x_hat"]).all() and a["size"].item() > 0
