@@ -468,3 +468,34 @@ def test_warp_feature_maps_vectorised(dev, convention):
     hip.warp(convention, wide.channels(8, 32), hip.nchw_to_nhwc(flow.to(dev)), out=dst.channels(12, 36))
     out = hip.nhwc_to_nchw(dst.channels(12, 36))
     _close(out, ref, 2e-5, f"vectorised warp W{convention}")
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_on_streaming_kernel_is_bit_identical(dev, inverse):
+    """GDN / IGDN (128 channels) through VC_CFG_PW: the x^2 contraction reads x once and multiplies the very registers
+    it squared -- must equal the general kernel bit for bit (with and without the residual add) and the oracle GDN."""
+    from oracle.cai.layers import GDN as OracleGDN
+    from vcamd import hip
+    from vcamd.layers import GDN
+    from vcamd.seeding import seeded_state_dict
+    ora = OracleGDN(128, inverse=inverse)
+    sd = seeded_state_dict(ora.state_dict(), seed=77)
+    ora.load_state_dict(sd)
+    g = GDN(128, inverse=inverse)
+    g.load_state_dict(sd)
+    g = g.to(dev)
+    x = _rand((2, 128, 37, 50), 78, 2.0)
+    res = _rand((2, 128, 37, 50), 79)
+    xt, rt = hip.nchw_to_nhwc(x.to(dev)), hip.nchw_to_nhwc(res.to(dev))
+    g.run(xt)                                            # packs
+    pc = g._packed
+    assert 6 in pc.candidates
+    outs = []
+    for cfg in (pc.cfg, 6):
+        pc.tuned = {(2, 37, 50, 0): cfg | hip.CFG_EXACT}
+        outs.append((hip.nhwc_to_nchw(g.run(xt)), hip.nhwc_to_nchw(g.run(xt, res=rt))))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    with torch.no_grad():
+        ref = ora(x)
+    _close(outs[1][0], ref, 3e-5, "GDN on the streaming kernel vs oracle")
+    _close(outs[1][1], ref + res, 3e-5, "GDN + residual")

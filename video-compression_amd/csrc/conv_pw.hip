@@ -23,9 +23,13 @@ template <int KQ, bool F16, bool INH> struct PwRaw {
     f32x4 v[KQ * PER_STEP];
 };
 
-template <int KQ, int NT, bool F16, bool INH>
+// EPI: 0 = plain, 1 = GDN, 2 = IGDN (fp32, cin == cout): the layer contracts x^2 and multiplies x by rsqrt / sqrt of the
+// result.  Both the B-operand layout and the accumulator layout give lane half h the channels 8q + 4h + e, so the x a
+// lane needs in the epilogue is the very register it squared for k-step q = 4t + g -- no second read of the input.
+template <int KQ, int NT, bool F16, bool INH, int EPI = 0>
 __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
 {
+    static_assert(EPI == 0 || (!F16 && KQ == 4 * NT), "GDN needs fp32 and cin == cout");
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [NT][KQ][64 lanes][4] weights | bias[NT*32]
     constexpr int KCH = F16 ? 16 : 8;                              // input channels per k-step
     const int kst_total = p.cin_pad / KCH;
@@ -121,7 +125,10 @@ __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
                                                                     acc[t], 0, 0, 0);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[e], cur[q][e], acc[t], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        const float b = EPI ? cur[q][e] * cur[q][e] : cur[q][e];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[e], b, acc[t], 0, 0, 0);
+                    }
                 }
             }
 
@@ -138,6 +145,11 @@ __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
                     const int co = t * 32 + 8 * g + 4 * h;
                     if (co < p.Cout) {
                         f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                        if constexpr (EPI != 0) {       // IEEE sqrt and divide, like the general kernel
+                            const f32x4 xin = cur[(4 * t + g) < KQ ? 4 * t + g : 0];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = (EPI == 1) ? xin[e] * (1.0f / sqrtf(v[e])) : xin[e] * sqrtf(v[e]);
+                        }
                         if (p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_pix + co);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
@@ -155,10 +167,10 @@ __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
     }
 }
 
-template <int KQ, int NT, bool F16, bool INH> int launch_pw(hipStream_t st, const ConvArgs &a)
+template <int KQ, int NT, bool F16, bool INH, int EPI = 0> int launch_pw(hipStream_t st, const ConvArgs &a)
 {
     const size_t lds_bytes = (size_t)(NT * KQ * 256 + NT * 32) * sizeof(float);
-    auto kern = conv_pw_kernel<KQ, NT, F16, INH>;
+    auto kern = conv_pw_kernel<KQ, NT, F16, INH, EPI>;
     if (lds_bytes > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
@@ -213,7 +225,12 @@ template <bool F16, bool INH> int by_kq(hipStream_t st, const ConvArgs &a)
 
 bool conv_pw_eligible(const ConvArgs &a, int k, int stride, bool f16)
 {
-    if (k != 1 || stride != 1 || a.epi != VC_EPI_NONE || a.in_xform != VC_IN_NONE || a.out_mode != VC_OUT_PLAIN) return false;
+    if (k != 1 || stride != 1 || a.out_mode != VC_OUT_PLAIN) return false;
+    if (a.epi != VC_EPI_NONE) {   // GDN / IGDN: x^2 contraction whose multiplier is the layer's own input, 128 channels, fp32
+        return !f16 && a.in_xform == VC_IN_SQUARE && a.act == VC_ACT_NONE && a.Cin == 128 && a.Cout == 128 && a.vec4 && a.vec_out &&
+               a.mul == a.in && a.mul_sn == a.in_sn && a.mul_sh == a.in_sh && a.mul_sw == a.in_sw && !a.res_first;
+    }
+    if (a.in_xform != VC_IN_NONE) return false;
     if (a.act != VC_ACT_NONE && a.act != VC_ACT_RELU && a.act != VC_ACT_LRELU) return false;
     if (!a.vec4 || !a.vec_out || (a.Cout % 4) || a.Cout > 128 || a.Cin > 128 || a.Cin < 32) return false;
     const int kch = f16 ? 16 : 8;
@@ -224,6 +241,8 @@ bool conv_pw_eligible(const ConvArgs &a, int k, int stride, bool f16)
 
 int conv_dispatch_pw(hipStream_t st, const ConvArgs &a, bool f16)
 {
+    if (a.epi == VC_EPI_GDN) return launch_pw<16, 4, false, false, 1>(st, a);
+    if (a.epi == VC_EPI_IGDN) return launch_pw<16, 4, false, false, 2>(st, a);
     if (!f16) return by_kq<false, false>(st, a);
     return a.in_f16 ? by_kq<true, true>(st, a) : by_kq<true, false>(st, a);
 }
