@@ -103,9 +103,16 @@ def test_gop16_graph_replay_equals_eager(dev, models):
     frames = [base[..., :128, i:i + 192].contiguous().to(dev) for i in range(17)]
     quality = vgop.FLEX_QUALITIES[3]
     with torch.no_grad():
+        rec_s = []
+        dec_s = vgop.code_gop_flex(prod, frames, frames[0], frames[16], 120, 180, quality, rec_s, batch_levels=False)
+        dec_s = {k: v.clone() for k, v in dec_s.items()}
         rec_e = []
         dec_e = vgop.code_gop_flex(prod, frames, frames[0], frames[16], 120, 180, quality, rec_e)
         dec_e = {k: v.clone() for k, v in dec_e.items()}
+        for k in range(1, 16):             # level-batched passes == frame-by-frame passes, bit for bit
+            assert torch.equal(dec_s[k], dec_e[k]), k
+        for a, b in zip(rec_s, rec_e):
+            assert a[:3] == b[:3] and float(a[3]) == float(b[3]) and float(a[4]) == float(b[4])
         runner = vgop.GopGraph(prod, 120, 180, kind="flex", quality=quality)
         rec_g = []
         runner.code(frames, records=rec_g)

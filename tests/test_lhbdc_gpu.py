@@ -145,6 +145,36 @@ def test_gop_graph_replay_equals_eager(dev, models):
     assert s["frames"] == 7 and s["bpp"] > 0
 
 
+def test_gops_batched_together_equal_gops_coded_alone(dev, models):
+    """code_gops_lhbdc / GopGraph(gops=2): two independent GOPs with their level passes batched == each GOP alone."""
+    from vcamd import gop as vgop
+    _, prod = models
+    g = torch.Generator().manual_seed(19)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 200, 300, generator=g), 9, 1)
+    gops = [[base[..., :192, 2 * i + off:2 * i + off + 256].contiguous().to(dev) for i in range(9)] for off in (0, 17)]
+    with torch.no_grad():
+        alone, recs_alone = [], []
+        for k, gp in enumerate(gops):
+            alone.append({o: v.clone() for o, v in vgop.code_gop_lhbdc(prod, gp, gp[0], gp[8], 180, 250, recs_alone, gop_index=5 + k).items()})
+        recs_b = []
+        both = vgop.code_gops_lhbdc(prod, gops, [(gp[0], gp[8]) for gp in gops], 180, 250, recs_b, first_gop_index=5)
+        for k in range(2):
+            for o in range(1, 8):
+                assert torch.equal(alone[k][o], both[k][o]), (k, o)
+        for a, b in zip(recs_alone, recs_b):
+            assert a[:3] == b[:3] and float(a[3]) == float(b[3]) and float(a[4]) == float(b[4])
+        runner = vgop.GopGraph(prod, 180, 250, gops=2)
+        flat = gops[0] + gops[1]
+        runner.code(flat)
+        recs_g = []
+        dec_g = runner.code(flat, gop_index=5, records=recs_g)
+    for k in range(2):
+        for o in range(1, 8):
+            assert torch.equal(alone[k][o], dec_g[k][o])
+    assert [r[1] for r in recs_g] == [r[1] for r in recs_alone]
+    assert all(float(a[4]) == float(b[4]) for a, b in zip(recs_alone, recs_g))
+
+
 def test_rejects_unpadded_or_mismatched_frames(dev, models):
     from vcamd import hip
     _, prod = models

@@ -251,19 +251,19 @@ class BidirFlowRef(nn.Module):
                 hip.nhwc_to_nchw(buf.channels(0, 16)))
 
     def forward_device(self, x_before, x_current, x_after, n=None, l=1):
-        """Batch-1 B-frame path with no host synchronisation (graph-capturable): (x_hat, bits[4] float64
-        device tensor = flow.y, flow.z, res.y, res.z)."""
+        """B-frame path with no host synchronisation (graph-capturable): (x_hat, bits[B,4] float64 device tensor =
+        flow.y, flow.z, res.y, res.z per frame).  A batch codes B independent frames at the SAME rate point (n, l) --
+        the frames of one hierarchy level of a GOP (gop.code_gop_flex)."""
         _require_frames(x_before, x_current, x_after)
-        if x_current.shape[0] != 1:
-            raise hip.VcError("forward_device codes one frame at a time")
         xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
-        dev = xc_.device
+        dev, b = xc_.device, xc_.shape[0]
         buf = self._process_t(xb_, xa_, xc_)
-        bits = BitCounter(dev)
+        bits = BitCounter(dev, max_rows=4 * b)
         flow_hat = self.flow_compressor.forward_t(buf, bits, self.flow_compressor.gains(n, l))
         pred, resid = self._compensate_t(buf, flow_hat, cur=buf.channels(16, 19))
         res_hat = self.residual_compressor.forward_t(resid, bits, self.residual_compressor.gains(n, l))
-        return hip.nhwc_to_nchw(hip.axpby(pred, res_hat)), bits.totals().view(1, 4)
+        # rows: flow (y, z) per image, then residual (y, z) per image
+        return hip.nhwc_to_nchw(hip.axpby(pred, res_hat)), bits.totals().view(2, b, 2).permute(1, 0, 2).reshape(b, 4)
 
     def forward(self, x_before, x_current, x_after, n=None, l=1, train=False):
         if train:

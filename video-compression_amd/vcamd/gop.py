@@ -68,19 +68,57 @@ def code_gop_lhbdc(model, gop, dec_first, dec_last, h, w, records=None, video=0,
     return decoded
 
 
-def code_gop_flex(model, gop, dec_first, dec_last, h, w, quality, records=None, video=0, gop_index=0):
+def code_gops_lhbdc(model, gops, bounds, h, w, records=None, video=0, first_gop_index=0):
+    """Several independent GOP-8s in one go: GOPs share nothing but the model, so hierarchy level l of ALL of them runs
+    as one batched pass (G, 2G, 4G frames) -- the same per-frame arithmetic as :func:`code_gop_lhbdc`, with the
+    single-frame level {4} and the coarse layers getting G times more work per launch.  ``gops``: list of G lists of 9
+    padded NCHW frames; ``bounds``: per GOP its (decoded first, decoded last) boundary frames.  Records are appended
+    GOP by GOP in the reference's coding order; returns the list of decoded dicts."""
+    decoded = [{0: b[0], 8: b[1]} for b in bounds]
+    stats = [{} for _ in gops]
+    for group in LEVEL_GROUPS:
+        xb = torch.cat([decoded[g][DECODING_INFO[o][0]] for g in range(len(gops)) for o in group], 0)
+        xc = torch.cat([gops[g][o] for g in range(len(gops)) for o in group], 0)
+        xa = torch.cat([decoded[g][DECODING_INFO[o][1]] for g in range(len(gops)) for o in group], 0)
+        x_hat, tot = model.forward_device(xb, xc, xa)
+        i = 0
+        for g in range(len(gops)):
+            for o in group:
+                decoded[g][o] = x_hat[i:i + 1]
+                stats[g][o] = tot[i].sum()
+                i += 1
+    if records is not None:
+        for g in range(len(gops)):
+            for order in CODING_ORDER[2:]:
+                records.append((video, (first_gop_index + g) * 8 + order, HIER_LEVELS[order],
+                                psnr_uint8(decoded[g][order], gops[g][order], h, w), stats[g][order], float(h * w)))
+    return decoded
+
+
+LEVEL_GROUPS_16 = [[8], [4, 12], [2, 6, 10, 14], [1, 3, 5, 7, 9, 11, 13, 15]]
+
+
+def code_gop_flex(model, gop, dec_first, dec_last, h, w, quality, records=None, video=0, gop_index=0, batch_levels=True):
     """Code the 15 B-frames of one GOP-16 with the per-hierarchy-level (n, l) of ``quality`` (an entry of
-    FLEX_QUALITIES or a plain {level: (n, l)} dict), like Flex-Rate.../test/testing.py:192-201."""
+    FLEX_QUALITIES or a plain {level: (n, l)} dict), like Flex-Rate.../test/testing.py:192-201.
+    ``batch_levels``: the frames of one hierarchy level share their rate point and depend only on lower levels, so
+    each level runs as one batched pass (1, 2, 4, 8 frames) with identical per-frame arithmetic."""
     table = quality[1] if isinstance(quality, tuple) else quality
-    decoded = {0: dec_first, 16: dec_last}
-    for order in CODING_ORDER_16[2:]:
-        r0, r1 = DECODING_INFO_16[order]
-        n, l = table[HIER_LEVELS_16[order]]
-        x_hat, tot = model.forward_device(decoded[r0], gop[order], decoded[r1], n=[n], l=l)
-        decoded[order] = x_hat
-        if records is not None:
-            records.append((video, gop_index * 16 + order, HIER_LEVELS_16[order], psnr_uint8(x_hat, gop[order], h, w),
-                            tot.sum(), float(h * w)))
+    decoded, stats = {0: dec_first, 16: dec_last}, {}
+    groups = LEVEL_GROUPS_16 if batch_levels else [[o] for o in CODING_ORDER_16[2:]]
+    for group in groups:
+        n, l = table[HIER_LEVELS_16[group[0]]]
+        xb = torch.cat([decoded[DECODING_INFO_16[o][0]] for o in group], 0)
+        xc = torch.cat([gop[o] for o in group], 0)
+        xa = torch.cat([decoded[DECODING_INFO_16[o][1]] for o in group], 0)
+        x_hat, tot = model.forward_device(xb, xc, xa, n=[n], l=l)
+        for i, o in enumerate(group):
+            decoded[o] = x_hat[i:i + 1]
+            stats[o] = tot[i].sum()
+    if records is not None:
+        for order in CODING_ORDER_16[2:]:
+            records.append((video, gop_index * 16 + order, HIER_LEVELS_16[order], psnr_uint8(decoded[order], gop[order], h, w),
+                            stats[order], float(h * w)))
     return decoded
 
 
@@ -197,12 +235,16 @@ class GopGraph:
     (7 B-frames for LHBDC GOP-8, 15 for Flex GOP-16) captures into one graph: static input slots for the
     frames, intermediates in the graph's private pool, per-frame PSNR/bits left in static device tensors."""
 
-    def __init__(self, model, h, w, video=0, kind="lhbdc", quality=None, pool=None):
+    def __init__(self, model, h, w, video=0, kind="lhbdc", quality=None, pool=None, gops=1):
         """``pool``: a torch.cuda.graph_pool_handle() shared by several GopGraphs that are replayed one after the
         other (e.g. one per quality level): their intermediates then reuse the same memory, and the tensors a
-        replay returns are only valid until the next replay of ANY graph of the pool."""
+        replay returns are only valid until the next replay of ANY graph of the pool.
+        ``gops`` (LHBDC only): number of consecutive GOPs coded per replay with their level passes batched together
+        (:func:`code_gops_lhbdc`); ``code`` then takes the 9*gops frames of those GOPs in order."""
         self.model, self.h, self.w, self.video, self.kind, self.quality = model, h, w, video, kind, quality
-        self.pool = pool
+        self.pool, self.gops = pool, int(gops)
+        if self.gops != 1 and kind != "lhbdc":
+            raise ValueError("multi-GOP graphs exist for the LHBDC coder only")
         self.orders = {"lhbdc": CODING_ORDER[2:], "flex": CODING_ORDER_16[2:], "icip2024": ICIP_ORDER_16[1:]}[kind]
         self.levels = {"lhbdc": HIER_LEVELS, "flex": HIER_LEVELS_16, "icip2024": ICIP_LEVELS_16}[kind]
         self.span = 8 if kind == "lhbdc" else 16
@@ -213,7 +255,10 @@ class GopGraph:
 
     def _run(self, frames):
         recs = []
-        if self.kind == "lhbdc":
+        if self.kind == "lhbdc" and self.gops > 1:
+            gops = [frames[9 * g:9 * g + 9] for g in range(self.gops)]
+            dec = code_gops_lhbdc(self.model, gops, [(gp[0], gp[8]) for gp in gops], self.h, self.w, recs, self.video, 0)
+        elif self.kind == "lhbdc":
             dec = code_gop_lhbdc(self.model, frames, frames[0], frames[8], self.h, self.w, recs, self.video, 0)
         elif self.kind == "icip2024":       # quality = level; flow-resolution search on the device
             dec, _ = code_gop_icip2024(self.model, frames, frames[0], frames[16], self.h, self.w, self.quality, recs,
@@ -240,9 +285,11 @@ class GopGraph:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         self.graph.replay()
-        if records is not None:
-            for i, order in enumerate(self.orders):
-                records.append((self.video, gop_index * self.span + order, self.levels[order], self.out_psnr[i].clone(),
+        if records is not None:     # (with gops > 1, gop_index is the index of the FIRST GOP of the replay)
+            for i in range(len(self.orders) * self.gops):
+                g, order = divmod(i, len(self.orders))
+                order = self.orders[order]
+                records.append((self.video, (gop_index + g) * self.span + order, self.levels[order], self.out_psnr[i].clone(),
                                 self.out_bits[i].clone(), float(self.h * self.w)))
         return self.decoded
 
