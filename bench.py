@@ -90,8 +90,8 @@ def main():
     ap.add_argument("--resolution", choices=["1080p", "2160p"], default="1080p")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gops-per-step", type=int, default=None,
-                    help="LHBDC only: independent GOPs coded per step and GPU with their hierarchy levels batched together "
-                         "(default 4 at 1080p, 1 at 2160p)")
+                    help="LHBDC / Flex-Rate: independent GOPs coded per step and GPU with their hierarchy levels batched together "
+                         "(default at 1080p: 4 / 2; 1 at 2160p)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel event timing table here (json)")
     args = ap.parse_args()
@@ -130,7 +130,7 @@ def main():
     per_gop = 15 if (is_flex or is_icip) else 7
     # GOPs per step and GPU (LHBDC): 4 at 1080p (+2.5 % over one: the single-frame level and the coarse layers get 4x
     # the work per launch), 1 at 2160p where a level pass is already four 1080p frames' worth of pixels
-    G = (args.gops_per_step or (4 if args.resolution == "1080p" else 1)) if not (is_flex or is_icip) else 1
+    G = 1 if is_icip else (args.gops_per_step or ((2 if is_flex else 4) if args.resolution == "1080p" else 1))
 
     # every rank codes its own GOP (GOP index = rank): weak scaling, per-GPU work fixed
     frames = []
@@ -150,7 +150,7 @@ def main():
         runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="icip2024", quality=lvl, pool=pool)
                    for lvl in range(5)]
     elif is_flex:
-        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="flex", quality=q) for q in rate_points]
+        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="flex", quality=q, gops=G) for q in rate_points]
     else:
         runners = [None if args.no_graph else vgop.GopGraph(model, H, W, gops=G)]
     counter = [0]
@@ -164,7 +164,9 @@ def main():
         elif is_icip:
             vgop.code_gop_icip2024(model, frames, frames[0], frames[16], H, W, i, recs, video=0, gop_index=rank)
         elif is_flex:
-            vgop.code_gop_flex(model, frames, frames[0], frames[16], H, W, rate_points[i], recs, video=0, gop_index=rank)
+            gops = [frames[17 * g:17 * g + 17] for g in range(G)]
+            vgop.code_gops_flex(model, gops, [(gp[0], gp[16]) for gp in gops], H, W, rate_points[i], recs, video=0,
+                                first_gop_index=rank * G)
         else:
             gops = [frames[9 * g:9 * g + 9] for g in range(G)]
             vgop.code_gops_lhbdc(model, gops, [(gp[0], gp[8]) for gp in gops], H, W, recs, video=0, first_gop_index=rank * G)
@@ -206,7 +208,7 @@ def main():
         "config": {"workload": (f"ICIP2024 FlowGuidedB {args.resolution} GOP-16: 15 B-frames per GOP via FlowGuidedB.forward with the "
                                 "per-frame flow-resolution search (5 flow+warp passes), quality level s=step%5, one GOP per GPU per step"
                                 if is_icip else f"Flex-Rate b_model {args.resolution} GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
-                                "n=step%4 through the gain units, one GOP per GPU per step" if is_flex else
+                                f"n=step%4 through the gain units, {G} independent GOP(s) per GPU per step, hierarchy levels batched" if is_flex else
                                 f"LHBDC {args.resolution} GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
                                 f"{G} independent GOP(s) per GPU per step, hierarchy levels batched across them"),
                    "frames_per_step_per_gpu": per_gop * G, "gop": 16 if (is_flex or is_icip) else 8,

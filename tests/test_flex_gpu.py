@@ -122,3 +122,29 @@ def test_gop16_graph_replay_equals_eager(dev, models):
         assert torch.equal(dec_e[k], dec_g[k]), k
     for a, b in zip(rec_e, rec_g):
         assert a[:3] == b[:3] and float(a[3]) == float(b[3]) and float(a[4]) == float(b[4])
+
+
+def test_gops_batched_together_equal_gops_coded_alone(dev, models):
+    """code_gops_flex / GopGraph(kind="flex", gops=2): two independent GOP-16s with batched level passes == each alone."""
+    from vcamd import gop as vgop
+    _, prod = models
+    g = torch.Generator().manual_seed(23)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 136, 240, generator=g), 9, 1)
+    gops = [[base[..., :128, i + off:i + off + 192].contiguous().to(dev) for i in range(17)] for off in (0, 21)]
+    quality = vgop.FLEX_QUALITIES[5]
+    with torch.no_grad():
+        alone, recs_alone = [], []
+        for k, gp in enumerate(gops):
+            d = vgop.code_gop_flex(prod, gp, gp[0], gp[16], 120, 180, quality, recs_alone, gop_index=3 + k)
+            alone.append({o: v.clone() for o, v in d.items()})
+        recs_b = []
+        both = vgop.code_gops_flex(prod, gops, [(gp[0], gp[16]) for gp in gops], 120, 180, quality, recs_b, first_gop_index=3)
+        for k in range(2):
+            for o in range(1, 16):
+                assert torch.equal(alone[k][o], both[k][o]), (k, o)
+        runner = vgop.GopGraph(prod, 120, 180, kind="flex", quality=quality, gops=2)
+        runner.code(gops[0] + gops[1])
+        recs_g = []
+        runner.code(gops[0] + gops[1], gop_index=3, records=recs_g)
+    assert [r[:3] for r in recs_alone] == [r[:3] for r in recs_b] == [r[:3] for r in recs_g]
+    assert all(float(a[4]) == float(b[4]) == float(c[4]) for a, b, c in zip(recs_alone, recs_b, recs_g))

@@ -98,28 +98,40 @@ def code_gops_lhbdc(model, gops, bounds, h, w, records=None, video=0, first_gop_
 LEVEL_GROUPS_16 = [[8], [4, 12], [2, 6, 10, 14], [1, 3, 5, 7, 9, 11, 13, 15]]
 
 
-def code_gop_flex(model, gop, dec_first, dec_last, h, w, quality, records=None, video=0, gop_index=0, batch_levels=True):
-    """Code the 15 B-frames of one GOP-16 with the per-hierarchy-level (n, l) of ``quality`` (an entry of
-    FLEX_QUALITIES or a plain {level: (n, l)} dict), like Flex-Rate.../test/testing.py:192-201.
-    ``batch_levels``: the frames of one hierarchy level share their rate point and depend only on lower levels, so
-    each level runs as one batched pass (1, 2, 4, 8 frames) with identical per-frame arithmetic."""
+def code_gops_flex(model, gops, bounds, h, w, quality, records=None, video=0, first_gop_index=0, batch_levels=True):
+    """The 15 B-frames of each of several independent GOP-16s with the per-hierarchy-level (n, l) of ``quality`` (an entry
+    of FLEX_QUALITIES or a plain {level: (n, l)} dict), like Flex-Rate.../test/testing.py:192-201.
+    ``batch_levels``: the frames of one hierarchy level share their rate point and depend only on lower levels, so each
+    level -- of ALL the GOPs given -- runs as one batched pass with identical per-frame arithmetic.
+    ``gops``: list of lists of 17 padded NCHW frames; ``bounds``: per GOP (decoded first, decoded last)."""
     table = quality[1] if isinstance(quality, tuple) else quality
-    decoded, stats = {0: dec_first, 16: dec_last}, {}
+    decoded = [{0: b[0], 16: b[1]} for b in bounds]
+    stats = [{} for _ in gops]
     groups = LEVEL_GROUPS_16 if batch_levels else [[o] for o in CODING_ORDER_16[2:]]
+    ng = range(len(gops))
     for group in groups:
         n, l = table[HIER_LEVELS_16[group[0]]]
-        xb = torch.cat([decoded[DECODING_INFO_16[o][0]] for o in group], 0)
-        xc = torch.cat([gop[o] for o in group], 0)
-        xa = torch.cat([decoded[DECODING_INFO_16[o][1]] for o in group], 0)
+        xb = torch.cat([decoded[g][DECODING_INFO_16[o][0]] for g in ng for o in group], 0)
+        xc = torch.cat([gops[g][o] for g in ng for o in group], 0)
+        xa = torch.cat([decoded[g][DECODING_INFO_16[o][1]] for g in ng for o in group], 0)
         x_hat, tot = model.forward_device(xb, xc, xa, n=[n], l=l)
-        for i, o in enumerate(group):
-            decoded[o] = x_hat[i:i + 1]
-            stats[o] = tot[i].sum()
+        i = 0
+        for g in ng:
+            for o in group:
+                decoded[g][o] = x_hat[i:i + 1]
+                stats[g][o] = tot[i].sum()
+                i += 1
     if records is not None:
-        for order in CODING_ORDER_16[2:]:
-            records.append((video, gop_index * 16 + order, HIER_LEVELS_16[order], psnr_uint8(decoded[order], gop[order], h, w),
-                            stats[order], float(h * w)))
+        for g in ng:
+            for order in CODING_ORDER_16[2:]:
+                records.append((video, (first_gop_index + g) * 16 + order, HIER_LEVELS_16[order],
+                                psnr_uint8(decoded[g][order], gops[g][order], h, w), stats[g][order], float(h * w)))
     return decoded
+
+
+def code_gop_flex(model, gop, dec_first, dec_last, h, w, quality, records=None, video=0, gop_index=0, batch_levels=True):
+    """One GOP-16 (see :func:`code_gops_flex`); returns its decoded dict."""
+    return code_gops_flex(model, [gop], [(dec_first, dec_last)], h, w, quality, records, video, gop_index, batch_levels)[0]
 
 
 # ICIP2024 GOP-16 (ICIP2024/src/utils.py:188-221, src/test.py:37-101): frame 16 is intra-coded first, then the
@@ -239,12 +251,12 @@ class GopGraph:
         """``pool``: a torch.cuda.graph_pool_handle() shared by several GopGraphs that are replayed one after the
         other (e.g. one per quality level): their intermediates then reuse the same memory, and the tensors a
         replay returns are only valid until the next replay of ANY graph of the pool.
-        ``gops`` (LHBDC only): number of consecutive GOPs coded per replay with their level passes batched together
-        (:func:`code_gops_lhbdc`); ``code`` then takes the 9*gops frames of those GOPs in order."""
+        ``gops`` (LHBDC, Flex-Rate): number of consecutive GOPs coded per replay with their level passes batched together
+        (:func:`code_gops_lhbdc`, :func:`code_gops_flex`); ``code`` then takes the frames of those GOPs in order."""
         self.model, self.h, self.w, self.video, self.kind, self.quality = model, h, w, video, kind, quality
         self.pool, self.gops = pool, int(gops)
-        if self.gops != 1 and kind != "lhbdc":
-            raise ValueError("multi-GOP graphs exist for the LHBDC coder only")
+        if self.gops != 1 and kind == "icip2024":
+            raise ValueError("multi-GOP graphs exist for the LHBDC and Flex-Rate coders")
         self.orders = {"lhbdc": CODING_ORDER[2:], "flex": CODING_ORDER_16[2:], "icip2024": ICIP_ORDER_16[1:]}[kind]
         self.levels = {"lhbdc": HIER_LEVELS, "flex": HIER_LEVELS_16, "icip2024": ICIP_LEVELS_16}[kind]
         self.span = 8 if kind == "lhbdc" else 16
@@ -263,6 +275,9 @@ class GopGraph:
         elif self.kind == "icip2024":       # quality = level; flow-resolution search on the device
             dec, _ = code_gop_icip2024(self.model, frames, frames[0], frames[16], self.h, self.w, self.quality, recs,
                                        self.video, 0, search="device")
+        elif self.gops > 1:
+            gops = [frames[17 * g:17 * g + 17] for g in range(self.gops)]
+            dec = code_gops_flex(self.model, gops, [(gp[0], gp[16]) for gp in gops], self.h, self.w, self.quality, recs, self.video, 0)
         else:
             dec = code_gop_flex(self.model, frames, frames[0], frames[16], self.h, self.w, self.quality, recs, self.video, 0)
         psnr = torch.stack([r[3] for r in recs])
