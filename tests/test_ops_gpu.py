@@ -492,8 +492,9 @@ def test_gdn_on_streaming_kernel_is_bit_identical(dev, inverse):
     assert 6 in pc.candidates
     outs = []
     for cfg in (pc.cfg, 6):
-        pc.tuned = {(2, 37, 50, 0): cfg | hip.CFG_EXACT}
+        pc.tuned = {(2, 37, 50, 0, hip.ACT_NONE, hip.EPI_IGDN if inverse else hip.EPI_GDN): cfg | hip.CFG_EXACT}
         outs.append((hip.nhwc_to_nchw(g.run(xt)), hip.nhwc_to_nchw(g.run(xt, res=rt))))
+        assert len(pc.tuned) == 1                       # the forced entry was the one used
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     with torch.no_grad():
         ref = ora(x)

@@ -388,7 +388,10 @@ class PackedConv:
         if use16:
             d.wpk = self.wpk16.data_ptr()
             flags |= CFG_F16 | (CFG_IN_F16 if half_in else 0) | (CFG_OUT_F16 if half_out else 0)
-        d.cfg = self._pick_cfg(d, (x.n, x.h, x.w, flags), flags)
+        # (the tuned choice is per shape AND per epilogue class: the streaming 1x1 kernel, for one, takes plain / ReLU /
+        #  GDN epilogues but not sigmoid or clamp, so a layer called both ways must not share one entry)
+        key = (x.n, x.h, x.w, flags) if (act < ACT_SIGMOID and epi == EPI_NONE) else (x.n, x.h, x.w, flags, act, epi)
+        d.cfg = self._pick_cfg(d, key, flags)
         what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})"
         if timer is None:
             check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
