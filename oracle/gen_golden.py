@@ -346,6 +346,34 @@ def gen_icip2024(outdir, frames, seed):
     np.savez_compressed(os.path.join(outdir, "icip2024_elic_a.npz"), seed=np.int64(seed + 1), conv_gain=np.float64(0.7),
                         current=c["current"], x_hat=dec_r.numpy(), size=np.float64(size_r.item()))
 
+    # the sequence loop itself (src/test.py:37-101) on a short synthetic clip: 20 frames = one full GOP-16 + an irregular
+    # tail; PNG decoding (prepare_frame) is replaced by in-memory frames, hydra/omegaconf (CLI only) are stubbed
+    for name in ("omegaconf", "hydra"):
+        stub = types.ModuleType(name)
+        stub.DictConfig = dict
+        sys.modules.setdefault(name, stub)
+    sys.path.insert(0, os.path.join(REF, "ICIP2024"))
+    from src import test as ref_test  # noqa
+    from_reference(ref_test)
+    sys.path.pop(0)
+    gen = torch.Generator().manual_seed(2024)
+    base = F.avg_pool2d(torch.rand(1, 3, 128 + 40, 192 + 60, generator=gen), 5, 1, 2)
+    clip = [(base[:, :, t:t + 128, (3 * t) // 2:(3 * t) // 2 + 192] + 0.01 * torch.randn(1, 3, 128, 192, generator=gen)).clamp(0, 1)
+            for t in range(20)]
+    clip = [torch.round(f * 255.0) / 255.0 for f in clip]            # what an 8-bit PNG would hold
+    ref_test.prepare_frame = lambda idx, p: clip[idx][0]
+    order_list, typ_list = ref_utils.get_order_typ_list(16, len(clip))
+    betas = torch.tensor([0.0056, 0.0107, 0.0207, 0.0400, 0.0772]) * (255 ** 2)
+    _, psnr_r, size_r = ref_test.val_sequence_level(list(range(len(clip))), [ref_i] * 5, ref, betas, torch.device("cpu"),
+                                                     order_list, typ_list, 1)
+    psnr_o, size_o = oicip.val_sequence_level(clip, [ora_i] * 5, ora, order_list, typ_list, 1)
+    check("val_sequence_level psnr", torch.tensor(psnr_o), torch.tensor(psnr_r))
+    check("val_sequence_level size", torch.tensor(size_o), torch.tensor(size_r))
+    np.savez_compressed(os.path.join(outdir, "icip2024_sequence_a.npz"), clip_seed=np.int64(2024),
+                        clip_u8=np.stack([(f[0] * 255.0).round().to(torch.uint8).numpy() for f in clip]),
+                        order=np.array(order_list, dtype=np.int64), typ="".join(typ_list), level=np.int64(1),
+                        psnr=np.array(psnr_r, dtype=np.float64), size=np.array(size_r, dtype=np.float64))
+
     book = {"order_typ": {}, "refs": {}}
     for n_frames in (17, 33, 40, 300, 600):
         o_r, t_r = ref_utils.get_order_typ_list(16, n_frames)

@@ -445,3 +445,31 @@ def get_order_typ_list(intra_size, frame_number):
     if frame_number == 600:
         o[-7:] = [599, 595, 593, 597, 594, 596, 598]
     return o, typ
+
+
+def val_sequence_level(frames, im_models, model, order_list, typ_list, level, h=1080, w=1920):
+    """src/test.py:37-101 on in-memory frames (list of [1,3,H,W] tensors, already padded): I-frames through
+    image_compress, B-frames through the flow-resolution search + FlowGuidedB.forward, references = the two buffered
+    decoded frames (clamped to [0,1]) closest in display order.  Returns (psnr_list, size_list) indexed by display
+    order; PSNR on uint8-rounded [:h,:w] crops, sizes in bits / (h*w) with the reference's hard-coded 1080x1920."""
+    psnr_list = [0.0] * len(frames)
+    size_list = [0.0] * len(frames)
+    buffer, buffer_order = [], []
+    with torch.no_grad():
+        for order in order_list:
+            frame = frames[order]
+            if typ_list[order] == "I":
+                dec, size = image_compress(frame, im_models, level)
+            else:
+                lo, hi = select_references(order, buffer_order)
+                o1, o2 = buffer_order[lo], buffer_order[hi]
+                s1, s2 = get_scales(order, o1, o2)
+                dr, _ = get_best_down_ratio_prediction(model, buffer[lo], buffer[hi], s1, s2, frame)
+                out = model(buffer[lo], buffer[hi], s1, s2, frame, level, dr)
+                dec, size = out["x_hat"], out["size"]
+            a = torch.round(torch.clamp(frame[0, :, :h, :w], 0, 1) * 255.0).to(torch.uint8).float()
+            b = torch.round(torch.clamp(dec[0, :, :h, :w], 0, 1) * 255.0).to(torch.uint8).float()
+            psnr_list[order] = (10 * torch.log10((255 ** 2) / torch.mean((b - a) ** 2))).item()
+            size_list[order] = size.item() / (h * w)
+            buffer, buffer_order = (buffer + [torch.clamp(dec, 0, 1)])[-32:], (buffer_order + [order])[-32:]
+    return psnr_list, size_list

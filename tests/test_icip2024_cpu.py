@@ -144,3 +144,20 @@ def test_product_elic_schema_equals_reference_schema():
     sd = seeded_state_dict(icip2024.ELIC().state_dict(), seed=5)
     icip2024.ELIC().load_state_dict(sd, strict=True)
     oi.ELIC().load_state_dict(sd, strict=True)
+
+
+def test_oracle_sequence_loop_matches_reference_fixture():
+    """val_sequence_level (src/test.py:37-101) on the 20-frame clip: one full GOP-16 plus an irregular 3-frame tail."""
+    fx = load_fixture("icip2024_sequence_a.npz")
+    clip = [torch.from_numpy(f.astype("float32"))[None] / 255.0 for f in fx["clip_u8"]]
+    fa, fe = load_fixture("icip2024_forward_a.npz"), load_fixture("icip2024_elic_a.npz")
+    model = oi.FlowGuidedB().eval()
+    model.load_state_dict(seeded_state_dict(model.state_dict(), seed=int(fa["seed"])))
+    intra = oi.ELIC().eval()
+    intra.load_state_dict(seeded_state_dict(intra.state_dict(), seed=int(fe["seed"]), conv_gain=float(fe["conv_gain"])))
+    order, typ = oi.get_order_typ_list(16, len(clip))
+    assert order == fx["order"].tolist() and "".join(typ) == str(fx["typ"])
+    first = order[:6]                                    # I, I, then the first B-frames (the full clip takes a minute)
+    psnr, size = oi.val_sequence_level(clip, [intra] * 5, model, first, typ, int(fx["level"]))
+    for o in first:
+        assert abs(psnr[o] - fx["psnr"][o]) < 1e-2 and abs(size[o] - fx["size"][o]) / fx["size"][o] < 1e-3

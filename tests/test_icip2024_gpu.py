@@ -364,3 +364,28 @@ def test_full_size_properties_1080p(dev, models):
         ref = prod(fr[0], fr[2], 0.5, 0.5, fr[1], 2, best_host)
         assert torch.equal(again, ref["x_hat"])
     assert torch.isfinite(a["x_hat"]).all() and a["size"].item() > 0
+
+
+def test_sequence_loop_matches_reference_fixture(dev, models):
+    """code_sequence_icip2024 against the reference's own val_sequence_level output (fixture): 20 frames = I, I, a full
+    hierarchical GOP-16 and an irregular tail (frames 17-19), ELIC intra frames, per-frame flow-resolution search."""
+    from vcamd import gop as vgop, icip2024
+    from vcamd.seeding import seeded_state_dict
+    _, prod = models
+    fx = load_fixture("icip2024_sequence_a.npz")
+    fe = load_fixture("icip2024_elic_a.npz")
+    intra = icip2024.ELIC()
+    intra.load_state_dict(seeded_state_dict(intra.state_dict(), seed=int(fe["seed"]), conv_gain=float(fe["conv_gain"])))
+    intra = intra.to(dev).eval()
+    clip = [(torch.from_numpy(f.astype("float32"))[None] / 255.0).to(dev) for f in fx["clip_u8"]]
+    with torch.no_grad():
+        psnr, size = vgop.code_sequence_icip2024(prod, [intra] * 5, lambda i: clip[i], len(clip), int(fx["level"]))
+        psnr_h, size_h = vgop.code_sequence_icip2024(prod, [intra] * 5, lambda i: clip[i], len(clip), int(fx["level"]),
+                                                     search="host", cache_features=False)
+    assert psnr == psnr_h and size == size_h                  # device search + cached features change nothing
+    d_psnr = max(abs(a - b) for a, b in zip(psnr, fx["psnr"].tolist()))
+    rel = max(abs(a - b) / b for a, b in zip(size, fx["size"].tolist()))
+    print(f"sequence loop: max dPSNR={d_psnr:.2e} dB, max size rel={rel:.2e} over {len(clip)} frames")
+    assert d_psnr < 2e-2 and rel < 5e-3                       # decoding errors compound down the hierarchy
+    early = fx["order"].tolist()[:6]
+    assert max(abs(psnr[o] - fx["psnr"][o]) for o in early) < 1e-3

@@ -239,6 +239,51 @@ def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None
     return decoded, picked
 
 
+def code_sequence_icip2024(model, i_models, load_frame, n_frames, level, h=1080, w=1920, intra_size=16, search="device",
+                           cache_features=True):
+    """The reference's whole-sequence loop (ICIP2024/src/test.py:37-101, ``val_sequence_level``) for ANY frame count:
+    coding order and frame types from get_order_typ_list (full GOP-16s plus the irregular tail the reference codes with
+    whatever references are nearest), I-frames through ``i_models[level]`` (ELIC), B-frames through the flow-resolution
+    search + FlowGuidedB, references = the two decoded frames (clamped to [0,1], at most 32 kept) closest in display
+    order.  ``load_frame(i)`` returns the padded NCHW CUDA frame i.  One frame per pass (the regular GOPs of a long
+    sequence go through :func:`code_gop_icip2024`, which batches levels); the only host sync is the final readback.
+    Returns (psnr list, size list) indexed by display order, PSNR on uint8-rounded [:h,:w] crops, sizes in bits/(h*w)
+    with the reference's 1080x1920 defaults."""
+    from . import hip, icip2024
+    from .layers import BitCounter
+    order_list, typ_list = icip2024.get_order_typ_list(intra_size, n_frames)
+    psnr, size = [None] * n_frames, [None] * n_frames
+    buffer, buffer_order, feats = [], [], {}
+    for order in order_list:
+        cur = load_frame(order)
+        tc = hip.nchw_to_nhwc(cur)
+        if typ_list[order] == "I":
+            bits = BitCounter(cur.device, max_rows=6)
+            dec = hip.nhwc_to_nchw(i_models[int(level)].forward_device(tc, bits))
+        else:
+            ref1, ref2, o1, o2 = icip2024.select_references(None, order, buffer, buffer_order)
+            s1, s2 = icip2024.get_scales(order, o1, o2)
+            t1, t2 = hip.nchw_to_nhwc(ref1), hip.nchw_to_nhwc(ref2)
+            flow, dr = None, None
+            if search == "device":
+                flow, _, _ = model.search_flow_t(tc, t1, t2, s1, s2)
+            else:
+                dr, _ = icip2024.get_best_down_ratio_prediction(model, ref1, ref2, s1, s2, cur)
+            f1 = f2 = None
+            if cache_features:
+                for o, t in ((o1, t1), (o2, t2)):
+                    if o not in feats:
+                        feats[o] = model.feature_extractor.run(t)
+                f1, f2 = [feats[o1]], [feats[o2]]
+            bits = BitCounter(cur.device, max_rows=12)
+            dec = hip.nhwc_to_nchw(model.forward_device(t1, t2, s1, s2, tc, level, dr, bits, flow=flow, feats1=f1, feats2=f2))
+        psnr[order] = psnr_uint8(dec, cur, h, w)
+        size[order] = bits.totals().sum() / float(h * w)
+        buffer, buffer_order = icip2024.update_buffer(buffer, buffer_order, torch.clamp(dec, 0, 1), order)
+        feats = {o: f for o, f in feats.items() if o in buffer_order}     # frames that left the buffer can go
+    return torch.stack(psnr).tolist(), torch.stack(size).tolist()
+
+
 class GopGraph:
     """One GOP of B-frame coding captured ONCE as a HIP graph and replayed per GOP.
 
