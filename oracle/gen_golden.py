@@ -399,6 +399,86 @@ def gen_icip2024(outdir, frames, seed):
     print("  ICIP2024 bookkeeping fixture:", {k: len(v) for k, v in book["refs"].items()})
 
 
+def gen_lhbdc_test_loop(outdir, seed):
+    """The reference's own evaluation function ``test()`` (LHBDC/test/testing.py:88-196) run on seven tiny synthetic
+    "videos" (the seven folder names are hard-coded there): UVGTestDataset reads PNGs this function writes to a temp
+    directory, TestInfographic collects the per-frame rows.  Stubs: imageio (PIL), natsort, matplotlib; pandas >= 2
+    lacks DataFrame.append / Series.iteritems, which are shimmed.  The script body itself executes argparse on import,
+    so only its loop constants and the two functions are extracted with ``ast``."""
+    import argparse as _argparse
+    import json
+    import tempfile
+    import pandas as pd
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    if not hasattr(pd.DataFrame, "append"):
+        pd.DataFrame.append = lambda self, row, ignore_index=False: pd.concat([self, pd.DataFrame([row])], ignore_index=ignore_index)
+    if not hasattr(pd.Series, "iteritems"):
+        pd.Series.iteritems = pd.Series.items
+    nat = types.ModuleType("natsort")
+    nat.natsorted = sorted
+    img = types.ModuleType("imageio")
+    img.imread = lambda path: np.asarray(Image.open(path).convert("RGB"))
+    mpl, plt = types.ModuleType("matplotlib"), types.ModuleType("matplotlib.pyplot")
+    mpl.pyplot = plt
+    sys.modules.update({"natsort": nat, "imageio": img, "matplotlib": mpl, "matplotlib.pyplot": plt})
+    sys.modules.pop("utils", None)
+    sys.path.insert(0, os.path.join(REF, "LHBDC", "test"))
+    import utils as ref_tutils  # noqa
+    from_reference(ref_tutils)
+    sys.path.pop(0)
+    ref_m = import_reference_lhbdc()
+    path = os.path.join(REF, "LHBDC/test/testing.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("image_compress", "test")]
+    keep += [n for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") in
+             ("coding_order", "decoding_info", "hier_levels")]
+    tree.body = keep
+    ns = {"torch": torch, "math": __import__("math"), "np": np, "logging": __import__("logging"), "DataLoader": DataLoader,
+          "TestInfographic": ref_tutils.TestInfographic, "UVGTestDataset": ref_tutils.UVGTestDataset,
+          "float_to_uint8": ref_tutils.float_to_uint8, "PSNR": ref_tutils.PSNR, "MSE": ref_tutils.MSE}
+    exec(compile(tree, path, "exec"), ns)
+
+    torch.manual_seed(0)
+    ref_b = ref_m.Model().eval()
+    sd_b = seeded_state_dict(ref_b.state_dict(), seed=seed)
+    ref_b.load_state_dict(sd_b)
+    ora_b = olhbdc.LhbdcModel().eval()
+    ora_b.load_state_dict(sd_b)
+    ref_i = cai.models.mbt2018_mean(7).eval()          # compressai.zoo stand-in (weights unavailable offline): seeded
+    sd_i = seeded_state_dict(ref_i.state_dict(), seed=seed + 7, conv_gain=0.8)
+    ref_i.load_state_dict(sd_i)
+    folders = ["beauty", "bosphorus", "honeybee", "jockey", "ready", "shake", "yatch"]
+    with tempfile.TemporaryDirectory() as tmp:
+        for k, name in enumerate(folders):
+            os.makedirs(os.path.join(tmp, name))
+            for t, f in enumerate(olhbdc.harness_frames(seed, k, 9)):
+                Image.fromarray(f).save(os.path.join(tmp, name, f"im{t:05d}.png"))
+        args = _argparse.Namespace(test_path=tmp + "/", test_gop_size=8, test_skip_frames=1, test_numbers=1, workers=0,
+                                   i_interval=1.0, i_qual=7)
+        info = ns["test"](ref_b, ref_i, torch.device("cpu"), args)
+    df = info.frame_df
+    rows = [[str(r.video), str(r.frame_type), float(r.frame_num), float(r.psnr), float(r["size"]), float(r.pixels)]
+            for _, r in df.iterrows()]
+    # the oracle's restatement of the loop, video by video
+    for k, name in enumerate(folders):
+        mine = olhbdc.test_video(ora_b, ref_i, olhbdc.harness_frames(seed, k, 9))
+        theirs = [r for r in rows if r[0] == name]
+        if len(mine) != len(theirs):
+            raise SystemExit(f"oracle test loop: {len(mine)} rows vs {len(theirs)} for {name}")
+        for m_, t_ in zip(mine, theirs):
+            if m_[0] != t_[1] or float(m_[1]) != t_[2]:
+                raise SystemExit(f"oracle test loop: frame bookkeeping differs for {name}: {m_[:2]} vs {t_[1:3]}")
+        check(f"test() psnr {name}", np.array([m_[2] for m_ in mine], dtype=np.float64), np.array([t_[3] for t_ in theirs], dtype=np.float64))
+        check(f"test() size {name}", np.array([m_[3] for m_ in mine], dtype=np.float64), np.array([t_[4] for t_ in theirs], dtype=np.float64))
+    info.print_per_level()
+    agg = {"per_level": {str(k_): float(v) for k_, v in info.average_bpp_psnr_dict.items()}}
+    with open(os.path.join(outdir, "lhbdc_test_loop.json"), "w") as f:
+        json.dump({"seed": seed, "intra_seed": seed + 7, "intra_conv_gain": 0.8, "folders": folders, "frames_per_video": 9,
+                   "frame_hw": [180, 180], "rows": rows, "aggregate_bpp_to_psnr": agg}, f)
+    print(f"  LHBDC test() fixture: {len(rows)} frame rows over {len(folders)} videos; bpp->PSNR {agg['per_level']}")
+
+
 def gen_harness(outdir):
     """G5: item lists of the reference's own UVGTestDataset (LHBDC/test/utils.py:162-203 and the Flex twin)
     for synthetic directory listings -- natsort / imageio / glob are stubbed, the class body is the reference's."""
@@ -437,7 +517,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--only", choices=["lhbdc", "flex", "harness", "icip2024"], default=None)
+    ap.add_argument("--only", choices=["lhbdc", "flex", "harness", "icip2024", "testloop"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         raise SystemExit("/root/reference is not present: fixtures can only be generated in the build container")
@@ -453,6 +533,8 @@ def main():
         gen_flex(args.out, frames, args.seed)
     if args.only in (None, "icip2024"):
         gen_icip2024(args.out, frames, args.seed)
+    if args.only in (None, "testloop"):
+        gen_lhbdc_test_loop(args.out, args.seed)
     if args.only in (None, "harness"):
         gen_harness(args.out)
     print("fixtures written to", args.out)

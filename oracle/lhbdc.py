@@ -296,3 +296,62 @@ def read_container(blob):
     s2 = blob[p:p + len0_res]; p += len0_res
     s3 = blob[p:]
     return lmbda, [[s0], [s1]], [[s2], [s3]], shape_mv, shape_res
+
+
+# ---------------------------------------------------------------------------------------------------
+# the evaluation loop that defines the metric (LHBDC/test/testing.py:88-196, one video, i_interval == gop)
+# ---------------------------------------------------------------------------------------------------
+GOP8_ORDER = [0, 8, 4, 2, 1, 3, 6, 5, 7]
+GOP8_REFS = {4: (0, 8), 2: (0, 4), 1: (0, 2), 3: (2, 4), 6: (4, 8), 5: (4, 6), 7: (6, 8)}
+
+
+def harness_frames(seed, video, count, h=180, w=180):
+    """Deterministic uint8 test clip (integer arithmetic only, so every host regenerates the same bytes): a box-blurred
+    random texture translating by (2, 3) pixels per frame plus +-2 levels of noise."""
+    import numpy as np
+    g = np.random.Generator(np.random.PCG64([int(seed), int(video)]))
+    big = g.integers(0, 256, size=(h + 64, w + 96, 3), dtype=np.int64)
+    k = 5
+    c = np.cumsum(np.cumsum(np.pad(big, ((k, 0), (k, 0), (0, 0))), 0), 1)
+    blur = (c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k]) // (k * k)
+    out = []
+    for t in range(count):
+        f = blur[2 * t:2 * t + h, 3 * t:3 * t + w] + g.integers(-2, 3, size=(h, w, 3))
+        out.append(np.clip(f, 0, 255).astype(np.uint8))
+    return out
+
+
+def test_video(b_model, i_model, frames_u8, gop_size=8):
+    """testing.py:125-188 for one video whose frame list is I B*7 I [B*7 I ...] (test_size GOPs, i_interval == gop_size):
+    returns rows (frame_type, frame_num, psnr, size) in the order the reference's TestInfographic receives them.
+    Frames are HWC uint8 arrays; padding (reflection to x64) and the uint8 PSNR on the unpadded crop as in test/utils.py."""
+    import numpy as np
+    h, w = frames_u8[0].shape[:2]
+    x = [pad64(torch.from_numpy(f.astype(np.float32).transpose(2, 0, 1))[None] / 255.0) for f in frames_u8]
+
+    def psnr(dec, src):
+        a = np.round(np.clip(dec[0, :, :h, :w].numpy(), 0, 1) * 255.0).astype(np.uint8).astype(np.float64)
+        b = np.round(np.clip(src[0, :, :h, :w].numpy(), 0, 1) * 255.0).astype(np.uint8).astype(np.float64)
+        return 10 * np.log10(255.0 ** 2 / np.mean((a - b) ** 2))
+
+    def intra(im):
+        out = i_model(im)
+        return out["x_hat"], _bits(out["likelihoods"]).item()
+
+    rows = []
+    with torch.no_grad():
+        dec0, size0 = intra(x[0])
+        rows.append(("I", 0, psnr(dec0, x[0]), size0))
+        decoded = {0: dec0}
+        for g in range((len(x) - 1) // gop_size):
+            gop = x[g * gop_size:(g + 1) * gop_size + 1]
+            dec_last, size_last = intra(gop[-1])
+            decoded[8] = dec_last
+            rows.append(("I", 0, psnr(dec_last, gop[-1]), size_last))
+            for order in GOP8_ORDER[2:]:
+                r0, r1 = GOP8_REFS[order]
+                dec, _, size = b_model(decoded[r0], gop[order], decoded[r1], False)
+                decoded[order] = dec
+                rows.append(("B", order, psnr(dec, gop[order]), size))
+            decoded = {0: dec_last}
+    return rows

@@ -113,3 +113,50 @@ def test_sequence_loop_with_iframes(dev, codecs):
     table.extend_from_records(recs, level=7)
     agg = table.per_level_frame_type()
     assert agg[(7, "I")]["frames"] == 3 and agg[(7, "B")]["frames"] == 14
+
+
+def test_sequence_loop_against_the_reference_test_function(dev):
+    """vcamd.gop.code_sequence_lhbdc + RdTable against the rows the reference's own ``test()``
+    (LHBDC/test/testing.py:88-196) produced for seven synthetic clips -- fixture lhbdc_test_loop.json, frames
+    regenerated bit-exactly by oracle.lhbdc.harness_frames.
+
+    Tolerances are graded by hierarchy level: LHBDC feeds UNCLAMPED decoded frames back as references, and with the
+    seeded (untrained, non-contractive) weights a 1e-6 dB difference in a reference grows ~100x per level through the
+    flow network -- I-frames and level 0 agree to 1e-3 dB, level 1 to 1e-2, level 2 to 0.1 dB / 10 % in size, which
+    still separates "same wiring" from "wrong reference" (a different reference changes the size by O(1)).  Per-frame
+    accuracy on identical inputs is covered by test_lhbdc_gpu.py (5e-5 dB at 1080p)."""
+    import json
+    import os
+    from helpers import GOLDEN, lhbdc_pair
+    from oracle import lhbdc as ol
+    from vcamd import gop as vgop, iframe
+    from vcamd.seeding import seeded_state_dict
+    fx = json.load(open(os.path.join(GOLDEN, "lhbdc_test_loop.json")))
+    _, b_model = lhbdc_pair(fx["seed"], dev)
+    i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
+    i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=fx["intra_seed"], conv_gain=fx["intra_conv_gain"]))
+    i_model = i_model.to(dev).eval()
+    h, w = fx["frame_hw"]
+    table = vgop.RdTable()
+    tol = {"I": (1e-3, 1e-4), 0: (1e-3, 1e-3), 1: (1e-2, 1e-2), 2: (0.1, 0.1)}
+    worst = {k: [0.0, 0.0] for k in tol}
+    with torch.no_grad():
+        for k, name in enumerate(fx["folders"]):
+            frames = [ol.pad64(torch.from_numpy(f.astype("float32").transpose(2, 0, 1))[None] / 255.0).to(dev)
+                      for f in ol.harness_frames(fx["seed"], k, fx["frames_per_video"])]
+            recs = vgop.code_sequence_lhbdc(b_model, i_model, lambda i: frames[i], len(frames), h, w, video=k, test_size=1)
+            ref = [r for r in fx["rows"] if r[0] == name]
+            assert len(recs) == len(ref) == 9
+            assert [int(r[6]) for r in recs] == [1 if r[1] == "I" else 0 for r in ref]          # I, I, then 7 B-frames
+            assert [int(r[1]) % 8 for r in recs[2:]] == [int(r[2]) for r in ref[2:]]            # coding order 4 2 1 3 6 5 7
+            for mine, theirs in zip(recs, ref):
+                key = "I" if theirs[1] == "I" else vgop.HIER_LEVELS[int(theirs[2])]
+                worst[key][0] = max(worst[key][0], abs(float(mine[3]) - theirs[3]))
+                worst[key][1] = max(worst[key][1], abs(float(mine[4]) - theirs[4]) / theirs[4])
+            table.extend_from_records(recs, 7)
+    print("test() loop, worst (dPSNR dB, size rel) per level:", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in worst.items()})
+    for key, (tp, ts) in tol.items():
+        assert worst[key][0] < tp and worst[key][1] < ts, (key, worst[key])
+    (bpp_ref, psnr_ref), = [(float(k), v) for k, v in fx["aggregate_bpp_to_psnr"]["per_level"].items()]
+    agg = table.per_level()[7]
+    assert abs(agg["bpp"] - bpp_ref) / bpp_ref < 1e-2 and abs(agg["psnr"] - psnr_ref) < 1e-2
