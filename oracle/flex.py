@@ -208,3 +208,51 @@ def decode_B(model, x_before, x_after, string_flow, string_res, shape_flow, shap
     flow_hat = model.flow_compressor.decompress(string_flow, shape_flow, [n], l)["x_hat"]
     x_comp = model.compensate(x_before, x_after, mvb, mva, flow_hat)
     return model.residual_compressor.decompress(string_res, shape_res, [n], l)["x_hat"] + x_comp
+
+
+# ---------------------------------------------------------------------------------------------------
+# the evaluation loop of Flex-Rate (test/testing.py:124-224), one video, one operating point, i_interval == gop
+# ---------------------------------------------------------------------------------------------------
+GOP16_ORDER = [0, 16, 8, 4, 2, 1, 3, 6, 5, 7, 12, 10, 9, 11, 14, 13, 15]
+GOP16_REFS = {8: (0, 16), 4: (0, 8), 2: (0, 4), 1: (0, 2), 3: (2, 4), 6: (4, 8), 5: (4, 6), 7: (6, 8),
+              12: (8, 16), 10: (8, 12), 9: (8, 10), 11: (10, 12), 14: (12, 16), 13: (12, 14), 15: (14, 16)}
+GOP16_LEVELS = {8: 0, 4: 1, 2: 2, 1: 3, 3: 3, 6: 2, 5: 3, 7: 3, 12: 1, 10: 2, 9: 3, 11: 3, 14: 2, 13: 3, 15: 3}
+
+
+def test_video(b_model, i_models, frames_u8, quality, gop_size=16):
+    """Rows (frame_type, frame_num, psnr, size) in the order the reference's TestInfographic receives them for
+    ``quality`` = (i_qual, {hierarchy level: (n, l)}): intra frames through ``i_models[i_qual]``, every B-frame through
+    BidirFlowRef.forward with the (n, l) of its level.  Frames are HWC uint8 arrays."""
+    import numpy as np
+    from .lhbdc import _bits, pad64
+    i_model, table = i_models[quality[0]], quality[1]
+    h, w = frames_u8[0].shape[:2]
+    x = [pad64(torch.from_numpy(f.astype(np.float32).transpose(2, 0, 1))[None] / 255.0) for f in frames_u8]
+
+    def psnr(dec, src):
+        a = np.round(np.clip(dec[0, :, :h, :w].numpy(), 0, 1) * 255.0).astype(np.uint8).astype(np.float64)
+        b = np.round(np.clip(src[0, :, :h, :w].numpy(), 0, 1) * 255.0).astype(np.uint8).astype(np.float64)
+        return 10 * np.log10(255.0 ** 2 / np.mean((a - b) ** 2))
+
+    def intra(im):
+        out = i_model(im)
+        return out["x_hat"], _bits(out["likelihoods"]).item()
+
+    rows = []
+    with torch.no_grad():
+        dec0, size0 = intra(x[0])
+        rows.append(("I", 0, psnr(dec0, x[0]), size0))
+        decoded = {0: dec0}
+        for g in range((len(x) - 1) // gop_size):
+            gop = x[g * gop_size:(g + 1) * gop_size + 1]
+            dec_last, size_last = intra(gop[-1])
+            decoded[16] = dec_last
+            rows.append(("I", 0, psnr(dec_last, gop[-1]), size_last))
+            for order in GOP16_ORDER[2:]:
+                r0, r1 = GOP16_REFS[order]
+                n, l = table[GOP16_LEVELS[order]]
+                out = b_model(decoded[r0], gop[order], decoded[r1], n=[n], l=l, train=False)
+                decoded[order] = out["x_hat"]
+                rows.append(("B", order, psnr(out["x_hat"], gop[order]), out["size"].squeeze(0).item()))
+            decoded = {0: dec_last}
+    return rows

@@ -479,6 +479,89 @@ def gen_lhbdc_test_loop(outdir, seed):
     print(f"  LHBDC test() fixture: {len(rows)} frame rows over {len(folders)} videos; bpp->PSNR {agg['per_level']}")
 
 
+def gen_flex_test_loop(outdir, seed):
+    """Flex-Rate's own ``test()`` (test/testing.py:124-224) on seven synthetic clips of 17 frames, for the first and the
+    last of its eight operating points (its module-level ``qualities`` list is cut to those two to keep the CPU run
+    short; the function itself is the reference's).  Same scaffolding as gen_lhbdc_test_loop."""
+    import argparse as _argparse
+    import json
+    import tempfile
+    import pandas as pd
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    if not hasattr(pd.DataFrame, "append"):
+        pd.DataFrame.append = lambda self, row, ignore_index=False: pd.concat([self, pd.DataFrame([row])], ignore_index=ignore_index)
+    if not hasattr(pd.Series, "iteritems"):
+        pd.Series.iteritems = pd.Series.items
+    nat = types.ModuleType("natsort")
+    nat.natsorted = sorted
+    img = types.ModuleType("imageio")
+    img.imread = lambda path: np.asarray(Image.open(path).convert("RGB"))
+    mpl, plt = types.ModuleType("matplotlib"), types.ModuleType("matplotlib.pyplot")
+    mpl.pyplot = plt
+    sys.modules.update({"natsort": nat, "imageio": img, "matplotlib": mpl, "matplotlib.pyplot": plt})
+    sys.modules.pop("utils", None)
+    tdir = os.path.join(REF, "Flex-Rate-Hier-Bidir-Video-Compression", "test")
+    sys.path.insert(0, tdir)
+    import utils as ref_tutils  # noqa
+    from_reference(ref_tutils)
+    sys.path.pop(0)
+    ref_b_mod = import_reference_flex()
+    path = os.path.join(tdir, "testing.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "test"]
+    keep += [n for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") in
+             ("coding_order", "decoding_info", "hier_levels", "qualities")]
+    tree.body = keep
+    ns = {"torch": torch, "math": __import__("math"), "np": np, "logging": __import__("logging"), "DataLoader": DataLoader,
+          "TestInfographic": ref_tutils.TestInfographic, "UVGTestDataset": ref_tutils.UVGTestDataset,
+          "float_to_uint8": ref_tutils.float_to_uint8, "PSNR": ref_tutils.PSNR, "MSE": ref_tutils.MSE,
+          "compressai_image_compress": ref_tutils.compressai_image_compress}
+    exec(compile(tree, path, "exec"), ns)
+    all_q = ns["qualities"]
+    ns["qualities"] = [all_q[0], all_q[-1]]
+
+    torch.manual_seed(0)
+    ref_b = ref_b_mod.BidirFlowRef(n=4).eval()
+    sd_b = seeded_state_dict(ref_b.state_dict(), seed=seed)
+    ref_b.load_state_dict(sd_b)
+    ora_b = oflex.FlexModel(n=4).eval()
+    ora_b.load_state_dict(sd_b)
+    i_models = {}
+    for q in sorted({all_q[0][0], all_q[-1][0]}):
+        m = cai.models.mbt2018_mean(q).eval()
+        m.load_state_dict(seeded_state_dict(m.state_dict(), seed=seed + q, conv_gain=0.8))
+        i_models[q] = m
+    folders = ["beauty", "bosphorus", "honeybee", "jockey", "ready", "shake", "yatch"]
+    with tempfile.TemporaryDirectory() as tmp:
+        for k, name in enumerate(folders):
+            os.makedirs(os.path.join(tmp, name))
+            for t, f in enumerate(olhbdc.harness_frames(seed, k, 17, 120, 180)):
+                Image.fromarray(f).save(os.path.join(tmp, name, f"im{t:05d}.png"))
+        args = _argparse.Namespace(test_path=tmp + "/", test_gop_size=16, test_skip_frames=1, test_numbers=1, workers=0,
+                                   i_interval=1.0, levels_intervals=[(0, 1.0)])
+        info = ns["test"](ref_b, i_models, torch.device("cpu"), args)
+    df = info.frame_df
+    rows = [[str(r.video), int(r.level), float(r.interval), str(r.frame_type), float(r.frame_num), float(r.psnr), float(r["size"]),
+             float(r.pixels)] for _, r in df.iterrows()]
+    for qi, q in enumerate(ns["qualities"]):
+        lvl, itv = q[1][3]
+        for k, name in enumerate(folders):
+            mine = oflex.test_video(ora_b, i_models, olhbdc.harness_frames(seed, k, 17, 120, 180), q)
+            theirs = [r for r in rows if r[0] == name and r[1] == lvl and r[2] == itv]
+            if [(m_[0], float(m_[1])) for m_ in mine] != [(t_[3], t_[4]) for t_ in theirs]:
+                raise SystemExit(f"oracle Flex test loop: frame bookkeeping differs for {name} at operating point {qi}")
+            check(f"flex test() psnr {name} q{qi}", np.array([m_[2] for m_ in mine], dtype=np.float64),
+                  np.array([t_[5] for t_ in theirs], dtype=np.float64))
+            check(f"flex test() size {name} q{qi}", np.array([m_[3] for m_ in mine], dtype=np.float64),
+                  np.array([t_[6] for t_ in theirs], dtype=np.float64))
+    with open(os.path.join(outdir, "flex_test_loop.json"), "w") as f:
+        json.dump({"seed": seed, "intra_seed_offset_is_quality": True, "intra_conv_gain": 0.8, "folders": folders,
+                   "frames_per_video": 17, "frame_hw": [120, 180],
+                   "qualities": [[q[0], {str(k_): list(v) for k_, v in q[1].items()}] for q in ns["qualities"]], "rows": rows}, f)
+    print(f"  Flex test() fixture: {len(rows)} frame rows, {len(ns['qualities'])} operating points x {len(folders)} videos")
+
+
 def gen_harness(outdir):
     """G5: item lists of the reference's own UVGTestDataset (LHBDC/test/utils.py:162-203 and the Flex twin)
     for synthetic directory listings -- natsort / imageio / glob are stubbed, the class body is the reference's."""
@@ -517,7 +600,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--only", choices=["lhbdc", "flex", "harness", "icip2024", "testloop"], default=None)
+    ap.add_argument("--only", choices=["lhbdc", "flex", "harness", "icip2024", "testloop", "flextestloop"], default=None)
     args = ap.parse_args()
     if not os.path.isdir(REF):
         raise SystemExit("/root/reference is not present: fixtures can only be generated in the build container")
@@ -535,6 +618,8 @@ def main():
         gen_icip2024(args.out, frames, args.seed)
     if args.only in (None, "testloop"):
         gen_lhbdc_test_loop(args.out, args.seed)
+    if args.only in (None, "flextestloop"):
+        gen_flex_test_loop(args.out, args.seed)
     if args.only in (None, "harness"):
         gen_harness(args.out)
     print("fixtures written to", args.out)

@@ -148,3 +148,46 @@ def test_gops_batched_together_equal_gops_coded_alone(dev, models):
         runner.code(gops[0] + gops[1], gop_index=3, records=recs_g)
     assert [r[:3] for r in recs_alone] == [r[:3] for r in recs_b] == [r[:3] for r in recs_g]
     assert all(float(a[4]) == float(b[4]) == float(c[4]) for a, b, c in zip(recs_alone, recs_b, recs_g))
+
+
+def test_sequence_loop_against_the_reference_test_function(dev):
+    """vcamd.gop.code_sequence_flex against the rows of the reference's own ``test()`` (fixture flex_test_loop.json: seven
+    clips x two operating points).  Tolerances graded by hierarchy level as in the LHBDC twin of this test (unclamped
+    decoded references + untrained weights amplify reference differences level by level)."""
+    import json
+    import os
+    from helpers import GOLDEN
+    from oracle import lhbdc as ol
+    from vcamd import flex, gop as vgop, iframe
+    from vcamd.seeding import seeded_state_dict
+    fx = json.load(open(os.path.join(GOLDEN, "flex_test_loop.json")))
+    b_model = flex.BidirFlowRef(n=4)
+    b_model.load_state_dict(seeded_state_dict(b_model.state_dict(), seed=fx["seed"]))
+    b_model = b_model.to(dev).eval()
+    h, w = fx["frame_hw"]
+    tol = {"I": (1e-3, 1e-4), 0: (1e-3, 1e-3), 1: (5e-3, 5e-3), 2: (2e-2, 1e-2), 3: (2e-2, 2e-2)}
+    worst = {k: [0.0, 0.0] for k in tol}
+    i_models = {}
+    with torch.no_grad():
+        for i_qual, table in fx["qualities"]:
+            quality = (i_qual, {int(k): tuple(v) for k, v in table.items()})
+            if i_qual not in i_models:
+                m = iframe.mbt2018_mean(i_qual, "mse", pretrained=False)
+                m.load_state_dict(seeded_state_dict(m.state_dict(), seed=fx["seed"] + i_qual, conv_gain=fx["intra_conv_gain"]))
+                i_models[i_qual] = m.to(dev).eval()
+            lvl, itv = quality[1][3]
+            for k, name in enumerate(fx["folders"][:3]):            # three clips per operating point keep the test short
+                frames = [ol.pad64(torch.from_numpy(f.astype("float32").transpose(2, 0, 1))[None] / 255.0).to(dev)
+                          for f in ol.harness_frames(fx["seed"], k, fx["frames_per_video"], h, w)]
+                recs = vgop.code_sequence_flex(b_model, i_models, lambda i: frames[i], len(frames), h, w, quality, video=k, test_size=1)
+                ref = [r for r in fx["rows"] if r[0] == name and r[1] == lvl and r[2] == itv]
+                assert len(recs) == len(ref) == 17
+                assert [int(r[6]) for r in recs] == [1 if r[3] == "I" else 0 for r in ref]
+                assert [int(r[1]) % 16 for r in recs[2:]] == [int(r[4]) for r in ref[2:]]
+                for mine, theirs in zip(recs, ref):
+                    key = "I" if theirs[3] == "I" else vgop.HIER_LEVELS_16[int(theirs[4])]
+                    worst[key][0] = max(worst[key][0], abs(float(mine[3]) - theirs[5]))
+                    worst[key][1] = max(worst[key][1], abs(float(mine[4]) - theirs[6]) / theirs[6])
+    print("flex test() loop, worst (dPSNR dB, size rel) per level:", {k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in worst.items()})
+    for key, (tp, ts) in tol.items():
+        assert worst[key][0] < tp and worst[key][1] < ts, (key, worst[key])

@@ -453,6 +453,32 @@ def code_sequence_lhbdc(b_model, i_model, load_frame, num_available, h, w, video
     return records
 
 
+def code_sequence_flex(b_model, i_models, load_frame, num_available, h, w, quality, video=0, gop_size=16, test_size=2):
+    """Flex-Rate.../test/testing.py:124-224 for one video and ONE operating point ``quality`` = (i_qual, {hierarchy level:
+    (n, l)}) (an entry of FLEX_QUALITIES): intra frame 0 once and one at the end of every GOP through
+    ``i_models[i_qual]``, the 15 B-frames between them with the (n, l) of their level (level-batched passes).
+    Returns records (video, frame_num, level|-1 for I, psnr, bits, pixels, is_intra) like code_sequence_lhbdc."""
+    i_model = i_models[quality[0]]
+    batches = gop_batches(uvg_frame_indices(num_available, gop_size, test_size), gop_size)
+    records = []
+
+    def intra(idx):
+        x = load_frame(idx)
+        x_hat, tot = i_model.forward_device(x)
+        records.append((video, idx, -1, psnr_uint8(x_hat, x, h, w), tot.sum(), float(h * w), 1))
+        return x_hat
+
+    dec_last = None
+    for g, idxs in enumerate(batches):
+        gop = [load_frame(i) for i in idxs]
+        dec_first = dec_last if dec_last is not None else intra(idxs[0])
+        dec_last = intra(idxs[-1])
+        recs = []
+        code_gop_flex(b_model, gop, dec_first, dec_last, h, w, quality, recs, video, g)
+        records.extend(r + (0,) for r in recs)
+    return records
+
+
 class RdTable:
     """Aggregation of TestInfographic (utils.py:393-489) without pandas: PSNR = mean of per-frame PSNR,
     bpp = sum(size)/sum(pixels), grouped like print_per_level / per_video_level / per_frame_type."""
