@@ -215,6 +215,7 @@ def main():
                    "resolution": f"{W}x{H}", "precision": args.precision, "parallelism": f"gop-shard x{world}",
                    "launch": "eager" if args.no_graph else "hip-graph per GOP"},
     }
+    result["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)   # of 288 GB, this rank, graphs included
     q = vgop.summarize(rows)
     result["quality"] = {"b_frames": q["frames"], "bpp_estimated": q["bpp"], "psnr_db": q["psnr"],
                          "note": "seeded random weights: R-D values are parity references, not codec quality"}
