@@ -338,7 +338,9 @@ class GopGraph:
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()                     # hand the eager warm-up's blocks back before capturing
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool):
+                # thread_local: only THIS thread's calls are checked against the capture -- a process-group watchdog
+                # thread polling events (multi-GPU runs) must not invalidate it
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
                     self.decoded, self.out_psnr, self.out_bits = self._run(self.static_in)
             self.graph = g
         for dst, src in zip(self.static_in, frames):
