@@ -170,7 +170,7 @@ def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None
     and picks the winner without leaving the GPU (no host sync in the whole GOP: capturable as one HIP graph);
     "host" compares the five PSNRs on the host like the reference loop (one sync per frame, no batching); None uses
     ``down_ratio``.  ``cache_features``: a decoded frame's feature pyramid is computed once and reused for every
-    B-frame it serves as reference.  ``batch_levels`` / ``max_batch``: see :func:`icip2024_gop_plan` (default cap: eight 1080p frames' worth of pixels per pass).  Decoded frames are clamped to
+    B-frame it serves as reference.  ``batch_levels`` / ``max_batch``: see :func:`icip2024_gop_plan` (default cap: 8 frames and sixteen 1080p frames' worth of pixels per pass -- 4 frames at 2160p, 167 GB peak).  Decoded frames are clamped to
     [0,1] before they serve as references (src/test.py:94).  Records are appended in the reference's coding order.
     Returns ({order: decoded}, {order: chosen down_ratio -- a device int32 index into (1,2,4,8,16) for "device"})."""
     from . import hip, icip2024
@@ -187,8 +187,8 @@ def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None
             feats[o] = model.feature_extractor.run(nhwc[o])
         return feats[o]
 
-    if max_batch is None:        # keep a batched pass at or below eight 1080p frames' worth of activations
-        max_batch = max(1, min(8, (8 * 1088 * 1920) // (gop[0].shape[2] * gop[0].shape[3])))
+    if max_batch is None:        # at most 8 frames and sixteen 1080p frames' worth of activations per batched pass
+        max_batch = max(1, min(8, (16 * 1088 * 1920) // (gop[0].shape[2] * gop[0].shape[3])))
     for group in icip2024_gop_plan(batch_levels and search != "host", max_batch):
         orders = [g[0] for g in group]
         s1, s2 = group[0][3], group[0][4]
