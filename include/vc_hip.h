@@ -257,6 +257,30 @@ int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, const int32_
                                 const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
                                 const int32_t *offsets, int32_t *symbols_out);
 
+/* ------------------------------------------------------------------------------------------
+ * Entry points under the operator names SURVEY.md section 8(b) lists for the boundary.  Thin forwards to the
+ * functions above (same kernels, same argument rules); a binding may use either spelling.
+ * ---------------------------------------------------------------------------------------- */
+/* compressai.layers.GDN(.inverse): y = x * rsqrt(beta + gamma @ x^2) (inverse: * sqrt), optional residual added to the
+ * result.  gamma_packed / beta_packed: the resolved (non-negative) gamma [C,C,1,1] and beta [C] packed with
+ * vc_conv_pack_weights for cfg = vc_conv_select_cfg(C, C, 1, 1). */
+int vc_gdn(vc_stream s, vc_view x, const float *gamma_packed, const float *beta_packed, int inverse, vc_view res /* p may be NULL */,
+           vc_view out);
+/* = vc_spynet_level_input (flow.py:93-98) */
+int vc_spynet_level(vc_stream s, vc_view first, vc_view second, vc_view flow_coarse, vc_view feat8, vc_view up2);
+/* = vc_avgpool_reflectpad / vc_upsample_bilinear / reflection padding alone (k = 1) / vc_lhbdc_blend */
+int vc_pool(vc_stream s, vc_view in, vc_view out, int k, float scale);
+int vc_upsample(vc_stream s, vc_view in, vc_view out, int factor, int align_corners, float scale);
+int vc_pad(vc_stream s, vc_view in, vc_view out);
+int vc_blend(vc_stream s, vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid);
+/* = vc_eb_forward / vc_gc_forward */
+int vc_factorized_bits(vc_stream s, vc_view z, const float *params, const float *in_gain, const float *out_gain,
+                       vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots);
+int vc_gaussian_symbols(vc_stream s, vc_view y, vc_view scales, vc_view means, const float *in_gain,
+                        const float *out_gain, vc_view y_hat, double *bits_partial, int bits_slots,
+                        const float *sym_src_p, int32_t *symbols, int32_t *indexes, const float *scale_table,
+                        int n_scales);
+
 #ifdef __cplusplus
 }
 #endif

@@ -500,3 +500,28 @@ def test_gdn_on_streaming_kernel_is_bit_identical(dev, inverse):
         ref = ora(x)
     _close(outs[1][0], ref, 3e-5, "GDN on the streaming kernel vs oracle")
     _close(outs[1][1], ref + res, 3e-5, "GDN + residual")
+
+
+def test_survey_named_entry_points_forward_to_the_same_kernels(dev):
+    """vc_gdn / vc_pad / vc_pool ... (the operator names of SURVEY.md 8(b)) give what the library's own entry points give"""
+    from vcamd import hip
+    from vcamd.layers import GDN
+    from vcamd.seeding import seeded_state_dict
+    L = hip.lib()
+    g = GDN(128)
+    g.load_state_dict(seeded_state_dict(g.state_dict(), seed=5))
+    g = g.to(dev)
+    x = hip.nchw_to_nhwc(_rand((1, 128, 20, 33), 91, 2.0).to(dev))
+    res = hip.nchw_to_nhwc(_rand((1, 128, 20, 33), 92).to(dev))
+    ref = g.run(x, res=res)
+    pc = g._packed
+    assert pc.cfg == L.vc_conv_select_cfg(128, 128, 1, 1)
+    out = hip.T.empty(1, 20, 33, 128, dev)
+    hip.check(L.vc_gdn(hip.stream(), x.view(), pc.wpk.data_ptr(), pc.bias.data_ptr(), 0, res.view(), out.view()), "vc_gdn")
+    assert torch.equal(hip.nhwc_to_nchw(out), hip.nhwc_to_nchw(ref))
+    img = _rand((1, 3, 30, 45), 93)
+    t = hip.nchw_to_nhwc(img.to(dev))
+    padded = hip.T.empty(1, 48, 64, 3, dev)
+    hip.check(L.vc_pad(hip.stream(), t.view(), padded.view()), "vc_pad")
+    ref_pad = torch.nn.ReflectionPad2d((0, 64 - 45, 0, 48 - 30))(img)
+    assert torch.equal(hip.nhwc_to_nchw(padded).cpu(), ref_pad)

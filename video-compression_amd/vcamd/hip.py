@@ -139,6 +139,8 @@ def lib():
     sig("vc_gc_dequant", ci, vp, vp, View, vp, View)
     sig("vc_bits_reduce", ci, vp, vp, ci, ci, vp)
     sig("vc_bits_slots", ci)
+    sig("vc_gdn", ci, vp, View, vp, vp, ci, View, View)
+    sig("vc_pad", ci, vp, View, View)
     sig("vc_pmf_to_quantized_cdf", ci, vp, ci, ci, vp)
     sig("vc_rans_bound", sz, sz)
     sig("vc_rans_encode_with_indexes", cll, vp, vp, sz, vp, ci, vp, vp, vp, sz)
@@ -157,6 +159,8 @@ EXPORTED_SYMBOLS = [
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
     "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes",
+    # the operator spellings of SURVEY.md 8(b), thin forwards (csrc/abi_aliases.cpp)
+    "vc_gdn", "vc_spynet_level", "vc_pool", "vc_upsample", "vc_pad", "vc_blend", "vc_factorized_bits", "vc_gaussian_symbols",
 ]
 
 
