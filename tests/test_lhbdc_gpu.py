@@ -232,3 +232,10 @@ def test_full_size_1080p_properties(dev, models):
     print(f"1080p residual stream: coded {real:.0f} bits vs estimated {est:.0f} bits")
     assert 0.5 * est < real < 1.02 * est
     assert len(blob) == 24 + sum(len(s[0]) for s in (s_mv + s_res))
+
+
+def test_cli_helper_ups(dev):
+    from vcamd import lhbdc
+    x = torch.randn(1, 2, 12, 20, generator=torch.Generator().manual_seed(3))
+    ref = torch.nn.Upsample(scale_factor=4, mode="bilinear")(x)
+    assert (lhbdc.ups(x.to(dev)).cpu() - ref).abs().max().item() < 1e-6

@@ -347,6 +347,12 @@ def pad(im):
     return hip.nhwc_to_nchw(hip.avgpool_reflectpad(t, 1, 1.0, t.h + _pad64(t.h), t.w + _pad64(t.w)))
 
 
+def ups(flow):
+    """encode_B.py:66-68 / decode_B.py:57-59: bilinear x4 of an NCHW CUDA flow field (nn.Upsample(scale_factor=4))."""
+    _require_cuda(flow)
+    return hip.nhwc_to_nchw(hip.upsample_bilinear(hip.nchw_to_nhwc(flow), 4))
+
+
 def process_frame(img, device="cuda"):
     x = np.ascontiguousarray(img.transpose(2, 0, 1))[None]
     x = normalize(torch.from_numpy(x).to(device).float())
