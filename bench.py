@@ -1,21 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- B-frame throughput of the LHBDC hot path on MI355X (BASELINE.json configs[1]).
 
-One "step" = one GOP-8 of a synthetic 1080p video (SURVEY.md 8(d) Config 2): the 7 B-frames coded in
-hierarchical order through Model.forward (flow -> warp -> mask/blend -> residual analysis -> hyperprior
--> likelihood/bit count -> synthesis), inputs resident in HBM, seeded random weights of the reference
-architecture (pretrained weights and UVG are not available offline).  I-frames are the reference's
-third-party mbt2018_mean codec -- outside the per-B-frame path -- so the boundary frames of each GOP
-are taken as already decoded.
+One "step" = one pass of the hot path over one batch of synthetic 1080p video (SURVEY.md 8(d) Config 2): the 7 B-frames
+of each GOP-8 coded in hierarchical order through Model.forward (flow -> warp -> mask/blend -> residual analysis ->
+hyperprior -> likelihood/bit count -> synthesis), inputs resident in HBM, seeded random weights of the reference
+architecture (pretrained weights and UVG are not available offline).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1: launched by torch.distributed.run, one rank per GPU; GOPs shard across ranks (weak scaling, no
-data-path collective), the per-frame R-D records are gathered over RCCL at the end.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--model ...] [--precision ...]
+
+N > 1: one rank per GPU.  Started by `python -m torch.distributed.run` the ranks read RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_*; started plainly (`python bench.py --gpus 8`) this process launches that command itself as a CHILD -- before
+anything touches the GPU -- and forwards rank 0's JSON line and the exit code.
+  --scaling weak   (default) every rank codes its own GOPs per step: per-GPU work fixed, no data-path collective;
+  --scaling strong BASELINE.json configs[3]: ONE fixed test set (LHBDC/test/testing.py:99-188: 7 sequences, every GOP-8,
+                   I-frames included through the mbt2018_mean architecture) sharded by contiguous GOP ranges
+                   (vcamd.gop.shard_gops / code_workload); a step = the whole set once.
+In both modes the only exchange is the final all-gather of per-frame R-D records (RCCL over xGMI).
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -26,18 +35,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
 
-H, W = 1080, 1920
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # BF16/FP16 matrix peak, dense
 PEAK_HBM_GBPS = 8000.0           # HBM3E peak (same guide)
-PEAK_HBM_GBS = 8000.0
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "traffic.json")
+
+
+def kernel_source_stamp():
+    """Hash of the convolution kernel sources: profiles/*/traffic.json is valid for exactly one version of them."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "video-compression_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.startswith("conv") and name.endswith((".h", ".hip")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def synthetic_gop(seed, gop_index, device, frames_per_gop=9, hw=None):
-    H, W = hw if hw is not None else (1080, 1920)
     """Config 2: band-limited noise texture (Gaussian sigma=3 px) + global translation (1.5,0.75) px per
     frame + 2 % additive noise, quantised to uint8, then /255 and reflection-padded to 1088x1920."""
     from scipy import ndimage
+    H, W = hw if hw is not None else (1080, 1920)
     rng = np.random.default_rng(seed)
     margin = 32
     tex = rng.random((3, H + 2 * margin, W + 2 * margin)).astype(np.float32)
@@ -57,27 +76,90 @@ def synthetic_gop(seed, gop_index, device, frames_per_gop=9, hw=None):
     return frames
 
 
-def pick_cpu_threads():
-    """Give the CPU baseline its best shot: time one representative convolution (SPyNet 7x7 32->64 at
-    272x480) at a few thread counts and keep the fastest (oversubscribing a big host is much slower)."""
-    cores = os.cpu_count() or 1
-    x = torch.randn(1, 32, 272, 480)
-    w = torch.randn(64, 32, 7, 7)
-    best, best_t = 1, float("inf")
-    for n in sorted({c for c in (8, 16, 32, 64, cores // 2, cores) if 1 <= c <= cores}):
-        torch.set_num_threads(n)
-        with torch.no_grad():
-            torch.nn.functional.conv2d(x, w, padding=3)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                torch.nn.functional.conv2d(x, w, padding=3)
-            dt = time.perf_counter() - t0
-        if dt < best_t:
-            best, best_t = n, dt
-    return best
+class SyntheticTestSet:
+    """The fixed workload of --scaling strong: ``videos`` sequences of ``frames`` 8-bit frames each, generated ON THE
+    DEVICE (same recipe as :func:`synthetic_gop`: band-limited texture, global translation, 2 % noise, 8-bit) and kept
+    resident in HBM as uint8 (6.2 MB per 1080p frame: the full 7 x 593-frame set is 26 GB of the 288 GB).  Only the
+    frames of this rank's GOP range are generated.  ``frame(video, idx)`` hands the padded fp32 NCHW tensor the codec
+    takes (uint8 -> float, /255, reflection pad: the test loop's data loader, LHBDC/test/utils.py:190-203)."""
+
+    def __init__(self, videos, frames, hw, device, seed=1234):
+        self.videos, self.frames, self.hw, self.device, self.seed = videos, frames, hw, device, seed
+        self.store = {}
+        self._tex = {}
+
+    def _texture(self, video):
+        if video not in self._tex:
+            H, W = self.hw
+            g = torch.Generator(device="cpu").manual_seed(self.seed + 1000 * video)
+            tex = torch.rand(1, 3, H + 64, W + 64, generator=g).to(self.device)
+            k = torch.arange(-9, 10, dtype=torch.float32, device=self.device)
+            k = torch.exp(-0.5 * (k / 3.0) ** 2)
+            k = (k / k.sum())
+            tex = torch.nn.functional.conv2d(tex.transpose(0, 1), k.view(1, 1, 1, -1), padding=(0, 9))
+            tex = torch.nn.functional.conv2d(tex, k.view(1, 1, -1, 1), padding=(9, 0)).transpose(0, 1)
+            self._tex = {video: (tex - tex.min()) / (tex.max() - tex.min())}       # keep one texture at a time
+        return self._tex[video]
+
+    def materialise(self, video, idx):
+        key = (video, idx)
+        if key in self.store:
+            return
+        H, W = self.hw
+        tex = self._texture(video)
+        dx, dy = 1.5 * (idx % 16), 0.75 * (idx % 16)
+        ix, iy, fx, fy = int(dx), int(dy), dx - int(dx), dy - int(dy)
+
+        def win(oy, ox):
+            return tex[:, :, 32 - iy - oy:32 - iy - oy + H, 32 - ix - ox:32 - ix - ox + W]
+        f = ((1 - fy) * ((1 - fx) * win(0, 0) + fx * win(0, 1)) + fy * ((1 - fx) * win(1, 0) + fx * win(1, 1)))
+        g = torch.Generator(device=self.device).manual_seed(self.seed + 7919 * video + idx)
+        f = f + 0.02 * torch.randn(f.shape, generator=g, device=self.device)
+        self.store[key] = torch.clamp(torch.round(f * 255.0), 0, 255).to(torch.uint8)
+
+    def frame(self, video, idx):
+        H, W = self.hw
+        x = self.store[(video, idx)].to(torch.float32) / 255.0
+        return torch.nn.functional.pad(x, (0, (64 - W % 64) % 64, 0, (64 - H % 64) % 64), mode="reflect")
 
 
-def main():
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:  # noqa: BLE001
+        pass
+    return os.cpu_count() or 1
+
+
+def launch_children(args):
+    """`python bench.py --gpus N` started plainly: run the documented torch.distributed.run command as a child process
+    (this process has not touched the GPU), forward rank 0's JSON line, exit with the child's code."""
+    if torch.cuda.device_count() < args.gpus:      # (counting devices does not initialise the GPU)
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.exit(proc.returncode if (proc.returncode != 0 or line is not None) else 1)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -88,20 +170,31 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32",
                     help="fp32 = exact path (headline); fp16 = half-precision MFMA conv path of BASELINE configs[4]")
     ap.add_argument("--resolution", choices=["1080p", "2160p"], default="1080p")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="strong = BASELINE configs[3]: a fixed multi-sequence test set GOP-sharded over the ranks (LHBDC)")
+    ap.add_argument("--sequences", type=int, default=7, help="--scaling strong: sequences in the test set (UVG: 7)")
+    ap.add_argument("--frames-per-sequence", type=int, default=593,
+                    help="--scaling strong: frames per sequence (UVG: 600 -> 74 GOP-8s = 593 frames coded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gops-per-step", type=int, default=None,
                     help="LHBDC / Flex-Rate: independent GOPs coded per step and GPU with their hierarchy levels batched together "
                          "(default at 1080p: 4 / 2; 1 at 2160p)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel event timing table here (json)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_children(args)          # never returns
 
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -112,13 +205,14 @@ def main():
     from vcamd import gop as vgop
     from vcamd.seeding import seeded_state_dict
 
-    global H, W
-    if args.resolution == "2160p":
-        H, W = 2160, 3840
+    H, W = (2160, 3840) if args.resolution == "2160p" else (1080, 1920)
     hip.set_conv_precision(args.precision)
     f16 = args.precision == "fp16"
     is_flex = args.model == "flex"
     is_icip = args.model == "icip2024"
+    strong = args.scaling == "strong"
+    if strong and (is_flex or is_icip):
+        raise SystemExit("--scaling strong is BASELINE configs[3]: the LHBDC test loop")
     if is_icip:
         from vcamd import icip2024
         model = icip2024.FlowGuidedB()
@@ -132,54 +226,81 @@ def main():
     # the work per launch), 1 at 2160p where a level pass is already four 1080p frames' worth of pixels
     G = 1 if is_icip else (args.gops_per_step or ((2 if is_flex else 4) if args.resolution == "1080p" else 1))
 
-    # every rank codes its own GOP (GOP index = rank): weak scaling, per-GPU work fixed
-    frames = []
-    for g in range(G):
-        frames += synthetic_gop(1234, rank * G + g, dev, 17 if (is_flex or is_icip) else 9, (H, W))
-    records = []
-    # Flex: 4 rate points selected purely through the gain units (n = 0..3, l = 1), one per step in turn
-    rate_points = [{lvl: (n, 1.0) for lvl in range(4)} for n in range(4)]
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if is_icip:                     # quality levels 0..4 in turn; the per-frame flow-resolution search runs on the device
-        pool = None if args.no_graph else torch.cuda.graph_pool_handle()   # the five graphs replay in turn: one memory pool
-        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="icip2024", quality=lvl, pool=pool)
-                   for lvl in range(5)]
-    elif is_flex:
-        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="flex", quality=q, gops=G) for q in rate_points]
-    else:
-        runners = [None if args.no_graph else vgop.GopGraph(model, H, W, gops=G)]
-    counter = [0]
+    records = []
+    if strong:
+        # ---- BASELINE configs[3]: one fixed test set, contiguous GOP ranges per rank ----
+        from vcamd import iframe
+        i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
+        i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=4321, conv_gain=0.8))
+        i_model = i_model.to(dev).eval()
+        plan = vgop.workload_plan([args.frames_per_sequence] * args.sequences)
+        lo, hi = vgop.shard_gops(len(plan), world, rank)
+        data = SyntheticTestSet(args.sequences, args.frames_per_sequence, (H, W), dev)
+        for video, _, idxs in plan[lo:hi]:
+            for i in idxs:
+                data.materialise(video, i)
+        coder = vgop.LhbdcWorkloadCoder(model, i_model, data.frame, H, W, graph=not args.no_graph)
+        frames_total = len({(video, i) for video, _, idxs in plan for i in idxs})       # every frame of the set, coded once
 
-    def step(keep):
-        i = counter[0] % len(runners)
-        counter[0] += 1
-        recs = records if keep else None
-        if runners[i] is not None:
-            runners[i].code(frames, gop_index=rank * G, records=recs)
-        elif is_icip:
-            vgop.code_gop_icip2024(model, frames, frames[0], frames[16], H, W, i, recs, video=0, gop_index=rank)
+        def step(keep):
+            recs = vgop.code_workload(plan, world, rank, coder.intra, coder.code_gops, gops_per_pass=G)
+            if keep:
+                records.extend(recs)
+        n_warm = args.warmup
+        # capture the HIP graphs (full passes of G GOPs and the shorter last pass) before the clock, whatever --warmup is
+        with torch.no_grad():
+            for size in {min(G, hi - lo), (hi - lo) % G}:
+                if size > 0:
+                    vgop.code_workload(plan[lo:lo + size], 1, 0, coder.intra, coder.code_gops, gops_per_pass=G)
+    else:
+        # every rank codes its own GOPs (GOP index = rank * G + g): weak scaling, per-GPU work fixed
+        frames = []
+        for g in range(G):
+            frames += synthetic_gop(1234, rank * G + g, dev, 17 if (is_flex or is_icip) else 9, (H, W))
+        # Flex: 4 rate points selected purely through the gain units (n = 0..3, l = 1), one per step in turn
+        rate_points = [{lvl: (n, 1.0) for lvl in range(4)} for n in range(4)]
+        if is_icip:                     # quality levels 0..4 in turn; the per-frame flow-resolution search runs on the device
+            pool = None if args.no_graph else torch.cuda.graph_pool_handle()   # the five graphs replay in turn: one memory pool
+            runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="icip2024", quality=lvl, pool=pool)
+                       for lvl in range(5)]
         elif is_flex:
-            gops = [frames[17 * g:17 * g + 17] for g in range(G)]
-            vgop.code_gops_flex(model, gops, [(gp[0], gp[16]) for gp in gops], H, W, rate_points[i], recs, video=0,
-                                first_gop_index=rank * G)
+            runners = [None if args.no_graph else vgop.GopGraph(model, H, W, kind="flex", quality=q, gops=G) for q in rate_points]
         else:
-            gops = [frames[9 * g:9 * g + 9] for g in range(G)]
-            vgop.code_gops_lhbdc(model, gops, [(gp[0], gp[8]) for gp in gops], H, W, recs, video=0, first_gop_index=rank * G)
+            runners = [None if args.no_graph else vgop.GopGraph(model, H, W, gops=G)]
+        counter = [0]
+
+        def step(keep):
+            i = counter[0] % len(runners)
+            counter[0] += 1
+            recs = records if keep else None
+            if runners[i] is not None:
+                runners[i].code(frames, gop_index=rank * G, records=recs)
+            elif is_icip:
+                vgop.code_gop_icip2024(model, frames, frames[0], frames[16], H, W, i, recs, video=0, gop_index=rank)
+            elif is_flex:
+                gops = [frames[17 * g:17 * g + 17] for g in range(G)]
+                vgop.code_gops_flex(model, gops, [(gp[0], gp[16]) for gp in gops], H, W, rate_points[i], recs, video=0,
+                                    first_gop_index=rank * G)
+            else:
+                gops = [frames[9 * g:9 * g + 9] for g in range(G)]
+                vgop.code_gops_lhbdc(model, gops, [(gp[0], gp[8]) for gp in gops], H, W, recs, video=0, first_gop_index=rank * G)
+        n_warm = max(args.warmup, len(runners))          # every graph is captured before the clock starts
 
     with torch.no_grad():
-        for _ in range(max(args.warmup, len(runners))):   # every graph is captured before the clock starts
+        for _ in range(n_warm):
             step(False)
-        counter[0] = 0
+        if not strong:
+            counter[0] = 0
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i == args.steps - 1)
-        rows = vgop.gather_records(records, dev)      # the only exchange: final R-D gather (RCCL)
+        rows = vgop.gather_records(records, dev, width=7 if strong else 6)      # the only exchange: final R-D gather (RCCL)
         barrier()
         elapsed = time.perf_counter() - t0
     if world > 1:
@@ -187,188 +308,284 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    b_frames = per_gop * G * args.steps * world
+    coded_frames = (frames_total if strong else per_gop * G * world) * args.steps
     try:        # the headline configuration reports BASELINE.json's metric verbatim (UVG itself is unavailable: see "data")
         with open(os.path.join(ROOT, "BASELINE.json")) as f:
             headline_metric = json.load(f)["metric"]
     except (OSError, KeyError, ValueError):
         headline_metric = "frames/sec + bpp/PSNR on UVG 1080p GOP-8, 1/2/4/8 MI355X"
+    if strong:
+        workload = (f"UVG-shaped test set, {args.sequences} sequences x {args.frames_per_sequence} frames at {args.resolution} "
+                    f"({len(plan)} GOP-8s: I-frames through the mbt2018_mean q7 architecture + 7 B-frames through LHBDC "
+                    f"Model.forward), contiguous GOP ranges per rank, {G} GOPs per batched pass")
+    elif is_icip:
+        workload = (f"ICIP2024 FlowGuidedB {args.resolution} GOP-16: 15 B-frames per GOP via FlowGuidedB.forward with the "
+                    "per-frame flow-resolution search (5 flow+warp passes), quality level s=step%5, one GOP per GPU per step")
+    elif is_flex:
+        workload = (f"Flex-Rate b_model {args.resolution} GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
+                    f"n=step%4 through the gain units, {G} independent GOP(s) per GPU per step, hierarchy levels batched")
+    else:
+        workload = (f"LHBDC {args.resolution} GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
+                    f"{G} independent GOP(s) per GPU per step, hierarchy levels batched across them")
     result = {
-        # BASELINE.json: "frames/sec + bpp/PSNR on UVG 1080p GOP-8"; value = B-frames/s of the codec hot path,
-        # bpp/PSNR of the same frames in "quality" (UVG is not available offline -> synthetic video)
+        # BASELINE.json: "frames/sec + bpp/PSNR on UVG 1080p GOP-8"; value = frames/s of the codec hot path (B-frames; in
+        # the strong-scaling test-set mode every coded frame, I-frames included), bpp/PSNR of the same frames in "quality"
         "metric": (f"frames/sec + bpp/PSNR on {args.resolution} GOP-16 (ICIP2024 FlowGuidedB B-frame path, 5 quality levels)" if is_icip else
                    f"frames/sec + bpp/PSNR on {args.resolution} GOP-16 (Flex-Rate B-frame path, 4 rate points)" if is_flex else
                    headline_metric if (args.resolution == "1080p") else
                    f"frames/sec + bpp/PSNR on {args.resolution} GOP-8 (LHBDC B-frame codec path)"),
-        "value": b_frames / elapsed,
+        "value": coded_frames / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f16 operands / f32 accumulate (eligible convolutions), f32 elsewhere" if f16 else "f32",
         "data": f"synthetic (band-limited texture + global translation + 2% noise, {H}x{W} reflection-padded to x64); seeded random weights",
-        "config": {"workload": (f"ICIP2024 FlowGuidedB {args.resolution} GOP-16: 15 B-frames per GOP via FlowGuidedB.forward with the "
-                                "per-frame flow-resolution search (5 flow+warp passes), quality level s=step%5, one GOP per GPU per step"
-                                if is_icip else f"Flex-Rate b_model {args.resolution} GOP-16: 15 B-frames per GOP via BidirFlowRef.forward, rate point "
-                                f"n=step%4 through the gain units, {G} independent GOP(s) per GPU per step, hierarchy levels batched" if is_flex else
-                                f"LHBDC {args.resolution} GOP-8 inference, single lambda: 7 B-frames per GOP via Model.forward, "
-                                f"{G} independent GOP(s) per GPU per step, hierarchy levels batched across them"),
-                   "frames_per_step_per_gpu": per_gop * G, "gop": 16 if (is_flex or is_icip) else 8,
+        "config": {"workload": workload,
+                   "frames_per_step": (frames_total if strong else per_gop * G * world), "gop": 16 if (is_flex or is_icip) else 8,
                    "resolution": f"{W}x{H}", "precision": args.precision, "parallelism": f"gop-shard x{world}",
-                   "launch": "eager" if args.no_graph else "hip-graph per GOP"},
+                   "launch": "eager" if args.no_graph else "hip-graph per GOP pass"},
     }
+    if world > 1:
+        result["rccl_ranks"] = world
     result["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)   # of 288 GB, this rank, graphs included
-    q = vgop.summarize(rows)
-    result["quality"] = {"b_frames": q["frames"], "bpp_estimated": q["bpp"], "psnr_db": q["psnr"],
-                         "note": "seeded random weights: R-D values are parity references, not codec quality"}
+    if strong:
+        table = vgop.RdTable()
+        table.extend_from_records(rows.tolist(), level=7)
+        agg = table.per_level_frame_type()
+        allf = table.per_level()[7]
+        result["quality"] = {"frames": allf["frames"], "bpp_estimated": allf["bpp"], "psnr_db": allf["psnr"],
+                             "rd_table": {f"{k[1]}": v for k, v in agg.items()},
+                             "note": "seeded random weights: R-D values are parity references, not codec quality"}
+        if allf["frames"] != frames_total:
+            raise SystemExit(f"gathered {allf['frames']} frame records, the test set has {frames_total}")
+    else:
+        q = vgop.summarize(rows)
+        result["quality"] = {"b_frames": q["frames"], "bpp_estimated": q["bpp"], "psnr_db": q["psnr"],
+                             "note": "seeded random weights: R-D values are parity references, not codec quality"}
 
     if rank == 0 and world == 1:
-        # ---- roofline of the dominant kernel: HIP events on the launch stream, one instrumented B-frame ----
-        with torch.no_grad():
-            hip.timer = hip.KernelTimer()
-            if is_icip:
-                model(frames[0], frames[16], 0.5, 0.5, frames[8], 2, 1)
-            elif is_flex:
-                model(frames[0], frames[8], frames[16], n=[1], l=1.0)
-            else:
-                model(frames[0], frames[4], frames[8], False)
-            table = hip.timer.table()
-            hip.timer = None
-        total_ms = sum(v["ms"] for v in table.values())
-        ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
-        key, dom = ranked[0]
-        per_launch_flop = dom["flops"] / dom["launches"]
-        per_launch_bytes = dom["bytes"] / dom["launches"]
-        avg_ms = dom["ms"] / dom["launches"]
-        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
-        # which roofline bounds the dominant kernel: arithmetic intensity against the ridge peak_flops / peak_bandwidth
-        intensity = per_launch_flop / max(per_launch_bytes, 1.0)
-        if intensity >= peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
-            achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                                  "frac": achieved / peak, "traffic": None}
-        else:
-            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-            result["roofline"] = {"bound": "hbm", "kernel": key, "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                  "frac": achieved / PEAK_HBM_GBPS, "traffic": None,
-                                  "algorithmic_bytes_per_launch": per_launch_bytes}
-        result["roofline"].update({"launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
-                                   "share_of_conv_time": dom["ms"] / total_ms,
-                                   "algorithmic_flop_per_launch": per_launch_flop,
-                                   "flop_per_byte": intensity})
-        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (profiles/r01/traffic.json:
-        # FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 correction)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
-                tr = json.load(f)["kernels"].get(key)
-            if tr and not f16 and args.resolution == "1080p":
-                result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = "profiles/r01/traffic.json (rocprofv3 --pmc, separate passes)"
-        except (OSError, KeyError, ValueError):
-            pass
-        ns = [kv for kv in ranked if kv[0].startswith("conv k3 s1 128->128 @1x544x960")]
-        if ns:
-            v = ns[0][1]
-            a = v["flops"] / v["launches"] / (v["ms"] / v["launches"] * 1e-3) / 1e12
-            result["roofline_3x3_analysis_conv"] = {"kernel": ns[0][0], "achieved": a, "peak": peak,
-                                                    "unit": "TFLOP/s", "frac": a / peak,
-                                                    "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
-        all_flops = sum(v["flops"] for v in table.values())
-        result["conv_engine"] = {"frame_conv_ms": total_ms, "frame_conv_tflop": all_flops / 1e12,
-                                 "avg_tflops": all_flops / (total_ms * 1e-3) / 1e12}
-        if args.kernel_table:
-            with open(args.kernel_table, "w") as f:
-                json.dump({k: v for k, v in ranked}, f, indent=1)
-
-        if not is_flex and not is_icip and args.resolution == "1080p":
-            # ---- whole GOP as testing.py codes it: 1 I-frame (mbt2018_mean q7 architecture) + 7 B-frames ----
-            from vcamd import iframe
-            i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
-            i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=4321, conv_gain=0.8))
-            i_model = i_model.to(dev).eval()
-            with torch.no_grad():
-                def full_gop():
-                    dec_last, _ = i_model.forward_device(frames[8])
-                    return vgop.code_gop_lhbdc(model, frames, frames[0], dec_last, H, W)
-                full_gop()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(2):
-                    full_gop()
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 2
-            result["full_gop"] = {"frames_per_s": 8.0 / dt, "ms_per_gop": 1000.0 * dt,
-                                  "what": "1 I-frame (mbt2018_mean q7 architecture, seeded) + 7 B-frames per GOP, eager launches"}
-
-        if is_icip and args.resolution == "1080p":
-            # ---- whole GOP-16 as src/test.py codes it: 1 intra frame (ELIC architecture, seeded) + 15 B-frames ----
-            from vcamd.layers import BitCounter
-            i_model = icip2024.ELIC()
-            i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=4321, conv_gain=0.7))
-            i_model = i_model.to(dev).eval()
-            with torch.no_grad():
-                def full_gop():
-                    dec_last = hip.nhwc_to_nchw(i_model.forward_device(hip.nchw_to_nhwc(frames[16]), BitCounter(dev, 6)))
-                    return vgop.code_gop_icip2024(model, frames, frames[0], torch.clamp(dec_last, 0, 1), H, W, 2)
-                full_gop()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(2):
-                    full_gop()
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 2
-            result["full_gop"] = {"frames_per_s": 16.0 / dt, "ms_per_gop": 1000.0 * dt,
-                                  "what": "1 I-frame (ELIC architecture of src/model/elic.py, seeded) + 15 B-frames per GOP-16, "
-                                          "eager launches, quality level 2"}
-
-        # ---- CPU baseline: the oracle (PyTorch-CPU restatement, tensor-equal to the reference) ----
-        if not args.no_cpu_baseline and args.resolution == "1080p":
-            from oracle import flex as oracle_flex
-            from oracle import lhbdc as oracle_lhbdc
-            if is_icip:
-                from oracle import icip2024 as oracle_icip
-                ora = oracle_icip.FlowGuidedB().eval()
-            else:
-                ora = (oracle_flex.FlexModel(n=4) if is_flex else oracle_lhbdc.LhbdcModel()).eval()
-            ora.load_state_dict(sd)
-            torch.set_num_threads(pick_cpu_threads())
-            mid = 8 if (is_flex or is_icip) else 4
-            xb, xc, xa = frames[0].cpu(), frames[mid].cpu(), frames[2 * mid].cpu()
-            with torch.no_grad():
-                t1 = time.perf_counter()
-                if is_icip:
-                    o = ora(xb, xa, 0.5, 0.5, xc, 2, 1)
-                    ref_hat, ref_bits = o["x_hat"], float(o["size"].item())
-                elif is_flex:
-                    o = ora(xb, xc, xa, n=[1], l=1.0, train=False)
-                    ref_hat, ref_bits = o["x_hat"], float(o["size"].item())
-                else:
-                    ref_hat, _, ref_bits = ora(xb, xc, xa, False)
-                cpu_s = time.perf_counter() - t1
-                if is_icip:
-                    g = model(frames[0], frames[16], 0.5, 0.5, frames[8], 2, 1)
-                    gpu_hat, gpu_bits = g["x_hat"], float(g["size"].item())
-                elif is_flex:
-                    g = model(frames[0], frames[mid], frames[2 * mid], n=[1], l=1.0)
-                    gpu_hat, gpu_bits = g["x_hat"], float(g["size"].item())
-                else:
-                    gpu_hat, _, gpu_bits = model(frames[0], frames[4], frames[8], False)
-            result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(),
-                                      "kind": "port", "sample": "1 B-frame 1088x1920 (middle frame of the same GOP), "
-                                      "PyTorch-CPU fp32 oracle (tensor-equal to the reference), thread count "
-                                      "chosen by a conv micro-calibration"}
-            src = frames[mid]
-            d_psnr = abs(float(vgop.psnr_uint8(gpu_hat, src, H, W)) - float(vgop.psnr_uint8(ref_hat.to(dev), src, H, W)))
-            result["parity_vs_cpu"] = {"d_psnr_db": d_psnr, "bits_rel": abs(gpu_bits - ref_bits) / abs(ref_bits),
-                                       "max_abs": float((gpu_hat.cpu() - ref_hat).abs().max())}
+        if strong:
+            frames = synthetic_gop(1234, 0, dev, 9, (H, W))
+        single_gpu_extras(args, result, model, frames, sd, dev, H, W)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
+    """N = 1 only: roofline of the dominant kernel (HIP events on the launch stream), whole-GOP rate with the I-frame,
+    the CPU baseline (oracle timed on this host) and the parity of the same frame against it."""
+    from vcamd import gop as vgop
+    from vcamd import hip
+    from vcamd.seeding import seeded_state_dict
+    f16 = args.precision == "fp16"
+    is_flex = args.model == "flex"
+    is_icip = args.model == "icip2024"
+    mid = 8 if (is_flex or is_icip) else 4
+
+    def product_frame(trace=None):
+        if is_icip:
+            g = model(frames[0], frames[16], 0.5, 0.5, frames[8], 2, 1)
+            return g["x_hat"], float(g["size"].item())
+        if is_flex:
+            x_hat, tot = model.forward_device(frames[0], frames[mid], frames[2 * mid], n=[1], l=1.0, trace=trace)
+            return x_hat, float(tot.sum().item())
+        x_hat, tot = model.forward_device(frames[0], frames[mid], frames[2 * mid], trace=trace)
+        return x_hat, float(tot.sum().item())
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, one instrumented B-frame ----
+    with torch.no_grad():
+        hip.timer = hip.KernelTimer()
+        product_frame()
+        table = hip.timer.table()
+        hip.timer = None
+    total_ms = sum(v["ms"] for v in table.values())
+    ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
+    key, dom = ranked[0]
+    per_launch_flop = dom["flops"] / dom["launches"]
+    per_launch_bytes = dom["bytes"] / dom["launches"]
+    avg_ms = dom["ms"] / dom["launches"]
+    peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+    # which roofline bounds the dominant kernel: arithmetic intensity against the ridge peak_flops / peak_bandwidth
+    intensity = per_launch_flop / max(per_launch_bytes, 1.0)
+    if intensity >= peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
+        achieved = per_launch_flop / (avg_ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": key, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                              "frac": achieved / peak, "traffic": None}
+    else:
+        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": key, "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                              "frac": achieved / PEAK_HBM_GBPS, "traffic": None}
+    result["roofline"].update({"launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
+                               "share_of_conv_time": dom["ms"] / total_ms,
+                               "algorithmic_flop_per_launch": per_launch_flop,
+                               "algorithmic_bytes_per_launch": per_launch_bytes,
+                               "flop_per_byte": intensity})
+    # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected
+    # in separate runs and corrected as tools/pmc_traffic.py documents).  The file is stamped with a hash of the kernel
+    # sources it was measured on: a stale one is refused rather than quoted.
+    try:
+        with open(TRAFFIC_JSON) as f:
+            tj = json.load(f)
+        if tj.get("kernel_source_stamp") != kernel_source_stamp():
+            result["roofline"]["traffic_note"] = (f"{os.path.relpath(TRAFFIC_JSON, ROOT)} was measured on other kernel sources "
+                                                  "(stamp mismatch): re-run tools/pmc_traffic.py")
+        else:
+            tr = tj["kernels"].get(key)
+            if tr:
+                result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_over_algorithmic"] = tr["hbm_bytes_per_launch"] / per_launch_bytes
+                result["roofline"]["traffic_source"] = f"{os.path.relpath(TRAFFIC_JSON, ROOT)} (rocprofv3 --pmc, separate passes)"
+            # the two dominant 7x7 kernels take turns at the top of the table: always show the worse traffic ratio of the pair
+            pair = {k: v for k, v in tj["kernels"].items() if k.startswith("conv k7 s1") and k in table}
+            if pair:
+                worst = max(pair, key=lambda k: pair[k]["hbm_bytes_per_launch"] / (table[k]["bytes"] / table[k]["launches"]))
+                result["roofline"]["worst_traffic_ratio"] = {
+                    "kernel": worst, "traffic": pair[worst]["hbm_bytes_per_launch"],
+                    "over_algorithmic": pair[worst]["hbm_bytes_per_launch"] / (table[worst]["bytes"] / table[worst]["launches"])}
+    except (OSError, KeyError, ValueError):
+        pass
+    ns = [kv for kv in ranked if kv[0].startswith("conv k3 s1 128->128 @1x544x960")]
+    if ns:
+        v = ns[0][1]
+        a = v["flops"] / v["launches"] / (v["ms"] / v["launches"] * 1e-3) / 1e12
+        result["roofline_3x3_analysis_conv"] = {"kernel": ns[0][0], "achieved": a, "peak": peak,
+                                                "unit": "TFLOP/s", "frac": a / peak,
+                                                "avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"]}
+    all_flops = sum(v["flops"] for v in table.values())
+    result["conv_engine"] = {"frame_conv_ms": total_ms, "frame_conv_tflop": all_flops / 1e12,
+                             "avg_tflops": all_flops / (total_ms * 1e-3) / 1e12}
+    if args.kernel_table:
+        with open(args.kernel_table, "w") as f:
+            json.dump({k: v for k, v in ranked}, f, indent=1)
+
+    if not is_flex and not is_icip and args.resolution == "1080p" and args.scaling == "weak":
+        # ---- whole GOP as testing.py codes it: 1 I-frame (mbt2018_mean q7 architecture) + 7 B-frames ----
+        from vcamd import iframe
+        i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
+        i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=4321, conv_gain=0.8))
+        i_model = i_model.to(dev).eval()
+        with torch.no_grad():
+            def full_gop():
+                dec_last, _ = i_model.forward_device(frames[8])
+                return vgop.code_gop_lhbdc(model, frames, frames[0], dec_last, H, W)
+            full_gop()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                full_gop()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 2
+        result["full_gop"] = {"frames_per_s": 8.0 / dt, "ms_per_gop": 1000.0 * dt,
+                              "what": "1 I-frame (mbt2018_mean q7 architecture, seeded) + 7 B-frames per GOP, eager launches"}
+
+    if is_icip and args.resolution == "1080p":
+        # ---- whole GOP-16 as src/test.py codes it: 1 intra frame (ELIC architecture, seeded) + 15 B-frames ----
+        from vcamd import icip2024
+        from vcamd.layers import BitCounter
+        i_model = icip2024.ELIC()
+        i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=4321, conv_gain=0.7))
+        i_model = i_model.to(dev).eval()
+        with torch.no_grad():
+            def full_gop():
+                dec_last = hip.nhwc_to_nchw(i_model.forward_device(hip.nchw_to_nhwc(frames[16]), BitCounter(dev, 6)))
+                return vgop.code_gop_icip2024(model, frames, frames[0], torch.clamp(dec_last, 0, 1), H, W, 2)
+            full_gop()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                full_gop()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 2
+        result["full_gop"] = {"frames_per_s": 16.0 / dt, "ms_per_gop": 1000.0 * dt,
+                              "what": "1 I-frame (ELIC architecture of src/model/elic.py, seeded) + 15 B-frames per GOP-16, "
+                                      "eager launches, quality level 2"}
+
+    # ---- CPU baseline: the oracle (PyTorch-CPU restatement, tensor-equal to the reference), BASELINE.md section 3 ----
+    if not args.no_cpu_baseline and args.resolution == "1080p":
+        from oracle import flex as oracle_flex
+        from oracle import lhbdc as oracle_lhbdc
+        from oracle.cai.entropy_models import get_scale_table
+        from oracle.trace import CallLog, CodecTrace, symbol_mismatch
+        if is_icip:
+            from oracle import icip2024 as oracle_icip
+            ora = oracle_icip.FlowGuidedB().eval()
+        else:
+            ora = (oracle_flex.FlexModel(n=4) if is_flex else oracle_lhbdc.LhbdcModel()).eval()
+        ora.load_state_dict(sd)
+        xb, xc, xa = frames[0].cpu(), frames[mid].cpu(), frames[2 * mid].cpu()
+
+        def oracle_frame():
+            if is_icip:
+                o = ora(xb, xa, 0.5, 0.5, xc, 2, 1)
+                return o["x_hat"], float(o["size"].item())
+            if is_flex:
+                o = ora(xb, xc, xa, n=[1], l=1.0, train=False)
+                return o["x_hat"], float(o["size"].item())
+            x_hat, _, bits = ora(xb, xc, xa, False)
+            return x_hat, float(bits)
+
+        runs = {}
+        ref_hat = ref_bits = None
+        traces = None
+        with torch.no_grad():
+            # 1 warm-up + 3 timed calls, median; at 8 threads (comparable with BASELINE.md section 2) and at all physical cores
+            for threads in sorted({min(8, physical_cores()), physical_cores()}):
+                torch.set_num_threads(threads)
+                oracle_frame()
+                times = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    ref_hat, ref_bits = oracle_frame()
+                    times.append(time.perf_counter() - t1)
+                runs[threads] = {"threads": threads, "median_s_per_frame": statistics.median(times), "times_s": times}
+            # one more (untimed) call with the latent capture hooked in, for the integer parity figures below
+            if not is_icip:
+                mv_name = "flow_compressor" if is_flex else "mv_compressor"
+                with CodecTrace(getattr(ora, mv_name)) as t_mv, CodecTrace(ora.residual_compressor) as t_res, \
+                        CallLog(ora.Mask if is_flex else ora.masknet) as t_mask:
+                    ref_hat, ref_bits = oracle_frame()
+                    table_s = get_scale_table()
+                    mask_ref = t_mask.outputs[-1]
+                    traces = {"mv": t_mv.latents(table_s), "res": t_res.latents(table_s),
+                              "mask": torch.sigmoid(mask_ref) if is_flex else mask_ref}     # b_model.py:66 applies the sigmoid outside
+        best = min(runs.values(), key=lambda r: r["median_s_per_frame"])
+        result["cpu_baseline"] = {"value": 1.0 / best["median_s_per_frame"], "unit": "frames/s", "cores": best["threads"],
+                                  "kind": "port",
+                                  "sample": "1 B-frame 1088x1920 (middle frame of the same GOP) through the PyTorch-CPU fp32 oracle "
+                                            "(tensor-equal to the reference); 1 warm-up + 3 timed calls, median, at 8 threads and "
+                                            "at all physical cores -- value = the faster setting",
+                                  "runs": list(runs.values()), "host_physical_cores": physical_cores()}
+        with torch.no_grad():
+            trace = {} if not is_icip else None
+            gpu_hat, gpu_bits = product_frame(trace)
+        src = frames[mid]
+        d_psnr = abs(float(vgop.psnr_uint8(gpu_hat, src, H, W)) - float(vgop.psnr_uint8(ref_hat.to(dev), src, H, W)))
+        diff = (gpu_hat.cpu() - ref_hat).abs()
+        parity = {"d_psnr_db": d_psnr, "bits_rel": abs(gpu_bits - ref_bits) / abs(ref_bits),
+                  "max_abs": float(diff.max()), "pixels_over_1e-3": float((diff > 1e-3).float().mean())}
+        if traces is not None:
+            # the integers of the bitstream: quantised symbols of y and z for the motion and the residual codec
+            sym = {}
+            for name, key in (("mv", "flow" if is_flex else "mv"), ("res", "res")):
+                for which in ("y_sym", "z_sym"):
+                    n_bad, frac = symbol_mismatch(trace[key][which].cpu(), traces[name][which])
+                    sym[f"{name}_{which}"] = {"differ": n_bad, "of": int(traces[name][which].numel()), "fraction": frac}
+            parity["symbols_differ"] = sym
+            total = sum(v["of"] for v in sym.values())
+            parity["symbols_differ_fraction"] = sum(v["differ"] for v in sym.values()) / total
+            parity["stage_max_abs"] = {
+                "mask": float((hip.nhwc_to_nchw(trace["mask"]).cpu() - traces["mask"]).abs().max()),
+                "residual_codec_input": float((hip.nhwc_to_nchw(trace["resid"]).cpu() - traces["res"]["x"]).abs().max()),
+                "res_y": float((hip.nhwc_to_nchw(trace["res"]["y"]).cpu() - traces["res"]["y"]).abs().max()),
+                "res_scales": float((hip.nhwc_to_nchw(trace["res"]["scales"]).cpu() - traces["res"]["scales"]).abs().max())}
+        result["parity_vs_cpu"] = parity
 
 
 if __name__ == "__main__":

@@ -217,21 +217,24 @@ int vc_select_flow(vc_stream s, const double *sse, int count, double n_elems, co
  * logistic-CDF MLP, lower-bounded 1e-9; bits += sum(-log2 p) into bits_partial (see vc_bits_reduce).
  * `in_gain` (nullable, per channel) is Flex's hyper_gain_unit, `out_gain` (nullable) its
  * hyper_inv_gain_unit applied to the stored z_hat (layers.py:139-141).
- * symbols (nullable, int32 NCHW order n,c,y,x) receives round(z*gain - med) for the range coder. */
+ * symbols (nullable, int32 NCHW order n,c,y,x) receives round(z*gain - med) for the range coder.
+ * likelihoods (nullable, fp32, same dense NCHW order) receives the per-element likelihood tensor the reference's
+ * callers read as out["likelihoods"]["z"] (LHBDC/model/m.py:73-91, layers.py:72-91). */
 int vc_eb_forward(vc_stream s, vc_view z, const float *params, const float *in_gain, const float *out_gain,
-                  vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots);
+                  vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots, float *likelihoods);
 /* inverse for the decoder: z_hat = (sym + med) * out_gain */
 int vc_eb_dequant(vc_stream s, const int32_t *symbols, const float *params, const float *out_gain, vc_view z_hat);
 
 /* GaussianConditional.forward (eval) on y with (scales, means) = chunk(h_s output, 2):
  *   y_hat = (round(y*gain - mu) + mu) * out_gain ; p = Phi((.5-|v|)/s) - Phi((-.5-|v|)/s), s>=0.11, p>=1e-9.
  * sym_src (nullable) lets Flex's compress() quantise the UN-gained y (layers.py:167): symbols are
- * round(sym_src - mu) when given, else round(y*gain - mu).  indexes = build_indexes(scales) against
- * scale_table[n_scales] (nullable together with symbols). */
+ * round(sym_src - mu) when given, else round(y*gain - mu).  indexes (nullable, needs scale_table) =
+ * build_indexes(scales) against scale_table[n_scales].  likelihoods (nullable, fp32, dense NCHW order like
+ * symbols) receives out["likelihoods"]["y"]. */
 int vc_gc_forward(vc_stream s, vc_view y, vc_view scales, vc_view means, const float *in_gain,
                   const float *out_gain, vc_view y_hat, double *bits_partial, int bits_slots,
                   const float *sym_src_p, int32_t *symbols, int32_t *indexes, const float *scale_table,
-                  int n_scales);
+                  int n_scales, float *likelihoods);
 /* decoder side: indexes from scales; y_hat = (sym + mu) * out_gain */
 int vc_gc_indexes(vc_stream s, vc_view scales, const float *scale_table, int n_scales, int32_t *indexes);
 int vc_gc_dequant(vc_stream s, const int32_t *symbols, vc_view means, const float *out_gain, vc_view y_hat);
@@ -245,16 +248,17 @@ int vc_bits_slots(void);
  * Range coder (host).  Replaces compressai._CXX.pmf_to_quantized_cdf and
  * compressai.ans.RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes as called from
  * EntropyModel.compress/decompress (reached from LHBDC/model/layers.py:97-98,103,108,112).
- * cdfs: dense int32 [n_tables][cdf_stride].
+ * cdfs: dense int32 [n_tables][cdf_stride]; cdf_sizes / offsets: [n_tables].  Every index is checked against
+ * n_tables and every cdf_size against cdf_stride (VC_EINVAL) -- a corrupt index never reads outside the tables.
  * ---------------------------------------------------------------------------------------- */
 int vc_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf_out /* n+1 */);
 /* returns bytes written (>=0) or a negative VC_E* code; out_cap >= 4*(count*? ) -- use vc_rans_bound */
 size_t vc_rans_bound(size_t count);
 long long vc_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes, size_t count,
-                                      const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                      const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes,
                                       const int32_t *offsets, uint8_t *out, size_t out_cap);
 int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, const int32_t *indexes, size_t count,
-                                const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes,
                                 const int32_t *offsets, int32_t *symbols_out);
 
 /* ------------------------------------------------------------------------------------------
@@ -275,11 +279,11 @@ int vc_pad(vc_stream s, vc_view in, vc_view out);
 int vc_blend(vc_stream s, vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid);
 /* = vc_eb_forward / vc_gc_forward */
 int vc_factorized_bits(vc_stream s, vc_view z, const float *params, const float *in_gain, const float *out_gain,
-                       vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots);
+                       vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots, float *likelihoods);
 int vc_gaussian_symbols(vc_stream s, vc_view y, vc_view scales, vc_view means, const float *in_gain,
                         const float *out_gain, vc_view y_hat, double *bits_partial, int bits_slots,
                         const float *sym_src_p, int32_t *symbols, int32_t *indexes, const float *scale_table,
-                        int n_scales);
+                        int n_scales, float *likelihoods);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 
 from oracle import cai, deform as odeform, flex as oflex, icip2024 as oicip, lhbdc as olhbdc  # noqa: E402
+from oracle.trace import CodecTrace  # noqa: E402
 
 # The seeded-checkpoint generator is loaded by file: video-compression_amd/ must NOT be on sys.path here, it holds
 # packages named like the reference's (model/, b_model/, src/) that would shadow the modules this script pins against.
@@ -134,6 +135,27 @@ def check(name, a, b, tol=0.0):
         raise SystemExit(f"oracle restatement differs from the reference at {name}: {d}")
 
 
+def latent_arrays(prefix, trace, codec, strings, code_ungained_y=False):
+    """What the reference's entropy models saw during compress() -- codec input, y, z, scales, means -- and the integers
+    its range coder consumed (symbols, scale-table indexes).  Re-encoding those integers must give the reference's
+    strings back, else the capture is not what was coded."""
+    lat = trace.latents(codec.gaussian_conditional.scale_table, code_ungained_y=code_ungained_y)
+    gc, eb = codec.gaussian_conditional, codec.entropy_bottleneck
+    y_str = cai.ans.encode_with_indexes(lat["y_sym"][0].reshape(-1).numpy(), lat["y_idx"][0].reshape(-1).numpy(),
+                                        gc._quantized_cdf.numpy(), gc._cdf_length.reshape(-1).int().numpy(),
+                                        gc._offset.reshape(-1).int().numpy())
+    z_idx = eb._build_indexes(lat["z"].size())
+    z_str = cai.ans.encode_with_indexes(lat["z_sym"][0].reshape(-1).numpy(), z_idx[0].reshape(-1).int().numpy(),
+                                        eb._quantized_cdf.numpy(), eb._cdf_length.reshape(-1).int().numpy(),
+                                        eb._offset.reshape(-1).int().numpy())
+    if y_str != strings[0][0] or z_str != strings[1][0]:
+        raise SystemExit(f"captured {prefix} symbols do not reproduce the reference's strings")
+    print(f"    captured {prefix} latents: y {tuple(lat['y'].shape)} z {tuple(lat['z'].shape)}; symbols re-encode to the "
+          f"reference's strings")
+    out = {f"{prefix}_{k}": v.numpy() for k, v in lat.items() if k != "y_raw" or code_ungained_y}
+    return out
+
+
 def gen_lhbdc(outdir, frames, seed):
     ref_m = import_reference_lhbdc()
     torch.manual_seed(0)
@@ -189,7 +211,11 @@ def gen_lhbdc(outdir, frames, seed):
         print(f"  LHBDC codec fixture: crop y0={y0} x0={x0} {h}x{w}")
         c = crop(frames, y0, x0, h, w)
         xb, xc, xa = (enc["process_frame"](c[k].astype(float)) for k in ("ref_1", "current", "ref_2"))
-        mv_bits_r, res_bits_r = enc["encode_B"](ref, xa, xc, xb)
+        with CodecTrace(ref.mv_compressor) as tr_mv, CodecTrace(ref.residual_compressor) as tr_res:
+            mv_bits_r, res_bits_r = enc["encode_B"](ref, xa, xc, xb)
+            latents = latent_arrays("mv", tr_mv, ref.mv_compressor, mv_bits_r["strings"])
+            latents.update(latent_arrays("res", tr_res, ref.residual_compressor, res_bits_r["strings"]))
+        np.savez_compressed(os.path.join(outdir, "lhbdc_codec_latents_a.npz"), seed=np.int64(seed), **latents)
         mv_bits_o, res_bits_o = olhbdc.encode_B(ora, xa, xc, xb)
         for nm, r, o in (("mv", mv_bits_r, mv_bits_o), ("res", res_bits_r, res_bits_o)):
             for j, part in enumerate("yz"):
@@ -253,7 +279,12 @@ def gen_flex(outdir, frames, seed):
             comp_r.update(force=True)
             comp_o.update(force=True)
         n, l = 1, 1.0
-        mv_r, res_r = enc["encode_B"](ref, xb, xc, xa, n=n, l=l)
+        with CodecTrace(ref.flow_compressor) as tr_mv, CodecTrace(ref.residual_compressor) as tr_res:
+            mv_r, res_r = enc["encode_B"](ref, xb, xc, xa, n=n, l=l)
+            latents = latent_arrays("flow", tr_mv, ref.flow_compressor, mv_r["strings"], code_ungained_y=True)
+            latents.update(latent_arrays("res", tr_res, ref.residual_compressor, res_r["strings"], code_ungained_y=True))
+        np.savez_compressed(os.path.join(outdir, "flex_codec_latents_a.npz"), seed=np.int64(seed), n=np.int64(n),
+                            l=np.float64(l), **latents)
         mv_o, res_o = oflex.encode_B(ora, xb, xc, xa, n=n, l=l)
         for nm, r, o in (("flow", mv_r, mv_o), ("res", res_r, res_o)):
             for j, part in enumerate("yz"):

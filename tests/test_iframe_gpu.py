@@ -160,3 +160,39 @@ def test_sequence_loop_against_the_reference_test_function(dev):
     (bpp_ref, psnr_ref), = [(float(k), v) for k, v in fx["aggregate_bpp_to_psnr"]["per_level"].items()]
     agg = table.per_level()[7]
     assert abs(agg["bpp"] - bpp_ref) / bpp_ref < 1e-2 and abs(agg["psnr"] - psnr_ref) < 1e-2
+
+
+def test_config4_gop_shards_union_equals_single_rank(dev, codecs):
+    """BASELINE.json configs[3] (the multi-sequence set GOP-sharded over P GPUs, testing.py:99-188): the union of every
+    rank's records equals the single-rank run RECORD FOR RECORD (bit-identical PSNR and bits), for P in {2, 3, 8} on two
+    clips of 3 + 2 GOPs -- a GOP depends only on its two boundary I-frames, and intra frames on nothing.  The same code
+    path drives bench.py --scaling strong; the N > 1 process-group leg runs under gloo in test_dist_cpu.py."""
+    from helpers import lhbdc_pair
+    from vcamd import gop as vgop
+    _, i_model = codecs
+    _, b_model = lhbdc_pair(1234, dev)
+    g = torch.Generator().manual_seed(15)
+    base = torch.nn.functional.avg_pool2d(torch.rand(2, 3, 200, 300, generator=g), 9, 1)      # 192 x 292
+    clips = [[base[v:v + 1, :, :192, i:i + 256].contiguous().to(dev) for i in range(n)] for v, n in ((0, 25), (1, 17))]
+    plan = vgop.workload_plan([25, 17])
+    assert len(plan) == 5
+
+    def run(world, rank, per_pass, graph=False):
+        coder = vgop.LhbdcWorkloadCoder(b_model, i_model, lambda v, i: clips[v][i], 180, 250, graph=graph)
+        recs = vgop.code_workload(plan, world, rank, coder.intra, coder.code_gops, gops_per_pass=per_pass)
+        return [(int(r[0]), int(r[1]), int(r[2]), float(r[3]), float(r[4]), float(r[5]), int(r[6])) for r in recs]
+
+    with torch.no_grad():
+        whole = sorted(run(1, 0, 1))
+        assert len(whole) == 25 + 17 and len({r[:2] for r in whole}) == 42
+        for world in (2, 3, 8):
+            union = sorted(sum((run(world, r, 1) for r in range(world)), []))
+            assert union == whole, world
+        # GOPs batched per pass and the HIP-graph runner give the same records too
+        assert sorted(run(1, 0, 2)) == whole
+        assert sorted(run(2, 0, 2, graph=True) + run(2, 1, 2, graph=True)) == whole
+    rows = vgop.gather_records([tuple(r) for r in whole], dev)
+    table = vgop.RdTable()
+    table.extend_from_records(rows.tolist(), level=7)
+    agg = table.per_level_frame_type()
+    assert agg[(7, "I")]["frames"] == 7 and agg[(7, "B")]["frames"] == 35

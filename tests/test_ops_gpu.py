@@ -369,13 +369,16 @@ def test_entropy_kernels_exact_inputs(dev):
     zt = hip.nchw_to_nhwc(z.to(dev))
     z_hat = T.empty(zt.n, zt.h, zt.w, zt.c, dev)
     sym = torch.empty(z.numel(), dtype=torch.int32, device=dev)
+    lik_d = torch.empty(z.shape, dtype=torch.float32, device=dev)
     hip.check(hip.lib().vc_eb_forward(hip.stream(), zt.view(), eb.device_params().data_ptr(), None, None, z_hat.view(),
-                                      sym.data_ptr(), bits.next_row_ptr(), bits.slots), "eb")
+                                      sym.data_ptr(), bits.next_row_ptr(), bits.slots, lik_d.data_ptr()), "eb")
     assert torch.equal(hip.nhwc_to_nchw(z_hat).cpu(), z_ref)
     med = o.quantiles[:, 0, 1].detach().view(1, -1, 1, 1)
     assert torch.equal(sym.cpu().view(z.shape), torch.round(z - med).int())
     rb = (-torch.log2(lik)).sum().item()
     assert abs(bits.totals()[0].item() - rb) / rb < 1e-5
+    # the likelihood TENSOR the reference's callers read (m.py:73-91), element by element
+    assert ((lik_d.cpu() - lik).abs() / lik).max().item() < 2e-5
 
     gc = OGC(None)
     gc.update_scale_table(get_scale_table(), force=True)
@@ -391,15 +394,19 @@ def test_entropy_kernels_exact_inputs(dev):
     y_hat = T.empty(yt.n, yt.h, yt.w, yt.c, dev)
     sym = torch.empty(y.numel(), dtype=torch.int32, device=dev)
     idx = torch.empty_like(sym)
+    lik_d = torch.empty(y.shape, dtype=torch.float32, device=dev)
     table = gc.scale_table.to(dev)
     hip.check(hip.lib().vc_gc_forward(hip.stream(), yt.view(), st.view(), mt.view(), None, None, y_hat.view(),
                                       bits.next_row_ptr(), bits.slots, None, sym.data_ptr(), idx.data_ptr(),
-                                      table.data_ptr(), table.numel()), "gc")
+                                      table.data_ptr(), table.numel(), lik_d.data_ptr()), "gc")
     assert torch.equal(hip.nhwc_to_nchw(y_hat).cpu(), y_ref)
     assert torch.equal(sym.cpu().view(y.shape), torch.round(y - mu).int())
     assert torch.equal(idx.cpu().view(y.shape), idx_ref)
     rb = (-torch.log2(lik)).sum().item()
     assert abs(bits.totals()[0].item() - rb) / rb < 1e-5
+    # erfc differences of nearly equal values: absolute 1e-7 where the likelihood is tiny, relative 1e-4 elsewhere
+    dl = (lik_d.cpu() - lik).abs()
+    assert (dl <= 1e-7 + 1e-4 * lik).all(), float((dl / lik).max())
 
 
 PW_CASES = [(128, 128, 37, 75, 2), (64, 64, 33, 64, 1), (96, 96, 20, 50, 1), (32, 32, 16, 96, 3), (128, 64, 18, 40, 1),

@@ -88,3 +88,33 @@ def test_decoder_rejects_truncated_stream():
         hip.rans_decode(data[:len(data) // 2 // 4 * 4], idx, cdfs, sizes, offs)
     with pytest.raises(hip.VcError):
         hip.rans_decode(b"\x00\x00", idx, cdfs, sizes, offs)
+
+
+def test_extreme_bypass_values():
+    """The largest magnitudes the format defines: the folded value must stay below 2^28 (seven nibbles) -- the format's
+    own encoder counts nibbles with a 32-bit shift that is undefined beyond.  The product refuses larger values."""
+    sym = np.array([2 ** 27 - 1, -(2 ** 27), 2 ** 27 - 3, 0, 3, -(2 ** 26)], dtype=np.int32)
+    idx = np.zeros(sym.size, dtype=np.int32)
+    a = ans.encode_with_indexes(sym, idx, CDF, SIZES, OFFS)
+    b = hip.rans_encode(sym, idx, CDF, SIZES, OFFS)
+    assert a == b
+    assert hip.rans_decode(b, idx, CDF, SIZES, OFFS).tolist() == sym.tolist()
+    assert ans.decode_with_indexes(a, idx, CDF, SIZES, OFFS).tolist() == sym.tolist()
+    with pytest.raises(hip.VcError):
+        hip.rans_encode(np.array([2 ** 30], dtype=np.int32), idx[:1], CDF, SIZES, OFFS)
+
+
+def test_out_of_range_table_index_is_rejected_not_dereferenced():
+    sym = np.array([0, 1, 0], dtype=np.int32)
+    good = np.zeros(3, dtype=np.int32)
+    data = hip.rans_encode(sym, good, CDF, SIZES, OFFS)
+    for bad_value in (1, -1, 2 ** 20):
+        bad = np.array([0, bad_value, 0], dtype=np.int32)
+        with pytest.raises(hip.VcError):
+            hip.rans_encode(sym, bad, CDF, SIZES, OFFS)
+        with pytest.raises(hip.VcError):
+            hip.rans_decode(data, bad, CDF, SIZES, OFFS)
+    with pytest.raises(hip.VcError):                  # a table claiming more entries than its row holds
+        hip.rans_encode(sym, good, CDF, np.array([9], dtype=np.int32), OFFS)
+    with pytest.raises(hip.VcError):                  # one size / offset per table
+        hip.rans_encode(sym, good, CDF, np.array([4, 4], dtype=np.int32), OFFS)

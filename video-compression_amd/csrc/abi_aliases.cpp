@@ -51,16 +51,16 @@ extern "C" int vc_blend(vc_stream s, vc_view fwbw, vc_view mask, vc_view cur, vc
 }
 
 extern "C" int vc_factorized_bits(vc_stream s, vc_view z, const float *params, const float *in_gain, const float *out_gain,
-                                  vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots)
+                                  vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots, float *likelihoods)
 {
-    return vc_eb_forward(s, z, params, in_gain, out_gain, z_hat, symbols, bits_partial, bits_slots);
+    return vc_eb_forward(s, z, params, in_gain, out_gain, z_hat, symbols, bits_partial, bits_slots, likelihoods);
 }
 
 extern "C" int vc_gaussian_symbols(vc_stream s, vc_view y, vc_view scales, vc_view means, const float *in_gain,
                                    const float *out_gain, vc_view y_hat, double *bits_partial, int bits_slots,
                                    const float *sym_src_p, int32_t *symbols, int32_t *indexes, const float *scale_table,
-                                   int n_scales)
+                                   int n_scales, float *likelihoods)
 {
     return vc_gc_forward(s, y, scales, means, in_gain, out_gain, y_hat, bits_partial, bits_slots, sym_src_p, symbols, indexes,
-                         scale_table, n_scales);
+                         scale_table, n_scales, likelihoods);
 }

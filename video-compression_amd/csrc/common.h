@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "vc_hip.h"
 
 #define VC_LAUNCH_CHECK()                                   \
@@ -12,6 +13,21 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Kernels that need more than the default 64 KiB of dynamic LDS opt in once per kernel instance AND device (the
+// attribute belongs to the current device's copy of the function).  `raised` is the instance's own flag word, one bit
+// per device; two threads racing on a first launch at worst set the attribute twice, which is harmless.
+static inline bool vc_raise_lds_limit(const void *kern, size_t lds_bytes, std::atomic<uint64_t> &raised)
+{
+    if (lds_bytes <= 64 * 1024) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (raised.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return false;
+    raised.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 
 static inline hipStream_t as_stream(vc_stream s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -519,15 +519,8 @@ template <int KH, int KW, int S, int CK, class C, bool F16 = false> int launch_c
     typedef ConvGeom<KH, KW, S, CK, C> G;
     constexpr size_t lds_bytes = (G::LDS_FLOATS + 4) * sizeof(float);   // + the staging dump slot
     auto kern = conv_mfma_kernel<KH, KW, S, CK, C, F16>;
-    if (lds_bytes > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instance
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes) != hipSuccess)
-                return VC_ELAUNCH;
-            raised = true;
-        }
-    }
+    static std::atomic<uint64_t> raised{0};      // per instance; one bit per device (common.h)
+    if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.total_blocks), dim3(256), lds_bytes, st, a);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
 }

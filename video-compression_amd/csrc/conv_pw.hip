@@ -171,15 +171,8 @@ template <int KQ, int NT, bool F16, bool INH, int EPI = 0> int launch_pw(hipStre
 {
     const size_t lds_bytes = (size_t)(NT * KQ * 256 + NT * 32) * sizeof(float);
     auto kern = conv_pw_kernel<KQ, NT, F16, INH, EPI>;
-    if (lds_bytes > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes) != hipSuccess)
-                return VC_ELAUNCH;
-            raised = true;
-        }
-    }
+    static std::atomic<uint64_t> raised{0};
+    if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
     const long long ntiles = (long long)a.N * a.H * ((a.W + 31) / 32);
     long long blocks = (ntiles + 3) / 4;
     if (blocks > 1024) blocks = 1024;               // persistent workgroups: up to four per CU (registers/LDS allow 2-4)

@@ -63,7 +63,8 @@ __device__ __forceinline__ float eb_logits(const float *__restrict__ q, float x)
 __global__ void __launch_bounds__(ENT_BLOCK) k_eb_forward(vc_view z, const float *__restrict__ params,
                                                           const float *__restrict__ in_gain,
                                                           const float *__restrict__ out_gain, vc_view zh,
-                                                          int32_t *__restrict__ symbols, double *__restrict__ partial)
+                                                          int32_t *__restrict__ symbols, double *__restrict__ partial,
+                                                          float *__restrict__ likelihoods)
 {
     __shared__ double sm[ENT_BLOCK / 64];
     double bits = 0.0;
@@ -87,19 +88,21 @@ __global__ void __launch_bounds__(ENT_BLOCK) k_eb_forward(vc_view z, const float
         lik = fmaxf(lik, 1e-9f);
         bits -= (double)log2f(lik);
         if (zh.p) zh.p[view_off(zh, n, y, x) + c] = out_gain ? zq * out_gain[c] : zq;
-        if (symbols) symbols[(((long long)n * z.c + c) * z.h + y) * z.w + x] = (int32_t)sym;
+        const long long o = (((long long)n * z.c + c) * z.h + y) * z.w + x;
+        if (symbols) symbols[o] = (int32_t)sym;
+        if (likelihoods) likelihoods[o] = lik;
     }
     const double r = block_sum(bits, sm);
     if (threadIdx.x == 0 && partial) partial[blockIdx.x] = r;
 }
 
 extern "C" int vc_eb_forward(vc_stream s, vc_view z, const float *params, const float *in_gain, const float *out_gain,
-                             vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots)
+                             vc_view z_hat, int32_t *symbols, double *bits_partial, int bits_slots, float *likelihoods)
 {
     if (!z.p || !params) return VC_EINVAL;
     if (bits_partial && bits_slots != ENT_SLOTS) return VC_EINVAL;
     hipLaunchKernelGGL(k_eb_forward, dim3(ENT_SLOTS), dim3(ENT_BLOCK), 0, as_stream(s), z, params, in_gain, out_gain,
-                       z_hat, symbols, bits_partial);
+                       z_hat, symbols, bits_partial, likelihoods);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -141,7 +144,8 @@ __global__ void __launch_bounds__(ENT_BLOCK) k_gc_forward(vc_view yv, vc_view sc
                                                           const float *__restrict__ out_gain, vc_view yh,
                                                           double *__restrict__ partial, const float *__restrict__ sym_src,
                                                           int32_t *__restrict__ symbols, int32_t *__restrict__ indexes,
-                                                          const float *__restrict__ table, int n_scales)
+                                                          const float *__restrict__ table, int n_scales,
+                                                          float *__restrict__ likelihoods)
 {
     __shared__ double sm[ENT_BLOCK / 64];
     double bits = 0.0;
@@ -167,11 +171,10 @@ __global__ void __launch_bounds__(ENT_BLOCK) k_gc_forward(vc_view yv, vc_view sc
         const float lik = fmaxf(upper - lower, 1e-9f);
         bits -= (double)log2f(lik);
         if (yh.p) yh.p[view_off(yh, n, y, x) + c] = out_gain ? yq * out_gain[c] : yq;
-        if (symbols) {
-            const long long o = (((long long)n * yv.c + c) * yv.h + y) * yv.w + x;
-            symbols[o] = sym_src ? (int32_t)rintf(sym_src[oy] - m) : (int32_t)q;
-            indexes[o] = scale_index(s, table, n_scales);
-        }
+        const long long o = (((long long)n * yv.c + c) * yv.h + y) * yv.w + x;
+        if (symbols) symbols[o] = sym_src ? (int32_t)rintf(sym_src[oy] - m) : (int32_t)q;
+        if (indexes) indexes[o] = scale_index(s, table, n_scales);
+        if (likelihoods) likelihoods[o] = lik;
     }
     const double r = block_sum(bits, sm);
     if (threadIdx.x == 0 && partial) partial[blockIdx.x] = r;
@@ -180,13 +183,14 @@ __global__ void __launch_bounds__(ENT_BLOCK) k_gc_forward(vc_view yv, vc_view sc
 extern "C" int vc_gc_forward(vc_stream s, vc_view y, vc_view scales, vc_view means, const float *in_gain,
                              const float *out_gain, vc_view y_hat, double *bits_partial, int bits_slots,
                              const float *sym_src_p, int32_t *symbols, int32_t *indexes, const float *scale_table,
-                             int n_scales)
+                             int n_scales, float *likelihoods)
 {
     if (!y.p || !scales.p || !means.p) return VC_EINVAL;
     if (bits_partial && bits_slots != ENT_SLOTS) return VC_EINVAL;
-    if (symbols && (!indexes || !scale_table || n_scales < 2)) return VC_EINVAL;
+    if (indexes && (!scale_table || n_scales < 2)) return VC_EINVAL;
+    if (sym_src_p && !symbols) return VC_EINVAL;
     hipLaunchKernelGGL(k_gc_forward, dim3(ENT_SLOTS), dim3(ENT_BLOCK), 0, as_stream(s), y, scales, means, in_gain, out_gain,
-                       y_hat, bits_partial, sym_src_p, symbols, indexes, scale_table, n_scales);
+                       y_hat, bits_partial, sym_src_p, symbols, indexes, scale_table, n_scales, likelihoods);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }

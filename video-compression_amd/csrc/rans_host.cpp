@@ -13,6 +13,15 @@
 #include "vc_hip.h"
 
 namespace {
+// every table must fit its row and hold at least one real bin + the escape bin
+bool tables_ok(const int32_t *cdf_sizes, int n_tables, int cdf_stride)
+{
+    if (n_tables < 1 || cdf_stride < 3) return false;
+    for (int t = 0; t < n_tables; ++t)
+        if (cdf_sizes[t] < 3 || cdf_sizes[t] > cdf_stride) return false;
+    return true;
+}
+
 constexpr uint32_t kProbBits = 16;
 constexpr uint32_t kBypassBits = 4;
 constexpr uint32_t kBypassMax = (1u << kBypassBits) - 1u;
@@ -48,11 +57,12 @@ struct Encoder {
 extern "C" size_t vc_rans_bound(size_t count) { return 4 * (2 * count + 4); }
 
 extern "C" long long vc_rans_encode_with_indexes(const int32_t *symbols, const int32_t *indexes, size_t count,
-                                                 const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
-                                                 const int32_t *offsets, uint8_t *out, size_t out_cap)
+                                                 const int32_t *cdfs, int n_tables, int cdf_stride,
+                                                 const int32_t *cdf_sizes, const int32_t *offsets, uint8_t *out, size_t out_cap)
 {
     if ((count && (!symbols || !indexes)) || !cdfs || !cdf_sizes || !offsets || !out || out_cap < 8) return VC_EINVAL;
     if (reinterpret_cast<uintptr_t>(out) % 4) return VC_EINVAL;
+    if (!tables_ok(cdf_sizes, n_tables, cdf_stride)) return VC_EINVAL;
     const size_t cap_words = out_cap / 4;
     uint32_t *base = reinterpret_cast<uint32_t *>(out);
     Encoder enc;
@@ -60,6 +70,7 @@ extern "C" long long vc_rans_encode_with_indexes(const int32_t *symbols, const i
     enc.floor = base + 2;  // keep room for the final flush
     for (size_t i = count; i-- > 0;) {
         const int32_t t = indexes[i];
+        if (static_cast<uint32_t>(t) >= static_cast<uint32_t>(n_tables)) return VC_EINVAL;
         const int32_t *cdf = cdfs + static_cast<size_t>(t) * cdf_stride;
         const int32_t escape = cdf_sizes[t] - 2;
         int32_t v = symbols[i] - offsets[t];
@@ -69,8 +80,11 @@ extern "C" long long vc_rans_encode_with_indexes(const int32_t *symbols, const i
         }
         // out-of-table value: sign/magnitude folded into `raw`, sent as nibbles after the escape bin
         const uint32_t raw = v < 0 ? static_cast<uint32_t>(-2 * v - 1) : static_cast<uint32_t>(2 * (v - escape));
+        // (the format's own encoder counts nibbles with `raw >> (n*4)` on a 32-bit value: undefined from 2^28 on, so
+        //  magnitudes that need an eighth nibble have no defined encoding -- refuse them)
+        if (raw >> 28) return VC_EINVAL;
         int32_t nibbles = 0;
-        while (nibbles < 8 && (raw >> (nibbles * kBypassBits)) != 0) ++nibbles;
+        while ((raw >> (nibbles * kBypassBits)) != 0) ++nibbles;
         for (int32_t j = nibbles - 1; j >= 0; --j) enc.put_nibble((raw >> (j * kBypassBits)) & kBypassMax);
         // nibble count in base-15 "unary" chunks; forward order is 15,15,...,rest -> reverse: rest first
         enc.put_nibble(static_cast<uint32_t>(nibbles) % kBypassMax);
@@ -87,10 +101,11 @@ extern "C" long long vc_rans_encode_with_indexes(const int32_t *symbols, const i
 }
 
 extern "C" int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, const int32_t *indexes, size_t count,
-                                           const int32_t *cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                           const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes,
                                            const int32_t *offsets, int32_t *out)
 {
     if (!data || nbytes < 8 || (nbytes % 4) || (count && (!indexes || !out)) || !cdfs || !cdf_sizes || !offsets) return VC_EINVAL;
+    if (!tables_ok(cdf_sizes, n_tables, cdf_stride)) return VC_EINVAL;
     const size_t nwords = nbytes / 4;
     size_t pos = 0;
     auto next_word = [&](uint32_t &w) -> bool {
@@ -111,14 +126,15 @@ extern "C" int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, c
             x = (x << 32) | w;
         }
     };
-    auto nibble = [&]() -> int32_t {
-        const int32_t v = static_cast<int32_t>(x & kBypassMax);
+    auto nibble = [&]() -> uint32_t {
+        const uint32_t v = static_cast<uint32_t>(x & kBypassMax);
         x >>= kBypassBits;
         refill();
         return v;
     };
     for (size_t i = 0; i < count; ++i) {
         const int32_t t = indexes[i];
+        if (static_cast<uint32_t>(t) >= static_cast<uint32_t>(n_tables)) return VC_EINVAL;
         const int32_t *cdf = cdfs + static_cast<size_t>(t) * cdf_stride;
         const int32_t n = cdf_sizes[t], escape = n - 2;
         const uint32_t cum = static_cast<uint32_t>(x & 0xFFFFu);
@@ -143,17 +159,17 @@ extern "C" int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, c
         refill();
         int32_t v = sidx;
         if (v == escape) {
-            int32_t got = nibble(), nibbles = got;
-            while (got == static_cast<int32_t>(kBypassMax)) {
+            uint32_t got = nibble(), nibbles = got;
+            while (got == kBypassMax) {
                 got = nibble();
                 nibbles += got;
-                if (bad) break;
+                if (bad || nibbles > 7) break;
             }
-            if (nibbles > 8) return VC_EDATA;
-            int32_t raw = 0;
-            for (int32_t k = 0; k < nibbles; ++k) raw |= nibble() << (k * kBypassBits);
-            v = static_cast<int32_t>(static_cast<uint32_t>(raw) >> 1);
-            if (raw & 1) v = -v - 1; else v += escape;
+            if (nibbles > 7) return VC_EDATA;      // no encoder of this format emits more than 7 (see the encoder)
+            uint32_t raw = 0;
+            for (uint32_t k = 0; k < nibbles; ++k) raw |= nibble() << (k * kBypassBits);
+            v = static_cast<int32_t>(raw >> 1);
+            if (raw & 1u) v = -v - 1; else v += escape;
         }
         if (bad) return VC_EDATA;
         out[i] = v + offsets[t];
@@ -187,5 +203,5 @@ extern "C" int vc_pmf_to_quantized_cdf(const float *pmf, int n, int precision, u
     return VC_OK;
 }
 
-extern "C" const char *vc_version(void) { return "vc_hip 0.1 (round 1)"; }
+extern "C" const char *vc_version(void) { return "vc_hip 0.2 (round 2)"; }
 extern "C" const char *vc_target_arch(void) { return "gfx950"; }

@@ -126,6 +126,13 @@ class Gain_Module(nn.Module):
         return self._cache[key]
 
 
+def _require_inference(codec):
+    """Noise quantisation (entropy models in training mode) is outside the inference hot path: refuse it loudly."""
+    if codec.entropy_bottleneck.training or codec.gaussian_conditional.training:
+        raise NotImplementedError("the entropy models are in training mode (noise quantisation): call .eval() -- "
+                                  "only the inference path is built")
+
+
 class _GainedCodec(MeanScaleHyperprior):
     def __init__(self, n, in_ch, out_ch, N=128, bias=False, zero_last=False, **kwargs):
         super().__init__(N=N, M=N, **kwargs)
@@ -159,14 +166,19 @@ class _GainedCodec(MeanScaleHyperprior):
                 self.hyper_gain_unit.vector(n, l), self.hyper_inv_gain_unit.vector(n, l))
 
     def forward(self, x, n=None, l=None, train=False):
-        if train:
-            raise NotImplementedError("training-mode (noise) quantisation is outside the inference hot path")
+        """{"x_hat", "likelihoods": {"y","z"}} like layers.py:133-151 (+ "bits": the -log2 sums, reduced on the device).
+        ``train`` only sets ``self.training`` there (layers.py:134): whether the entropy models quantise with noise
+        is decided by THEIR training flags, so on an ``.eval()`` model train=True computes exactly the same thing."""
+        self.training = train
+        _require_inference(self)
         _require_cuda(x)
-        bits = BitCounter(x.device)
-        x_hat = self.forward_t(hip.nchw_to_nhwc(x), bits, self.gains(n, l))
+        bits = BitCounter(x.device, max_rows=2 * x.shape[0])
+        lik = {}
+        x_hat = self.forward_t(hip.nchw_to_nhwc(x), bits, self.gains(n, l), likelihoods=lik)
         tot = bits.totals()
         tot = tot.view(-1, 2)       # rows are (y, z) per image; the reference sums over the whole batch
-        return {"x_hat": hip.nhwc_to_nchw(x_hat), "bits": {"y": tot[:, 0].sum(), "z": tot[:, 1].sum()}}
+        return {"x_hat": hip.nhwc_to_nchw(x_hat), "likelihoods": lik,
+                "bits": {"y": tot[:, 0].sum(), "z": tot[:, 1].sum()}}
 
     def compress(self, x, n, l):
         _require_cuda(x)
@@ -226,7 +238,7 @@ class BidirFlowRef(nn.Module):
         hip.warp(hip.WARP_W2, buf.channels(7, 10), ft1, out=buf.channels(13, 16))
         return buf
 
-    def _compensate_t(self, buf, flow_hat, cur=None):
+    def _compensate_t(self, buf, flow_hat, cur=None, trace=None):
         """b_model.py:61-73: refine the motion, warp, 2-channel mask, normalised blend (+ residual)."""
         n, h, w, dev = buf.n, buf.h, buf.w, buf.buf.device
         L = hip.lib()
@@ -237,6 +249,8 @@ class BidirFlowRef(nn.Module):
         hip.warp(hip.WARP_W2, buf.channels(4, 7), mbuf.channels(0, 2), out=mbuf.channels(10, 13))
         hip.warp(hip.WARP_W2, buf.channels(7, 10), mbuf.channels(2, 4), out=mbuf.channels(13, 16))
         mask = self.Mask.run(mbuf, final_act=hip.ACT_SIGMOID)
+        if trace is not None:
+            trace.update({"mbuf": mbuf, "mask": mask})
         pred = T.empty(n, h, w, 3, dev)
         resid = T.empty(n, h, w, 3, dev) if cur is not None else None
         hip.check(L.vc_flex_blend(hip.stream(), mbuf.channels(10, 13).view(), mbuf.channels(13, 16).view(), mask.view(),
@@ -250,7 +264,7 @@ class BidirFlowRef(nn.Module):
         return (hip.nhwc_to_nchw(buf.channels(0, 2)), hip.nhwc_to_nchw(buf.channels(2, 4)),
                 hip.nhwc_to_nchw(buf.channels(0, 16)))
 
-    def forward_device(self, x_before, x_current, x_after, n=None, l=1):
+    def forward_device(self, x_before, x_current, x_after, n=None, l=1, trace=None):
         """B-frame path with no host synchronisation (graph-capturable): (x_hat, bits[B,4] float64 device tensor =
         flow.y, flow.z, res.y, res.z per frame).  A batch codes B independent frames at the SAME rate point (n, l) --
         the frames of one hierarchy level of a GOP (gop.code_gop_flex)."""
@@ -259,15 +273,20 @@ class BidirFlowRef(nn.Module):
         dev, b = xc_.device, xc_.shape[0]
         buf = self._process_t(xb_, xa_, xc_)
         bits = BitCounter(dev, max_rows=4 * b)
-        flow_hat = self.flow_compressor.forward_t(buf, bits, self.flow_compressor.gains(n, l))
-        pred, resid = self._compensate_t(buf, flow_hat, cur=buf.channels(16, 19))
-        res_hat = self.residual_compressor.forward_t(resid, bits, self.residual_compressor.gains(n, l))
+        t_mv, t_res = ({}, {}) if trace is not None else (None, None)     # parity instrumentation (tests / bench.py)
+        flow_hat = self.flow_compressor.forward_t(buf, bits, self.flow_compressor.gains(n, l), trace=t_mv)
+        pred, resid = self._compensate_t(buf, flow_hat, cur=buf.channels(16, 19), trace=trace)
+        res_hat = self.residual_compressor.forward_t(resid, bits, self.residual_compressor.gains(n, l), trace=t_res)
+        if trace is not None:
+            trace.update({"buf": buf, "flow_hat": flow_hat, "pred": pred, "resid": resid, "flow": t_mv, "res": t_res})
         # rows: flow (y, z) per image, then residual (y, z) per image
         return hip.nhwc_to_nchw(hip.axpby(pred, res_hat)), bits.totals().view(2, b, 2).permute(1, 0, 2).reshape(b, 4)
 
     def forward(self, x_before, x_current, x_after, n=None, l=1, train=False):
-        if train:
-            raise NotImplementedError("training-mode (noise) quantisation is outside the inference hot path")
+        # b_model.py:49-96: ``train`` is handed to the compressors, where it only sets their own .training attribute
+        for comp in (self.flow_compressor, self.residual_compressor):
+            comp.training = train
+            _require_inference(comp)
         if x_current.shape[0] != 1:   # per-item sizes: run items one by one (the reference harness uses batch 1)
             outs = [self.forward(x_before[i:i + 1], x_current[i:i + 1], x_after[i:i + 1], n, l, train)
                     for i in range(x_current.shape[0])]
@@ -281,31 +300,38 @@ class BidirFlowRef(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # CLI functions (test/encode_B.py, test/decode_B.py)
 # ------------------------------------------------------------------------------------------------
-def encode_B(model, x_before, x_current, x_after, n=None, l=1.0, train=False):
+def encode_B(model, x_before, x_current, x_after, n=None, l=1.0, train=False, trace=None):
+    """test/encode_B.py:72-122.  ``trace``: a dict that receives {"flow": {...}, "res": {...}} = the coder's integers."""
     for t in (x_before, x_current, x_after):
         _require_cuda(t)
     xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
     dev = xc_.device
     buf = model._process_t(xb_, xa_, xc_)
     fc, rc = model.flow_compressor, model.residual_compressor
-    strings, shape = fc.compress_t(buf, fc.gains([n], l), code_ungained_y=True)
+    t_mv, t_res = ({}, {}) if trace is not None else (None, None)
+    strings, shape = fc.compress_t(buf, fc.gains([n], l), code_ungained_y=True, trace=t_mv)
     mv_bits = {"strings": strings, "shape": torch.Size(shape)}
-    flow_hat = fc.forward_t(buf, BitCounter(dev), fc.gains([n], l))    # un-clamped (encode_B.py:92-93)
+    flow_hat = fc.forward_t(buf, BitCounter(dev, max_rows=2 * buf.n), fc.gains([n], l))    # un-clamped (encode_B.py:92-93)
     _, resid = model._compensate_t(buf, flow_hat, cur=buf.channels(16, 19))
-    strings, shape = rc.compress_t(resid, rc.gains([n], l), code_ungained_y=True)
+    strings, shape = rc.compress_t(resid, rc.gains([n], l), code_ungained_y=True, trace=t_res)
+    if trace is not None:
+        trace.update({"flow": t_mv, "res": t_res})
     return mv_bits, {"strings": strings, "shape": torch.Size(shape)}
 
 
-def decode_B(model, x_before, x_after, string_flow, string_res, shape_flow, shape_res, n, l):
+def decode_B(model, x_before, x_after, string_flow, string_res, shape_flow, shape_res, n, l, trace=None):
     for t in (x_before, x_after):
         _require_cuda(t)
     xb_, xa_ = x_before.contiguous().float(), x_after.contiguous().float()
     dev = xb_.device
     buf = model._process_t(xb_, xa_, None)
     fc, rc = model.flow_compressor, model.residual_compressor
-    flow_hat = fc.decompress_t(string_flow, shape_flow, dev, fc.gains([n], l), final_act=hip.ACT_CLAMP01)
+    t_mv, t_res = ({}, {}) if trace is not None else (None, None)
+    flow_hat = fc.decompress_t(string_flow, shape_flow, dev, fc.gains([n], l), final_act=hip.ACT_CLAMP01, trace=t_mv)
     pred, _ = model._compensate_t(buf, flow_hat)
-    res_hat = rc.decompress_t(string_res, shape_res, dev, rc.gains([n], l), final_act=hip.ACT_CLAMP01)
+    res_hat = rc.decompress_t(string_res, shape_res, dev, rc.gains([n], l), final_act=hip.ACT_CLAMP01, trace=t_res)
+    if trace is not None:
+        trace.update({"flow": t_mv, "res": t_res})
     return hip.nhwc_to_nchw(hip.axpby(res_hat, pred))
 
 

@@ -363,28 +363,45 @@ def shard_gops(num_gops, world_size, rank):
     return lo, hi
 
 
-def gather_records(records, device):
+def gather_records(records, device, width=None):
     """All-gather per-frame R-D records over the default process group (RCCL on GPUs, gloo on CPU) and
-    return them sorted in (video, frame) order on every rank.  Payload is a few KB: latency-bound."""
+    return them sorted in (video, frame) order on every rank.  Payload is a few KB: latency-bound.
+    Records are (video, frame, level, psnr, bits, pixels) or, from the sequence loops, the same + is_intra; a rank
+    without records (more ranks than GOPs) passes ``width`` or takes part with the 7-column layout."""
     import torch.distributed as dist
-    rows = [[float(v), float(f), float(l), float(p), float(b), float(px)] for v, f, l, p, b, px in records]
-    local = torch.tensor(rows, dtype=torch.float64, device=device).reshape(-1, 6)
+    if width is None:
+        width = len(records[0]) if records else 7
+    if any(len(r) != width for r in records):
+        raise ValueError("records of one gather must all have the same number of fields")
+    # psnr / bits are device scalars (no host sync inside a GOP): stack them on the device, one D2H at the very end
+    cols = []
+    for j in range(width):
+        vals = [r[j] for r in records]
+        if any(isinstance(v, torch.Tensor) for v in vals):
+            cols.append(torch.stack([v.to(device=device, dtype=torch.float64).reshape(()) if isinstance(v, torch.Tensor)
+                                     else torch.tensor(float(v), dtype=torch.float64, device=device) for v in vals]))
+        else:
+            cols.append(torch.tensor([float(v) for v in vals], dtype=torch.float64, device=device))
+    local = torch.stack(cols, 1) if records else torch.zeros((0, width), dtype=torch.float64, device=device)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         allrows = local
     else:
         world = dist.get_world_size()
-        count = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+        count = torch.tensor([local.shape[0], width], dtype=torch.int64, device=device)
         counts = [torch.zeros_like(count) for _ in range(world)]
         dist.all_gather(counts, count)
-        m = int(max(c.item() for c in counts))
-        padded = torch.zeros((m, 6), dtype=torch.float64, device=device)
+        counts = [c.cpu() for c in counts]
+        if any(int(c[1]) != width for c in counts if int(c[0]) > 0):
+            raise ValueError("ranks disagree on the record layout")
+        m = max(1, int(max(int(c[0]) for c in counts)))
+        padded = torch.zeros((m, width), dtype=torch.float64, device=device)
         padded[: local.shape[0]] = local
         parts = [torch.zeros_like(padded) for _ in range(world)]
         dist.all_gather(parts, padded)
-        allrows = torch.cat([p[: int(c.item())] for p, c in zip(parts, counts)], 0)
+        allrows = torch.cat([p[: int(c[0])] for p, c in zip(parts, counts)], 0)
     allrows = allrows.cpu()
     key = allrows[:, 0] * 1e9 + allrows[:, 1]
-    return allrows[torch.argsort(key)]
+    return allrows[torch.argsort(key, stable=True)]
 
 
 def summarize(rows):
@@ -453,6 +470,91 @@ def code_sequence_lhbdc(b_model, i_model, load_frame, num_available, h, w, video
             code_gop_lhbdc(b_model, gop, dec_first, dec_last, h, w, recs, video, g)
         records.extend(r + (0,) for r in recs)
     return records
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3]: the whole test set (7 UVG sequences in testing.py:99-188), GOP-sharded across GPUs
+# ------------------------------------------------------------------------------------------------------
+def workload_plan(frames_per_video, gop_size=8, test_size=0):
+    """The GOPs of a multi-video test set in the order testing.py walks them (video by video, GOP by GOP):
+    [(video, gop_in_video, [source frame index of the gop_size+1 dataset items])].  ``frames_per_video``: frames
+    available per video; ``test_size`` as UVGTestDataset (0 = all frames)."""
+    plan = []
+    for video, n in enumerate(frames_per_video):
+        for g, idxs in enumerate(gop_batches(uvg_frame_indices(n, gop_size, test_size), gop_size)):
+            plan.append((video, g, list(idxs)))
+    return plan
+
+
+def code_workload(plan, world_size, rank, intra, code_gops, gops_per_pass=1):
+    """Rank ``rank``'s contiguous share (:func:`shard_gops`) of a :func:`workload_plan`, with NO data-path exchange:
+    a GOP needs only its two boundary I-frames, and intra frames depend on nothing, so a shard that starts inside a
+    video codes that boundary frame itself (it is RECORDED by the rank that owns the GOP it closes).
+
+    ``intra(video, frame_idx) -> (decoded, record_tail)`` codes one I-frame; ``record_tail`` = (psnr, bits, pixels).
+    ``code_gops(items, bounds) -> records`` codes the B-frames of up to ``gops_per_pass`` GOPs in one batched pass:
+    ``items`` = plan entries, ``bounds`` = per GOP (decoded first, decoded last); returns 6-field records
+    (video, frame, level, psnr, bits, pixels) with frame = gop_in_video * gop_size + order.
+    Returns 7-field records (…, is_intra) in coding order; the union over all ranks is exactly the single-rank result."""
+    lo, hi = shard_gops(len(plan), world_size, rank)
+    records, batch, prev = [], [], None
+
+    def flush():
+        if batch:
+            recs = code_gops([b[0] for b in batch], [(b[1], b[2]) for b in batch])
+            records.extend(tuple(r) + (0,) for r in recs)
+            batch.clear()
+
+    for k in range(lo, hi):
+        video, g, idxs = plan[k]
+        if prev is not None and prev[0] == video and prev[1] == idxs[0]:
+            dec_first = prev[2]
+        else:
+            dec_first, tail = intra(video, idxs[0])
+            if g == 0:                            # frame 0 of a video belongs to its first GOP
+                records.append((video, idxs[0], -1) + tuple(tail) + (1,))
+        dec_last, tail = intra(video, idxs[-1])
+        records.append((video, idxs[-1], -1) + tuple(tail) + (1,))
+        batch.append((plan[k], dec_first, dec_last))
+        if len(batch) == gops_per_pass:
+            flush()
+        prev = (video, idxs[-1], dec_last)
+    flush()
+    return records
+
+
+class LhbdcWorkloadCoder:
+    """The two callbacks of :func:`code_workload` on the HIP path: mbt2018_mean I-frames + LHBDC B-frames, ``G`` GOPs per
+    pass with their hierarchy levels batched (one HIP graph per pass size when ``graph``)."""
+
+    def __init__(self, b_model, i_model, load_frame, h, w, graph=True):
+        self.b_model, self.i_model, self.load_frame, self.h, self.w, self.graph = b_model, i_model, load_frame, h, w, graph
+        self.runners = {}
+
+    def intra(self, video, idx):
+        x = self.load_frame(video, idx)
+        x_hat, tot = self.i_model.forward_device(x)
+        return x_hat, (psnr_uint8(x_hat, x, self.h, self.w), tot.sum(), float(self.h * self.w))
+
+    def code_gops(self, items, bounds):
+        recs = []
+        gops = [[self.load_frame(v, i) for i in idxs] for v, _, idxs in items]
+        if self.graph:
+            g = len(items)
+            if g not in self.runners:
+                self.runners[g] = GopGraph(self.b_model, self.h, self.w, gops=g)
+            frames = []
+            for gp, (first, last) in zip(gops, bounds):
+                frames += [first] + gp[1:-1] + [last]
+            self.runners[g].code(frames, gop_index=0, records=recs)
+            out = []
+            for j, r in enumerate(recs):          # the runner numbers GOPs 0..g-1: re-label with the plan's (video, gop)
+                video, gop_in_video, _ = items[j // 7]
+                out.append((video, gop_in_video * 8 + int(r[1]) % 8) + tuple(r[2:]))
+            return out
+        for (video, gop_in_video, _), gp, (first, last) in zip(items, gops, bounds):
+            code_gop_lhbdc(self.b_model, gp, first, last, self.h, self.w, recs, video, gop_in_video)
+        return recs
 
 
 def code_sequence_flex(b_model, i_models, load_frame, num_available, h, w, quality, video=0, gop_size=16, test_size=2):

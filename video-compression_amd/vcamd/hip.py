@@ -132,9 +132,9 @@ def lib():
     sig("vc_attention_gate", ci, vp, View, View, View, View)
     sig("vc_sse_clamp01", ci, vp, View, View, vp, ci)
     sig("vc_select_flow", ci, vp, vp, ci, ctypes.c_double, ctypes.POINTER(View), View, vp)
-    sig("vc_eb_forward", ci, vp, View, vp, vp, vp, View, vp, vp, ci)
+    sig("vc_eb_forward", ci, vp, View, vp, vp, vp, View, vp, vp, ci, vp)
     sig("vc_eb_dequant", ci, vp, vp, vp, vp, View)
-    sig("vc_gc_forward", ci, vp, View, View, View, vp, vp, View, vp, ci, vp, vp, vp, vp, ci)
+    sig("vc_gc_forward", ci, vp, View, View, View, vp, vp, View, vp, ci, vp, vp, vp, vp, ci, vp)
     sig("vc_gc_indexes", ci, vp, View, vp, ci, vp)
     sig("vc_gc_dequant", ci, vp, vp, View, vp, View)
     sig("vc_bits_reduce", ci, vp, vp, ci, ci, vp)
@@ -143,8 +143,8 @@ def lib():
     sig("vc_pad", ci, vp, View, View)
     sig("vc_pmf_to_quantized_cdf", ci, vp, ci, ci, vp)
     sig("vc_rans_bound", sz, sz)
-    sig("vc_rans_encode_with_indexes", cll, vp, vp, sz, vp, ci, vp, vp, vp, sz)
-    sig("vc_rans_decode_with_indexes", ci, vp, sz, vp, sz, vp, ci, vp, vp, vp)
+    sig("vc_rans_encode_with_indexes", cll, vp, vp, sz, vp, ci, ci, vp, vp, vp, sz)
+    sig("vc_rans_decode_with_indexes", ci, vp, sz, vp, sz, vp, ci, ci, vp, vp, vp)
     _lib = L
     return L
 
@@ -528,13 +528,22 @@ def _i32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
 
 
-def rans_encode(symbols, indexes, cdfs, cdf_sizes, offsets):
-    sym, idx = _i32(symbols).reshape(-1), _i32(indexes).reshape(-1)
+def _tables(cdfs, cdf_sizes, offsets):
     cdfs = _i32(cdfs)
     sizes, offs = _i32(cdf_sizes).reshape(-1), _i32(offsets).reshape(-1)
+    if cdfs.ndim != 2 or sizes.size != cdfs.shape[0] or offs.size != cdfs.shape[0]:
+        raise VcError("range-coder tables: cdfs must be [n_tables, stride] with one size and one offset per table")
+    return cdfs, sizes, offs
+
+
+def rans_encode(symbols, indexes, cdfs, cdf_sizes, offsets):
+    sym, idx = _i32(symbols).reshape(-1), _i32(indexes).reshape(-1)
+    if sym.size != idx.size:
+        raise VcError("range coder: one table index per symbol")
+    cdfs, sizes, offs = _tables(cdfs, cdf_sizes, offsets)
     cap = lib().vc_rans_bound(sym.size)
     out = np.empty(cap // 4, dtype=np.uint32)
-    n = lib().vc_rans_encode_with_indexes(sym.ctypes.data, idx.ctypes.data, sym.size, cdfs.ctypes.data,
+    n = lib().vc_rans_encode_with_indexes(sym.ctypes.data, idx.ctypes.data, sym.size, cdfs.ctypes.data, cdfs.shape[0],
                                           cdfs.shape[1], sizes.ctypes.data, offs.ctypes.data, out.ctypes.data, cap)
     if n < 0:
         check(int(n), "vc_rans_encode_with_indexes")
@@ -543,11 +552,10 @@ def rans_encode(symbols, indexes, cdfs, cdf_sizes, offsets):
 
 def rans_decode(data, indexes, cdfs, cdf_sizes, offsets):
     idx = _i32(indexes).reshape(-1)
-    cdfs = _i32(cdfs)
-    sizes, offs = _i32(cdf_sizes).reshape(-1), _i32(offsets).reshape(-1)
+    cdfs, sizes, offs = _tables(cdfs, cdf_sizes, offsets)
     buf = np.frombuffer(data, dtype=np.uint8)
     out = np.empty(idx.size, dtype=np.int32)
     check(lib().vc_rans_decode_with_indexes(buf.ctypes.data, buf.size, idx.ctypes.data, idx.size, cdfs.ctypes.data,
-                                            cdfs.shape[1], sizes.ctypes.data, offs.ctypes.data, out.ctypes.data),
+                                            cdfs.shape[0], cdfs.shape[1], sizes.ctypes.data, offs.ctypes.data, out.ctypes.data),
           "vc_rans_decode_with_indexes")
     return out

@@ -365,7 +365,7 @@ class _Elic(JointAutoregressiveHierarchicalPriors):
         z = self.seq("h_a", y, final_chscale=hypergain)
         for i in range(n):                                           # one counter row per image and tensor
             hip.check(L.vc_eb_forward(hip.stream(), z.images(i, i + 1).view(), self.entropy_bottleneck.device_params().data_ptr(),
-                                      None, None, hip.NULL_VIEW, None, bits.next_row_ptr(), bits.slots), "vc_eb_forward")
+                                      None, None, hip.NULL_VIEW, None, bits.next_row_ptr(), bits.slots, None), "vc_eb_forward")
         z_hat = hip.quantize_mask(z, gain=invhypergain)
         fusion_in = T.empty(n, h, w, 2 * M, dev)                       # [h_s(z_hat) | temporal condition]
         self.seq("h_s", z_hat, out=fusion_in.channels(0, M))
@@ -390,7 +390,7 @@ class _Elic(JointAutoregressiveHierarchicalPriors):
                 hip.check(L.vc_gc_forward(hip.stream(), y.channels(c0, c1).images(j, j + 1).view(),
                                           gp.channels(0, half).images(j, j + 1).view(),
                                           gp.channels(half, 2 * half).images(j, j + 1).view(), None, None, hip.NULL_VIEW,
-                                          bits.next_row_ptr(), bits.slots, None, None, None, None, 0), "vc_gc_forward")
+                                          bits.next_row_ptr(), bits.slots, None, None, None, None, 0, None), "vc_gc_forward")
         y_hat = hip.quantize_mask(y, gain=invgain)
         xhat3 = self.seq("g_s3", y_hat)
         head3 = self._head("g_o3", [xhat3, f3d], res[2])
@@ -498,7 +498,7 @@ class ELIC(JointAutoregressiveHierarchicalPriors):
         dev, n, h, w = y.buf.device, y.n, y.h, y.w
         for i in range(n):
             hip.check(L.vc_eb_forward(hip.stream(), z.images(i, i + 1).view(), self.entropy_bottleneck.device_params().data_ptr(),
-                                      None, None, hip.NULL_VIEW, None, bits.next_row_ptr(), bits.slots), "vc_eb_forward")
+                                      None, None, hip.NULL_VIEW, None, bits.next_row_ptr(), bits.slots, None), "vc_eb_forward")
         params_in = T.empty(n, h, w, 6 * M, dev)                       # [ctx | channel ctx | hyper]
         hyper = self.seq("h_s", hip.quantize_mask(z), out=params_in.channels(4 * M, 6 * M))
         params_in0 = T.empty(n, h, w, 4 * M, dev)                      # group 0: [ctx | hyper]
@@ -522,7 +522,7 @@ class ELIC(JointAutoregressiveHierarchicalPriors):
                 hip.check(L.vc_gc_forward(hip.stream(), y.channels(c0, c1).images(j, j + 1).view(),
                                           gp.channels(0, half).images(j, j + 1).view(),
                                           gp.channels(half, 2 * half).images(j, j + 1).view(), None, None, hip.NULL_VIEW,
-                                          bits.next_row_ptr(), bits.slots, None, None, None, None, 0), "vc_gc_forward")
+                                          bits.next_row_ptr(), bits.slots, None, None, None, None, 0, None), "vc_gc_forward")
         return self.seq("g_s", y_round)
 
     def forward(self, x):

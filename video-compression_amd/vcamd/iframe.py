@@ -35,17 +35,20 @@ class ImageMeanScaleHyperprior(MeanScaleHyperprior):
         self.h_s = nn.Sequential(deconv(N, M), nn.LeakyReLU(inplace=True), deconv(M, M * 3 // 2),
                                  nn.LeakyReLU(inplace=True), conv(M * 3 // 2, M * 2, stride=1, kernel_size=3))
 
-    def forward_device(self, x):
+    def forward_device(self, x, likelihoods=None):
         """(x_hat NCHW, bits float64 device tensor [n, 2] = per image (y, z)); no host sync."""
         _require_cuda(x)
         n = x.shape[0]
         bits = BitCounter(x.device, max_rows=2 * n)
-        x_hat = self.forward_t(hip.nchw_to_nhwc(x.contiguous().float()), bits)
+        x_hat = self.forward_t(hip.nchw_to_nhwc(x.contiguous().float()), bits, likelihoods=likelihoods)
         return hip.nhwc_to_nchw(x_hat), bits.totals().view(n, 2)
 
     def forward(self, x):
-        x_hat, tot = self.forward_device(x)
-        return {"x_hat": x_hat, "bits": {"y": tot[:, 0].sum(), "z": tot[:, 1].sum()}}
+        """{"x_hat", "likelihoods": {"y","z"}} as compressai's MeanScaleHyperprior.forward returns (what image_compress
+        reads: LHBDC/test/testing.py:58-63), plus "bits" = their -log2 sums reduced on the device."""
+        lik = {}
+        x_hat, tot = self.forward_device(x, likelihoods=lik)
+        return {"x_hat": x_hat, "likelihoods": lik, "bits": {"y": tot[:, 0].sum(), "z": tot[:, 1].sum()}}
 
     def compress(self, x):
         _require_cuda(x)

@@ -417,16 +417,21 @@ class BitCounter:
 
     def __init__(self, device, max_rows=16):
         self.slots = hip.lib().vc_bits_slots()
-        self.partial = torch.zeros(max_rows * self.slots, dtype=torch.float64, device=device)
-        self.out = torch.zeros(max_rows, dtype=torch.float64, device=device)
+        self.max_rows = int(max_rows)
+        self.partial = torch.zeros(self.max_rows * self.slots, dtype=torch.float64, device=device)
+        self.out = torch.zeros(self.max_rows, dtype=torch.float64, device=device)
         self.rows = 0
 
     def next_row_ptr(self):
+        if self.rows >= self.max_rows:      # a row past the end would be written into a neighbouring allocation
+            raise hip.VcError(f"BitCounter: all {self.max_rows} rows are in use (size it from the batch: rows per image x images)")
         ptr = self.partial.data_ptr() + 8 * self.rows * self.slots
         self.rows += 1
         return ptr
 
     def totals(self):
+        if self.rows == 0:
+            raise hip.VcError("BitCounter: no rows were written")
         hip.check(hip.lib().vc_bits_reduce(hip.stream(), self.partial.data_ptr(), self.slots, self.rows,
                                            self.out.data_ptr()), "vc_bits_reduce")
         return self.out[: self.rows]
@@ -473,8 +478,12 @@ class MeanScaleHyperprior(_Prepared):
         """(gain, inv_gain, hyper_gain, hyper_inv_gain) device vectors or Nones (Flex overrides)."""
         return None, None, None, None
 
-    def forward_t(self, x, bits, gains=(None, None, None, None)):
-        """x: T [n,h,w,c_in] -> x_hat T; appends two rows (y then z) to the BitCounter."""
+    def forward_t(self, x, bits, gains=(None, None, None, None), likelihoods=None, trace=None):
+        """x: T [n,h,w,c_in] -> x_hat T; appends two rows (y then z) PER IMAGE to the BitCounter.
+        ``likelihoods``: a dict that receives the per-element likelihood tensors "y" [n,M,h/16,w/16] and "z"
+        [n,N,h/64,w/64] (NCHW fp32 CUDA tensors, what CompressAI's forward returns under "likelihoods").
+        ``trace``: a dict that receives the analysis outputs and the quantised integers (parity instrumentation of the
+        tests and bench.py: "y", "z", "scales", "means" as T windows, "y_sym" / "z_sym" int32 NCHW device tensors)."""
         g, ig, hg, hig = gains
         L = hip.lib()
         y = run_sequential(self.g_a, x, self._cache["g_a"], final_chscale=g)      # gained y when g is set
@@ -482,19 +491,33 @@ class MeanScaleHyperprior(_Prepared):
         z_hat = T.empty(z.n, z.h, z.w, z.c, z.buf.device)
         # one (y, z) pair of counter rows PER IMAGE, so a batch of independent frames keeps per-frame sizes
         rows = [(bits.next_row_ptr(), bits.next_row_ptr()) for _ in range(z.n)]
+        lik_y = lik_z = None
+        if likelihoods is not None:
+            lik_z = torch.empty((z.n, z.c, z.h, z.w), dtype=torch.float32, device=z.buf.device)
+            lik_y = torch.empty((y.n, y.c, y.h, y.w), dtype=torch.float32, device=y.buf.device)
+            likelihoods["y"], likelihoods["z"] = lik_y, lik_z
+        sym_y = sym_z = None
+        if trace is not None:
+            sym_z = torch.empty((z.n, z.c, z.h, z.w), dtype=torch.int32, device=z.buf.device)
+            sym_y = torch.empty((y.n, y.c, y.h, y.w), dtype=torch.int32, device=y.buf.device)
+            trace.update({"y": y, "z": z, "y_sym": sym_y, "z_sym": sym_z})
         for i in range(z.n):
             hip.check(L.vc_eb_forward(hip.stream(), z.images(i, i + 1).view(), self.entropy_bottleneck.device_params().data_ptr(),
                                       None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
-                                      z_hat.images(i, i + 1).view(), None, rows[i][1], bits.slots), "vc_eb_forward")
+                                      z_hat.images(i, i + 1).view(), None if sym_z is None else sym_z[i].data_ptr(),
+                                      rows[i][1], bits.slots, None if lik_z is None else lik_z[i].data_ptr()), "vc_eb_forward")
         gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
+        if trace is not None:
+            trace.update({"scales": scales, "means": means})
         y_hat = T.empty(y.n, y.h, y.w, y.c, y.buf.device)
         for i in range(y.n):
             hip.check(L.vc_gc_forward(hip.stream(), y.images(i, i + 1).view(), scales.images(i, i + 1).view(),
                                       means.images(i, i + 1).view(), None, None if ig is None else ig.data_ptr(),
                                       y_hat.images(i, i + 1).view(), rows[i][0], bits.slots,
-                                      None, None, None, None, 0), "vc_gc_forward")
+                                      None, None if sym_y is None else sym_y[i].data_ptr(), None, None, 0,
+                                      None if lik_y is None else lik_y[i].data_ptr()), "vc_gc_forward")
         return run_sequential(self.g_s, y_hat, self._cache["g_s"])
 
     def _scale_table_dev(self):
@@ -505,8 +528,10 @@ class MeanScaleHyperprior(_Prepared):
             gc._packed = gc.scale_table.detach().float().contiguous().to(gc.scale_bound.device)
         return gc._packed
 
-    def compress_t(self, x, gains=(None, None, None, None), code_ungained_y=False):
-        """Analysis + symbolisation on the GPU, range coding on the host.  Returns (strings, (hz,wz))."""
+    def compress_t(self, x, gains=(None, None, None, None), code_ungained_y=False, trace=None):
+        """Analysis + symbolisation on the GPU, range coding on the host.  Returns (strings, (hz,wz)).
+        ``trace``: a dict that receives the integers handed to the range coder ("y_sym", "y_idx", "z_sym": host int32
+        arrays [n, count]) -- parity instrumentation."""
         g, ig, hg, hig = gains
         L = hip.lib()
         dev = x.buf.device
@@ -523,7 +548,7 @@ class MeanScaleHyperprior(_Prepared):
         z_sym = torch.empty(z.n * z.c * z.h * z.w, dtype=torch.int32, device=dev)
         hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
                                   None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
-                                  z_hat.view(), z_sym.data_ptr(), None, 0), "vc_eb_forward")
+                                  z_hat.view(), z_sym.data_ptr(), None, 0, None), "vc_eb_forward")
         gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
@@ -532,11 +557,13 @@ class MeanScaleHyperprior(_Prepared):
         table = self._scale_table_dev()
         hip.check(L.vc_gc_forward(hip.stream(), y.view(), scales.view(), means.view(), None, None, hip.NULL_VIEW,
                                   None, 0, None if y_raw is None else y_raw.ptr, y_sym.data_ptr(), y_idx.data_ptr(),
-                                  table.data_ptr(), table.numel()), "vc_gc_forward")
+                                  table.data_ptr(), table.numel(), None), "vc_gc_forward")
         # single D2H of the integer symbols, then the serial coder on the host
         z_sym_h = z_sym.cpu().numpy().reshape(z.n, -1)
         y_sym_h = y_sym.cpu().numpy().reshape(y.n, -1)
         y_idx_h = y_idx.cpu().numpy().reshape(y.n, -1)
+        if trace is not None:
+            trace.update({"y_sym": y_sym_h, "y_idx": y_idx_h, "z_sym": z_sym_h})
         eb_cdf, eb_len, eb_off = self.entropy_bottleneck.tables()
         gc_cdf, gc_len, gc_off = self.gaussian_conditional.tables()
         z_index = np.repeat(np.arange(z.c, dtype=np.int32), z.h * z.w)
@@ -544,7 +571,8 @@ class MeanScaleHyperprior(_Prepared):
         y_strings = [hip.rans_encode(y_sym_h[i], y_idx_h[i], gc_cdf, gc_len, gc_off) for i in range(y.n)]
         return [y_strings, z_strings], (z.h, z.w)
 
-    def decompress_t(self, strings, shape, device, gains=(None, None, None, None), final_act=None):
+    def decompress_t(self, strings, shape, device, gains=(None, None, None, None), final_act=None, trace=None):
+        """``trace``: a dict that receives the decoder's integers ("z_sym", "y_idx", "y_sym": host int32 [n, count])."""
         assert isinstance(strings, list) and len(strings) == 2
         g, ig, hg, hig = gains
         L = hip.lib()
@@ -567,7 +595,11 @@ class MeanScaleHyperprior(_Prepared):
         hip.check(L.vc_gc_indexes(hip.stream(), scales.view(), table.data_ptr(), table.numel(), idx_d.data_ptr()),
                   "vc_gc_indexes")
         idx_h = idx_d.cpu().numpy().reshape(n, -1)
+        if trace is not None:
+            trace.update({"z_sym": z_sym, "y_idx": idx_h})
         y_sym = np.stack([hip.rans_decode(strings[0][i], idx_h[i], gc_cdf, gc_len, gc_off) for i in range(n)])
+        if trace is not None:
+            trace["y_sym"] = y_sym
         y_sym_d = torch.from_numpy(y_sym).to(device)
         y_hat = T.empty(n, gp.h, gp.w, m, device)
         hip.check(L.vc_gc_dequant(hip.stream(), y_sym_d.data_ptr(), means.view(), None if ig is None else ig.data_ptr(),

@@ -145,14 +145,16 @@ class _LhbdcCodec(MeanScaleHyperprior):
             ResidualBlock(N, N), subpel_conv3x3(N, io_channels, 2))
 
     def forward(self, x):
-        """{"x_hat": NCHW tensor, "bits": {"y","z"}}.  The reference returns per-element likelihood tensors
-        under "likelihoods"; here -log2 of them is summed on the device (what m.py:73-91 does with them)."""
+        """{"x_hat": NCHW tensor, "likelihoods": {"y","z"}} like layers.py:72-91, plus "bits": {"y","z"} = the
+        -log2 sums of the same likelihoods reduced on the device (what m.py:73-91 computes from the tensors)."""
         _require_cuda(x)
-        bits = BitCounter(x.device)
-        x_hat = self.forward_t(hip.nchw_to_nhwc(x), bits)
+        bits = BitCounter(x.device, max_rows=2 * x.shape[0])
+        lik = {}
+        x_hat = self.forward_t(hip.nchw_to_nhwc(x), bits, likelihoods=lik)
         tot = bits.totals()
         tot = tot.view(-1, 2)       # rows are (y, z) per image; the reference sums over the whole batch
-        return {"x_hat": hip.nhwc_to_nchw(x_hat), "bits": {"y": tot[:, 0].sum(), "z": tot[:, 1].sum()}}
+        return {"x_hat": hip.nhwc_to_nchw(x_hat), "likelihoods": lik,
+                "bits": {"y": tot[:, 0].sum(), "z": tot[:, 1].sum()}}
 
     def compress(self, x):
         _require_cuda(x)
@@ -269,7 +271,7 @@ class Model(nn.Module):
         hp, wp = flow.h // 4, flow.w // 4
         return hip.avgpool_reflectpad(flow, 4, scale, hp + _pad64(hp), wp + _pad64(wp)), hp, wp
 
-    def _predict(self, xb, xa, mv_hat, flow_ab, flow_ba, hh, ww, cur=None):
+    def _predict(self, xb, xa, mv_hat, flow_ab, flow_ba, hh, ww, cur=None, trace=None):
         """m.py:55-67: add the predictors back, crop, x4 bilinear, warp both references, mask, blend.
         Returns (pred, resid or None)."""
         dev = xb.buf.device
@@ -282,6 +284,8 @@ class Model(nn.Module):
         hip.warp(hip.WARP_W1, xb, cb_up, out=fwbw.channels(0, 3))
         hip.warp(hip.WARP_W1, xa, ca_up, out=fwbw.channels(3, 6))
         mask = self.masknet.run(fwbw)
+        if trace is not None:
+            trace.update({"fwbw": fwbw, "mask": mask})
         pred = T.empty(n, xb.h, xb.w, 3, dev)
         resid = T.empty(n, xb.h, xb.w, 3, dev) if cur is not None else None
         hip.check(hip.lib().vc_lhbdc_blend(hip.stream(), fwbw.view(), mask.view(),
@@ -289,10 +293,13 @@ class Model(nn.Module):
                                            resid.view() if resid is not None else hip.NULL_VIEW), "vc_lhbdc_blend")
         return pred, resid
 
-    def forward_device(self, x_before, x_current, x_after):
+    def forward_device(self, x_before, x_current, x_after, trace=None):
         """The whole B-frame path with NO host synchronisation (graph-capturable) for a batch of n
         independent frames: returns (x_hat NCHW [n,3,H,W], bits float64 device tensor [n, 4] =
-        per frame (mv.y, mv.z, res.y, res.z))."""
+        per frame (mv.y, mv.z, res.y, res.z)).
+        ``trace`` (parity instrumentation of the tests / bench.py): a dict that receives the stage outputs -- "flows"
+        (the four SPyNet fields ba, ab, cb, ca), "mv_hat", "mask", "pred", "resid" as T windows and "mv" / "res" = the
+        compressors' traces (MeanScaleHyperprior.forward_t)."""
         _require_frames(x_before, x_current, x_after)
         xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
         n = xc_.shape[0]
@@ -308,10 +315,13 @@ class Model(nn.Module):
         hip.axpby(flow_cb, flow_ab, 1.0, -1.0, out=diff.channels(0, 2))      # m.py:52
         hip.axpby(flow_ca, flow_ba, 1.0, -1.0, out=diff.channels(2, 4))
         bits = BitCounter(dev, max_rows=4 * n)
-        mv_hat = self.mv_compressor.forward_t(diff, bits)
+        t_mv, t_res = ({}, {}) if trace is not None else (None, None)
+        mv_hat = self.mv_compressor.forward_t(diff, bits, trace=t_mv)
         xb, xc, xa = hip.nchw_to_nhwc(xb_), hip.nchw_to_nhwc(xc_), hip.nchw_to_nhwc(xa_)
-        pred, resid = self._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww, cur=xc)
-        res_hat = self.residual_compressor.forward_t(resid, bits)
+        pred, resid = self._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww, cur=xc, trace=trace)
+        res_hat = self.residual_compressor.forward_t(resid, bits, trace=t_res)
+        if trace is not None:
+            trace.update({"flows": flows, "diff": diff, "mv_hat": mv_hat, "pred": pred, "resid": resid, "mv": t_mv, "res": t_res})
         x_hat = hip.nhwc_to_nchw(hip.axpby(res_hat, pred))                   # m.py:71
         # counter rows were appended as mv:(y,z) per image, then res:(y,z) per image
         tot = bits.totals().view(2, n, 2).permute(1, 0, 2).reshape(n, 4)
@@ -367,8 +377,9 @@ def _cli_predictors(model, frames, n):
     return flow_ab, flow_ab, hh, ww
 
 
-def encode_B(model, x_after, x_current, x_before):
-    """(mv_bits, res_bits) like encode_B.py:71-105 -- note the argument order."""
+def encode_B(model, x_after, x_current, x_before, trace=None):
+    """(mv_bits, res_bits) like encode_B.py:71-105 -- note the argument order.
+    ``trace``: a dict that receives {"mv": {...}, "res": {...}} = the integers handed to the range coder."""
     for t in (x_after, x_current, x_before):
         _require_cuda(t)
     xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
@@ -382,26 +393,33 @@ def encode_B(model, x_after, x_current, x_before):
     diff = T.empty(n, flow_ab.h, flow_ab.w, 4, dev)
     hip.axpby(flow_cb, flow_ab, 1.0, -1.0, out=diff.channels(0, 2))
     hip.axpby(flow_ca, flow_ba, 1.0, -1.0, out=diff.channels(2, 4))
-    mv_hat = model.mv_compressor.forward_t(diff, BitCounter(dev))
-    strings, shape = model.mv_compressor.compress_t(diff)
+    mv_hat = model.mv_compressor.forward_t(diff, BitCounter(dev, max_rows=2 * n))
+    t_mv, t_res = ({}, {}) if trace is not None else (None, None)
+    strings, shape = model.mv_compressor.compress_t(diff, trace=t_mv)
     mv_bits = {"strings": strings, "shape": torch.Size(shape)}
     xb, xc, xa = hip.nchw_to_nhwc(xb_), hip.nchw_to_nhwc(xc_), hip.nchw_to_nhwc(xa_)
     _, resid = model._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww, cur=xc)
-    strings, shape = model.residual_compressor.compress_t(resid)
+    strings, shape = model.residual_compressor.compress_t(resid, trace=t_res)
+    if trace is not None:
+        trace.update({"mv": t_mv, "res": t_res})
     return mv_bits, {"strings": strings, "shape": torch.Size(shape)}
 
 
-def decode_B(x_before, x_after, model, string_flow, string_res, shape_flow, shape_res):
+def decode_B(x_before, x_after, model, string_flow, string_res, shape_flow, shape_res, trace=None):
+    """decode_B.py:63-86.  ``trace``: a dict that receives {"mv": {...}, "res": {...}} = the decoder's integers."""
     for t in (x_before, x_after):
         _require_cuda(t)
     xb_, xa_ = x_before.contiguous().float(), x_after.contiguous().float()
     n = xb_.shape[0]
     dev = xb_.device
     flow_ba, flow_ab, hh, ww = _cli_predictors(model, {"b": xb_, "a": xa_}, n)
-    mv_hat = model.mv_compressor.decompress_t(string_flow, shape_flow, dev)
+    t_mv, t_res = ({}, {}) if trace is not None else (None, None)
+    mv_hat = model.mv_compressor.decompress_t(string_flow, shape_flow, dev, trace=t_mv)
     xb, xa = hip.nchw_to_nhwc(xb_), hip.nchw_to_nhwc(xa_)
     pred, _ = model._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww)
-    res_hat = model.residual_compressor.decompress_t(string_res, shape_res, dev)
+    res_hat = model.residual_compressor.decompress_t(string_res, shape_res, dev, trace=t_res)
+    if trace is not None:
+        trace.update({"mv": t_mv, "res": t_res})
     return hip.nhwc_to_nchw(hip.axpby(res_hat, pred))
 
 
