@@ -546,6 +546,7 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                     times.append(time.perf_counter() - t1)
                 runs[threads] = {"threads": threads, "median_s_per_frame": statistics.median(times), "times_s": times}
             # one more (untimed) call with the latent capture hooked in, for the integer parity figures below
+            torch.set_num_threads(min(runs.values(), key=lambda r: r["median_s_per_frame"])["threads"])
             if not is_icip:
                 mv_name = "flow_compressor" if is_flex else "mv_compressor"
                 with CodecTrace(getattr(ora, mv_name)) as t_mv, CodecTrace(ora.residual_compressor) as t_res, \
@@ -580,6 +581,11 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
             parity["symbols_differ"] = sym
             total = sum(v["of"] for v in sym.values())
             parity["symbols_differ_fraction"] = sum(v["differ"] for v in sym.values()) / total
+            # every residual-codec flip must be a boundary case: the oracle's own (y - mu) within fp32 noise of a half-integer
+            v = traces["res"]["y"] - traces["res"]["means"]
+            flipped = trace["res"]["y_sym"].cpu() != traces["res"]["y_sym"]
+            dist = ((v - torch.floor(v)) - 0.5).abs()[flipped]
+            parity["res_y_flips_farthest_from_rounding_boundary"] = float(dist.max()) if dist.numel() else 0.0
             parity["stage_max_abs"] = {
                 "mask": float((hip.nhwc_to_nchw(trace["mask"]).cpu() - traces["mask"]).abs().max()),
                 "residual_codec_input": float((hip.nhwc_to_nchw(trace["resid"]).cpu() - traces["res"]["x"]).abs().max()),

@@ -68,7 +68,7 @@ def test_process_and_backwarp_surface(dev, models):
         assert (a.cpu() - b).abs().max().item() < 2e-4
 
 
-def test_codec_against_reference_bitstream(dev, models):
+def test_codec_roundtrip_through_container(dev, models):
     from vcamd import flex
     _, prod = models
     for c in (prod.flow_compressor, prod.residual_compressor):
@@ -82,15 +82,13 @@ def test_codec_against_reference_bitstream(dev, models):
         _, s_mv, s_res, sh_mv, sh_res = flex.read_container(blob)
         dec = flex.decode_B(prod, xb, xa, s_mv, s_res, sh_mv, sh_res, n, l)
     assert tuple(sh_mv) == tuple(fx["flow_shape"]) and tuple(sh_res) == tuple(fx["res_shape"])
-    same = {}
+    # (byte-identity of the strings and the integers behind them: test_bitstream_gpu.py)
     for k, s in (("flow_y", mv_bits["strings"][0][0]), ("flow_z", mv_bits["strings"][1][0]),
                  ("res_y", res_bits["strings"][0][0]), ("res_z", res_bits["strings"][1][0])):
-        same[k] = s == fx[k].tobytes()
         assert abs(len(s) - fx[k].size) <= max(8, 0.01 * fx[k].size), k
     ref = torch.from_numpy(fx["decoded"])
     src = frame_tensor(fx["current"])
     d_psnr = abs(psnr(dec.cpu(), src) - psnr(ref, src))
-    print("flex byte-identical to the reference bitstream:", same, f"dPSNR={d_psnr:.2e}")
     assert d_psnr < 5e-3
     assert dec.min().item() >= -1.0  # residual path is clamped to [0,1] then added to the prediction
 

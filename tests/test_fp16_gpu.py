@@ -117,3 +117,93 @@ def test_half_activation_never_reaches_other_kernels(dev):
         hip.axpby(t, None)
     with pytest.raises(hip.VcError):
         hip.nhwc_to_nchw(t)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: "ICIP2024 config 2160p (4K) inference, fp16 MFMA conv path"
+# ---------------------------------------------------------------------------------------------------------------------
+def _icip_fp16(dev):
+    from vcamd import hip, icip2024
+    from vcamd.seeding import seeded_state_dict
+    hip.set_conv_precision("fp16")
+    m = icip2024.FlowGuidedB()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed=1234))
+    return m.to(dev).eval()          # (layers pack lazily: the caller keeps the fp16 mode set during the first forward)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_icip2024_forward_fp16_against_reference_fixture(dev, tag):
+    """FlowGuidedB.forward on the fp16 path against the fp32 REFERENCE outputs (icip2024_forward_a.npz): operands are
+    rounded to half, so the bar is the fp16 tolerance of this file, not the 1e-3 dB of the exact path."""
+    from vcamd import hip
+    fx = load_fixture("icip2024_forward_a.npz")
+    x1, xc, x2 = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    s1, s2, lvl, drr = (float(v) for v in fx[f"cfg_{tag}"])
+    try:
+        m = _icip_fp16(dev)
+        with torch.no_grad():
+            out = m(x1, x2, s1, s2, xc, lvl, int(drr))
+    finally:
+        hip.set_conv_precision("fp32")
+    ref = torch.from_numpy(fx[f"x_hat_{tag}"])
+    src = frame_tensor(fx["current"])
+    d_psnr = abs(psnr(out["x_hat"].cpu(), src) - psnr(ref, src))
+    rel = abs(out["size"].item() - float(fx[f"size_{tag}"])) / float(fx[f"size_{tag}"])
+    print(f"icip2024 fp16 {tag}: dPSNR={d_psnr:.4f} dB, size rel={rel:.4f}, PSNR(fp16 vs fp32 output)={psnr(out['x_hat'].cpu(), ref):.2f} dB")
+    assert d_psnr < PSNR_TOL_DB and rel < BITS_TOL
+
+
+def _frames_4k(dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 2176 + 16, 3840 + 24, generator=g), 9, 1)
+    return [base[..., 2 * t:2 * t + 2176, 3 * t:3 * t + 3840].contiguous().to(dev) for t in range(3)]
+
+
+def test_icip2024_fp16_2160p_properties(dev):
+    """configs[4] at its own size (2176x3840 = 2160p padded to x64), size-independent properties: the run is deterministic
+    (two passes identical, bit for bit), finite, rate == size / pixels (m.py:245-252 divides by the padded frame), and
+    the per-frame flow-resolution search returns one of its five candidates."""
+    from vcamd import hip
+    x1, xc, x2 = _frames_4k(dev, 41)
+    try:
+        m = _icip_fp16(dev)
+        with torch.no_grad():
+            a = m(x1, x2, 0.5, 0.5, xc, 2, 2)
+            b = m(x1, x2, 0.5, 0.5, xc, 2, 2)
+            flow, choice, _ = m.search_flow_t(hip.nchw_to_nhwc(xc), hip.nchw_to_nhwc(x1), hip.nchw_to_nhwc(x2), 0.5, 0.5)
+    finally:
+        hip.set_conv_precision("fp32")
+    assert tuple(a["x_hat"].shape) == (1, 3, 2176, 3840)
+    assert torch.equal(a["x_hat"], b["x_hat"]) and float(a["size"]) == float(b["size"])
+    assert torch.isfinite(a["x_hat"]).all() and float(a["size"]) > 0
+    assert abs(float(a["rate"]) - float(a["size"]) / (2176 * 3840)) < 1e-5 * float(a["rate"])
+    assert 0 <= int(choice[0]) < 5 and (flow.h, flow.w, flow.c) == (1088, 1920, 4)       # flows live at half resolution
+
+
+def test_lhbdc_2160p_properties(dev):
+    """LHBDC at 2176x3840 on the exact fp32 path: deterministic, finite, rate = size / pixels / 2 (the m.py:96 halving),
+    and the fp16 path of the same frame stays within this file's tolerance of it."""
+    from vcamd import hip, lhbdc
+    from vcamd.seeding import seeded_state_dict
+    xb, xc, xa = _frames_4k(dev, 43)
+    m = lhbdc.Model()
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed=1234))
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        x1, rate1, bits1 = m(xb, xc, xa, False)
+        x2, rate2, bits2 = m(xb, xc, xa, False)
+    assert torch.equal(x1, x2) and bits1 == bits2
+    assert torch.isfinite(x1).all() and bits1 > 0
+    assert abs(float(rate1) - bits1 / (2176 * 3840) / 2.0) < 1e-5 * float(rate1)
+    hip.set_conv_precision("fp16")
+    try:
+        h = lhbdc.Model()
+        h.load_state_dict(seeded_state_dict(h.state_dict(), seed=1234))
+        h = h.to(dev).eval()
+        with torch.no_grad():
+            x16, _, bits16 = h(xb, xc, xa, False)
+    finally:
+        hip.set_conv_precision("fp32")
+    d_psnr = abs(psnr(x16.cpu(), xc.cpu()) - psnr(x1.cpu(), xc.cpu()))
+    print(f"LHBDC 2160p fp16 vs fp32: dPSNR={d_psnr:.4f} dB, bits rel={abs(bits16 - bits1) / bits1:.4f}")
+    assert d_psnr < PSNR_TOL_DB and abs(bits16 - bits1) / bits1 < BITS_TOL

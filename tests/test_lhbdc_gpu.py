@@ -68,9 +68,10 @@ def test_forward_matches_oracle_other_size(dev, models):
     assert torch.equal(out2, out)
 
 
-def test_codec_roundtrip_and_reference_bitstream(dev, models):
-    """encode_B -> container -> decode_B on the GPU; the strings are compared with the reference's own
-    bitstream for the same inputs (byte-exact when no latent rounding flips; else length within 1%)."""
+def test_codec_roundtrip_through_container(dev, models):
+    """encode_B -> bits_B.bin container -> decode_B on the GPU against the reference's decoded frame for the same inputs.
+    (The integer side -- symbols, indexes, byte-identity of the four strings with the reference's, HIP decoding of the
+    reference's own container -- is asserted in test_bitstream_gpu.py.)"""
     from vcamd import lhbdc
     _, prod = models
     prod.mv_compressor.update(force=True)
@@ -83,18 +84,12 @@ def test_codec_roundtrip_and_reference_bitstream(dev, models):
     blob = lhbdc.write_container(None, 1626, mv_bits, res_bits)
     lm, s_mv, s_res, shape_mv, shape_res = lhbdc.read_container(blob)
     assert lm == 1626 and tuple(shape_mv) == tuple(fx["mv_shape"]) and tuple(shape_res) == tuple(fx["res_shape"])
+    assert len(blob) == len(fx["container"]) or abs(len(blob) - len(fx["container"])) <= 0.01 * len(fx["container"])
     with torch.no_grad():
         dec = lhbdc.decode_B(xb, xa, prod, s_mv, s_res, shape_mv, shape_res)
     ref_dec = torch.from_numpy(fx["decoded"])
     src = frame_tensor(fx["current"])
     d_psnr = abs(psnr(dec.cpu()[..., :h, :w], src) - psnr(ref_dec[..., :h, :w], src))
-    same = {k: bytes(fx[k].tobytes()) == s for k, s in
-            (("mv_y", mv_bits["strings"][0][0]), ("mv_z", mv_bits["strings"][1][0]),
-             ("res_y", res_bits["strings"][0][0]), ("res_z", res_bits["strings"][1][0]))}
-    print("byte-identical to the reference bitstream:", same, f"dPSNR={d_psnr:.2e}")
-    for k, s in (("mv_y", mv_bits["strings"][0][0]), ("mv_z", mv_bits["strings"][1][0]),
-                 ("res_y", res_bits["strings"][0][0]), ("res_z", res_bits["strings"][1][0])):
-        assert abs(len(s) - fx[k].size) <= max(8, 0.01 * fx[k].size), k
     assert d_psnr < 5e-3
     u8 = lhbdc.float_to_uint8(dec[0].cpu().numpy())[:h, :w]
     assert (np.abs(u8.astype(int) - fx["decoded_u8"].astype(int)) > 1).mean() < 1e-3

@@ -148,6 +148,20 @@ typedef TileCfg<64, 8, 1, 2, 1> CfgN4;
 typedef TileCfg<32, 16, 1, 4, 1> CfgN32T16;
 typedef TileCfg<32, 8, 1, 4, 2, 2> CfgN128b;   // 2x2 waves: each wave 4 rows x 64 channels (half the B-fragment loads)
 
+// fp16 path: depth of the register ring that holds prefetched weight fragments.  One k-step is only 32*WM*WN matrix
+// cycles there (an fp32 step is 8x longer), far less than an L2 round trip, so the fragment of step g is requested D
+// steps ahead.  D divides the steps of a kernel row (ring slots stay compile-time constants across the rolled ky loop)
+// and is capped by what the accumulators leave of the register file.
+constexpr int vc_ring_depth(int steps_x, int wm, int wn, int nreg)
+{
+    int budget = (200 - wm * wn * nreg - 8 * wm) / (4 * wn);
+    if (budget > 8) budget = 8;
+    int d = 1;
+    for (int c = 2; c <= budget; ++c)
+        if (steps_x % c == 0) d = c;
+    return d;
+}
+
 template <int KH, int KW, int S, int CK, class C> struct ConvGeom {
     static constexpr bool POINT = (KH == 1 && KW == 1);
     static constexpr int LS = POINT ? 1 : S;                  // stride as seen by the LDS image
@@ -321,6 +335,17 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         ? reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(p.in) + (long long)img * p.in_sn)
         : p.in + (long long)img * p.in_sn;
 
+    constexpr int RING = F16 ? vc_ring_depth(KW * KSTEPS, WM, WN, M::NREG) : 1;
+    f32x4 ring[RING][WN];
+    if constexpr (F16) {          // steps 0 .. RING-1 of the first chunk's first kernel row
+#pragma unroll
+        for (int d = 0; d < RING; ++d)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+                ring[d][n] = *reinterpret_cast<const f32x4 *>(wlane + n * ntile_stride +
+                                                              ((long long)(d / KSTEPS) * ksteps_total + d % KSTEPS) * 256);
+    }
+
     VC_T(t_start);
     for (int c0 = 0; c0 < p.cin_pad; c0 += CKC) {
         VC_T(t_a);
@@ -362,6 +387,43 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
             for (int t = 0; t < WM; ++t) a[t] = *reinterpret_cast<const f32x4 *>(&lds[abase[t] + rowoff + koff + ks * KS]);
         };
+        if constexpr (F16) {
+            // ---- fp16: weight fragments through a D-deep register ring (filled before the chunk loop and kept full
+            // across rows, chunks and the staging barriers), activations one step ahead from LDS ----
+            const float *wchunk_n = wlane + (long long)((c0 + CKC < p.cin_pad ? c0 + CKC : c0) / KSC) * 256;
+            load_a(ac, 0, 0);
+#pragma unroll 1
+            for (int ky = 0; ky < KH; ++ky) {
+                const float *wrow = wchunk + (long long)ky * KW * ksteps_total * 256;
+                const float *wrow_n = ky + 1 < KH ? wrow + (long long)KW * ksteps_total * 256 : wchunk_n;
+                const int rowoff = ky * G::COLS_L * G::CKP;
+                const int rowoff_n = (ky + 1 < KH ? ky + 1 : ky) * G::COLS_L * G::CKP;
+                static_for<0, STEPS_X>([&](auto sc) {
+                    constexpr int sx = decltype(sc)::value;
+                    constexpr int slot = sx % RING;
+                    if constexpr (sx + 1 < STEPS_X) load_a(an, rowoff, sx + 1);
+                    else load_a(an, rowoff_n, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < WM; ++t)
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) {
+                            if constexpr (MT == 32)
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ring[slot][n]),
+                                                                                   __builtin_bit_cast(f16x8, ac[t]), acc[t][n], 0, 0, 0);
+                            else
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[slot][n]),
+                                                                                   __builtin_bit_cast(f16x8, ac[t]), acc[t][n], 0, 0, 0);
+                        }
+                    // refill the slot just consumed with the fragment RING steps ahead (same row, next row or next chunk)
+                    if constexpr (sx + RING < STEPS_X) load_b(ring[slot], wrow, sx + RING);
+                    else load_b(ring[slot], wrow_n, sx + RING - STEPS_X);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < WM; ++t) ac[t] = an[t];
+                });
+            }
+        } else {
         load_b(bc, wchunk, 0);
         load_a(ac, 0, 0);
 #pragma unroll 1
@@ -408,6 +470,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
                 for (int t = 0; t < WM; ++t) ac[t] = an[t];
             });
+        }
         }
         VC_T(t_e);
         VC_ACC(0, t_b, t_a);   // barrier before staging (waiting for the slowest wave of the previous chunk)
