@@ -87,6 +87,10 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
 /* OR into vc_conv_desc.cfg: add `res` BEFORE the (plain / ReLU / LeakyReLU) activation instead of after it --
  * out = relu(conv(x) + res), the ResidualUnit of compressai.layers.AttentionBlock (ICIP2024/src/model/elic.py:97-121). */
 #define VC_CFG_RES_FIRST 0x1000
+/* With VC_CFG_F16 only (3x3 / 7x7 stride-1 instances): producer/consumer kernel -- four waves stage the NEXT (tile,
+ * channel-chunk) item into the second half of a double-buffered LDS tile while four waves contract the current one; one
+ * persistent workgroup per CU.  Bit-identical to the classic fp16 kernel of the same tile configuration. */
+#define VC_CFG_WS 0x2000
 
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */

@@ -152,6 +152,56 @@ def test_conv2d_fp16_path(dev, cin, cout, k, stride, h, w, act, ps):
     _close(out, exact, 5e-3, "fp16 conv vs exact fp32")
 
 
+WS_CASES = [  # cin, cout, k, n, h, w, base tile configs to compare
+    (64, 32, 7, 2, 50, 70, (2, 7)), (32, 64, 7, 1, 34, 60, (1, 2, 7)), (128, 128, 3, 1, 40, 72, (1, 2, 5)), (128, 128, 3, 3, 17, 33, (5,)),
+    (256, 128, 3, 1, 16, 40, (1, 5)), (128, 512, 3, 1, 17, 30, (1, 2, 5)), (64, 64, 3, 1, 300, 280, (1, 2)), (128, 32, 7, 1, 20, 36, (2, 7)),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,n,h,w,cfgs", WS_CASES)
+def test_producer_consumer_fp16_kernel_is_bit_identical(dev, cin, cout, k, n, h, w, cfgs):
+    """VC_CFG_WS (csrc/conv_ws.h): persistent workgroups, producer waves staging the next (tile, chunk) item into the
+    second LDS buffer, consumer waves contracting -- same geometry and accumulation order as the classic fp16 kernel of
+    the same tile configuration, so every result must be equal bit for bit: plain / residual / pixel-shuffle epilogues,
+    fp32 and half-precision inputs and outputs, ragged sizes, several images, more tiles than CUs."""
+    from vcamd import hip
+    from vcamd.hip import T
+    ps = cout == 512
+    x = _rand((n, cin, h, w), 51)
+    wt = _rand((cout, cin, k, k), 52, 1.0 / np.sqrt(cin * k * k))
+    b = _rand((cout,), 53, 0.1)
+    hip.set_conv_precision("fp16")
+    try:
+        pc = hip.PackedConv(wt, b, pixelshuffle=ps, device=dev)
+    finally:
+        hip.set_conv_precision("fp32")
+    assert pc.wpk16 is not None
+    xt = hip.nchw_to_nhwc(x.to(dev))
+    ho, wo, co = pc.out_shape(h, w)
+    res = hip.nchw_to_nhwc(_rand((n, co, ho, wo), 54).to(dev))
+    fl = hip.CFG_F16
+    seen = 0
+    for base in cfgs:
+        if base not in pc.candidates and base != pc.cfg:
+            continue
+        outs = {}
+        for ws in (0, hip.CFG_WS):
+            pc.tuned = {(n, h, w, fl): base | ws | hip.CFG_EXACT | fl,
+                        (n, h, w, fl | hip.CFG_OUT_F16): base | ws | hip.CFG_EXACT | fl | hip.CFG_OUT_F16,
+                        (n, h, w, fl | hip.CFG_IN_F16): base | ws | hip.CFG_EXACT | fl | hip.CFG_IN_F16}
+            plain = pc(xt, act=hip.ACT_LRELU, slope=0.01)
+            with_res = pc(xt, act=hip.ACT_RELU, res=res)
+            half = pc(xt, act=hip.ACT_RELU, out_f16=True)                # half-precision output ...
+            assert half.dtype == "f16"
+            outs[ws] = [plain.buf.clone(), with_res.buf.clone(), half.buf.clone()]
+            if cout == cin and not ps:                                    # ... consumed as a half-precision input
+                outs[ws].append(pc(half, act=hip.ACT_NONE).buf.clone())
+        for a, c in zip(outs[0], outs[hip.CFG_WS]):
+            assert torch.equal(a, c), (base, (a.float() - c.float()).abs().max().item())
+        seen += 1
+    assert seen > 0
+
+
 def test_conv_residual_and_channel_slices(dev):
     """residual add + reading/writing channel slices of wider buffers (concat-free U-Net plumbing)"""
     from vcamd import hip

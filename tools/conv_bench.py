@@ -23,6 +23,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32")
+    ap.add_argument("--half-io", action="store_true",
+                    help="fp16 path: half-precision input AND output tensors (VC_CFG_IN_F16 / OUT_F16), as inside a chain of "
+                         "fp16-path layers; default is fp32 tensors either side (the first / last layer of a chain)")
     ap.add_argument("shapes", nargs="*", default=DEFAULT)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -37,11 +40,14 @@ def main():
         if len(fields) > 7:            # optional 8th field: force a (layout-compatible) narrower tile config
             f16 = pc.wpk16 is not None
             fl = hip.CFG_F16 if f16 else 0
+            if args.half_io:
+                fl |= hip.CFG_IN_F16 | hip.CFG_OUT_F16
             pc.tuned = {(n, h, w, fl): fields[7] | hip.CFG_EXACT | fl}
-        x = hip.T.empty(n, h, w, cin, dev)
+        io = "f16" if (args.half_io and args.precision == "fp16") else "f32"
+        x = hip.T.empty(n, h, w, cin, dev, io)
         x.buf.normal_()
         ho, wo, co = pc.out_shape(h, w)
-        out = hip.T.empty(n, ho, wo, co, dev)
+        out = hip.T.empty(n, ho, wo, co, dev, io)
         for _ in range(2):
             pc(x, out=out, act=hip.ACT_LRELU)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

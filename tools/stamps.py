@@ -20,7 +20,12 @@ PHASES = ["barrier-before-stage", "staging", "barrier-after-stage", "mfma loop",
 
 
 def main():
-    shapes = sys.argv[1:] or ["64,32,7,1,4,1088,1920", "128,128,3,1,1,544,960,5", "128,128,3,1,1,544,960,1"]
+    argv = sys.argv[1:]
+    f16 = "--fp16" in argv          # with libvc_hip_stamps16.so (`make stamps16`): the fp16-path instances
+    argv = [a for a in argv if a != "--fp16"]
+    if f16:
+        hip.set_conv_precision("fp16")
+    shapes = argv or ["64,32,7,1,4,1088,1920", "128,128,3,1,1,544,960,5", "128,128,3,1,1,544,960,1"]
     L = hip.lib()
     if not hasattr(L, "vc_debug_read_stamps"):
         raise SystemExit("this library has no stamps: build `make -C video-compression_amd/csrc stamps` and set VC_HIP_LIB")
@@ -33,7 +38,8 @@ def main():
         g = torch.Generator().manual_seed(0)
         pc = hip.PackedConv(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.zeros(cout), stride=s, device=dev)
         if len(f) > 7:
-            pc.tuned = {(n, h, w, 0): f[7] | hip.CFG_EXACT}
+            fl = hip.CFG_F16 if f16 else 0
+            pc.tuned = {(n, h, w, fl): f[7] | hip.CFG_EXACT | fl}
         x = hip.T.empty(n, h, w, cin, dev)
         x.buf.normal_()
         out = hip.T.empty(n, *pc.out_shape(h, w), dev)
@@ -45,6 +51,12 @@ def main():
         L.vc_debug_read_stamps(buf)
         waves = buf[6] / reps
         print(f"conv k{k} {cin}->{cout} @{n}x{h}x{w} cfg={f[7] if len(f) > 7 else 'auto'}: waves/launch={waves:.0f}")
+        if len(f) > 7 and f[7] & hip.CFG_WS:
+            print("   (producer/consumer kernel: consumer waves only; 'barrier-after-stage' = waiting for the producers, 'mfma loop' = "
+                  "contraction of all items, no staging in these waves)")
+        if len(f) > 7 and f[7] & hip.CFG_WS:
+            print(f"   producers (per producer wave = per consumer wave): commit {buf[0] / buf[6]:.0f}, issue {buf[1] / buf[6]:.0f}, "
+                  f"waiting at the item barrier {buf[7] / buf[6]:.0f}")
         for i, name in enumerate(PHASES):
             print(f"   {name:22s} {buf[i] / buf[6]:12.0f} cycles/wave  {100.0 * buf[i] / buf[5]:5.1f}% of lifetime")
 

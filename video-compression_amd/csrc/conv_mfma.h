@@ -42,6 +42,8 @@ __device__ unsigned long long g_vc_stamps[8];
 #define VC_ACC(slot, t1, t0)
 #endif
 
+#define VC_CFG_WS_BIT 0x100      // dispatcher-internal: producer/consumer kernel (conv_ws.h) requested
+
 struct ConvArgs {
     const float *in;
     long long in_sn, in_sh, in_sw;
@@ -152,14 +154,19 @@ typedef TileCfg<32, 8, 1, 4, 2, 2> CfgN128b;   // 2x2 waves: each wave 4 rows x 
 // cycles there (an fp32 step is 8x longer), far less than an L2 round trip, so the fragment of step g is requested D
 // steps ahead.  D divides the steps of a kernel row (ring slots stay compile-time constants across the rolled ky loop)
 // and is capped by what the accumulators leave of the register file.
-constexpr int vc_ring_depth(int steps_x, int wm, int wn, int nreg)
+constexpr int vc_ring_depth(int steps_x, int free_regs, int wn, int cap = 8)
 {
-    int budget = (200 - wm * wn * nreg - 8 * wm) / (4 * wn);
-    if (budget > 8) budget = 8;
+    int budget = free_regs / (4 * wn);
+    if (budget > cap) budget = cap;
     int d = 1;
     for (int c = 2; c <= budget; ++c)
         if (steps_x % c == 0) d = c;
     return d;
+}
+// registers the classic kernel can spare for the ring next to accumulators, two A fragments and the staging batch
+constexpr int vc_ring_regs_classic(int wm, int wn, int nreg, int min_waves)
+{
+    return (min_waves >= 3 ? 112 : 176) - wm * wn * nreg - 8 * wm;
 }
 
 template <int KH, int KW, int S, int CK, class C> struct ConvGeom {
@@ -188,9 +195,10 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
 
 // INH: the input tensor itself is stored in half precision (VC_CFG_IN_F16): an item is ONE 16-byte load of 8
 // channels and needs no conversion -- the producer's epilogue already rounded exactly as this stage would have.
-template <int KH, int KW, int S, int CK, class C, bool VEC, bool F16, bool INH = false>
+// WIDE (producer waves of conv_ws.h, which hold no accumulators): the whole footprint in ONE round of loads when it fits.
+template <int KH, int KW, int S, int CK, class C, bool VEC, bool F16, bool INH = false, bool WIDE = false>
 __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const float *in_img, int c0, int oy0, int ox0,
-                                            int iy0, int ix0)
+                                            int iy0, int ix0, int tid)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     constexpr int C4 = CK / 4;                                   // 16-byte LDS items per pixel
@@ -198,7 +206,9 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
     constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
     constexpr int IPT = (ITEMS + 255) / 256;                    // items per thread
     constexpr int BATCH0 = (IPT + 1) / 2 > 8 ? 8 : (IPT + 1) / 2;   // two rounds per chunk when registers allow
-    constexpr int BATCH = (F16 && !INH) ? (BATCH0 > 4 ? 4 : BATCH0) : BATCH0; // (an fp16 item from fp32 data is two 16-byte loads)
+    constexpr int BATCH1 = (F16 && !INH) ? (BATCH0 > 4 ? 4 : BATCH0) : BATCH0; // (an fp16 item from fp32 data is two 16-byte loads)
+    constexpr int WIDE_MAX = INH ? 24 : 12;
+    constexpr int BATCH = !WIDE ? BATCH1 : (IPT <= WIDE_MAX ? IPT : (IPT + (IPT + WIDE_MAX - 1) / WIDE_MAX - 1) / ((IPT + WIDE_MAX - 1) / WIDE_MAX));
 #pragma unroll
     for (int b0 = 0; b0 < IPT; b0 += BATCH) {
         f32x4 v[BATCH], v2[(F16 && !INH) ? BATCH : 1];
@@ -207,7 +217,7 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
             if (b0 + j >= IPT) continue;
-            const int idx = threadIdx.x + (b0 + j) * 256;
+            const int idx = tid + (b0 + j) * 256;
             const int c4 = idx % C4;
             const int pc = idx / C4;
             const int col = pc % G::COLS_IN, row = pc / G::COLS_IN;
@@ -263,6 +273,176 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
             *reinterpret_cast<f32x4 *>(&lds[dst[j]]) = w;
         }
     }
+}
+
+// ---- epilogue: (GDN) -> activation -> channel gain -> residual -> store (plain / pixel-shuffle) ----
+// Shared by the classic kernel and the producer/consumer kernel (conv_ws.h).
+template <class C, bool F16>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &p, typename Mfma<C::MT>::acc_t (&acc)[C::WM][C::WN], int nblk, int wm,
+                                              int wn, int lane, int oy0, int ox0, int img)
+{
+    typedef Mfma<C::MT> M;
+    constexpr int MT = C::MT, WM = C::WM, WN = C::WN, NT = C::NT;
+    // ---- epilogue: (GDN) -> activation -> channel gain -> residual -> store (plain / pixel-shuffle) ----
+    // One lane owns one pixel of the M-tile and, per register quad, 4 consecutive output channels: the residual /
+    // GDN-input loads and the store are single 16-byte accesses.  The mode (GDN / IGDN / sigmoid / clamp / plain)
+    // is resolved ONCE per wave: a per-element switch unrolled over 128 accumulators cost ~40k instructions.
+    const int pxl = M::px(lane);
+    auto epilogue = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;   // 0 plain/relu/lrelu, 1 GDN, 2 IGDN, 3 sigmoid, 4 clamp01
+        // plain / ReLU / LeakyReLU share one formula: v >= 0 ? v : v * neg
+        const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+        static_for<0, WM>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int m = wm * WM + t;
+            const int oy = oy0 + m / C::XT;
+            const int ox = ox0 + (m % C::XT) * MT + pxl;
+            const bool pix_ok = (oy < p.Ho) && (ox < p.Wo);
+            const long long mul_pix = (long long)img * p.mul_sn + (long long)oy * p.mul_sh + (long long)ox * p.mul_sw;
+            static_for<0, WN>([&](auto nc) {
+                constexpr int n = decltype(nc)::value;
+#pragma unroll
+                for (int g = 0; g < M::NREG / 4; ++g) {
+                    const int co = nblk * C::BN + (wn * WN + n) * NT + M::crow(4 * g, lane);   // first of 4 consecutive channels
+                    f32x4 v = {acc[t][n][4 * g], acc[t][n][4 * g + 1], acc[t][n][4 * g + 2], acc[t][n][4 * g + 3]};
+                    if (pix_ok && co < p.Cout) {
+                        const int cps = p.Cout >> 2;
+                        const bool ps = p.out_mode != VC_OUT_PLAIN;
+                        const int pos = ps ? co / cps : 0;
+                        const int cch = ps ? co - pos * cps : co;
+                        const int sc = ps ? 2 : 1;
+                        const int yy = sc * oy + (pos >> 1), xx = sc * ox + (pos & 1);
+                        const long long o_off = (long long)img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
+                        const long long r_off = (long long)img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
+                        if (p.vec_out) {
+                            if constexpr (MODE == 1 || MODE == 2) {
+                                const f32x4 x = *reinterpret_cast<const f32x4 *>(p.mul + mul_pix + co);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)   // IEEE sqrt and divide, like the CPU path's x * rsqrt(norm)
+                                    v[e] = (MODE == 1) ? x[e] * (1.0f / sqrtf(v[e])) : x[e] * sqrtf(v[e]);
+                            }
+                            if (MODE == 0 && p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if constexpr (MODE == 3) v[e] = 1.0f / (1.0f + expf(-v[e]));
+                                else if constexpr (MODE == 4) v[e] = fminf(fmaxf(v[e], 0.0f), 1.0f);
+                                else if constexpr (MODE == 0) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
+                            }
+                            if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
+                            if (p.res && !(MODE == 0 && p.res_first)) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                            if (F16 && p.out_f16) {
+                                const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                                *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + o_off) = hv;
+                            } else {
+                                *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (co + e < p.Cout) {
+                                    float w = v[e];
+                                    if constexpr (MODE == 1 || MODE == 2) {
+                                        const float x = p.mul[mul_pix + co + e];
+                                        w = (MODE == 1) ? x * (1.0f / sqrtf(w)) : x * sqrtf(w);
+                                    }
+                                    // (pixel-shuffle: a quad may straddle two output positions when cout/4 % 4 != 0)
+                                    const int pe = ps ? (co + e) / cps : 0;
+                                    const int ce = ps ? co + e - pe * cps : co + e;
+                                    const int ye = sc * oy + (pe >> 1), xe = sc * ox + (pe & 1);
+                                    const long long re = (long long)img * p.res_sn + (long long)ye * p.res_sh + (long long)xe * p.res_sw + ce;
+                                    const bool first = MODE == 0 && p.res_first;
+                                    if (first) w += p.res[re];
+                                    if constexpr (MODE == 3) w = 1.0f / (1.0f + expf(-w));
+                                    else if constexpr (MODE == 4) w = fminf(fmaxf(w, 0.0f), 1.0f);
+                                    else if constexpr (MODE == 0) w = w >= 0.0f ? w : w * neg;
+                                    if (p.chscale) w *= p.chscale[co + e];
+                                    if (p.res && !first) w += p.res[re];
+                                    const long long oe = (long long)img * p.out_sn + (long long)ye * p.out_sh + (long long)xe * p.out_sw + ce;
+                                    if (F16 && p.out_f16) reinterpret_cast<_Float16 *>(p.out)[oe] = (_Float16)w;
+                                    else p.out[oe] = w;
+                                }
+                            }
+                        }
+                    }
+                }
+            });
+        });
+    };
+    // (the reference never combines GDN with an activation, nor sigmoid/clamp with GDN)
+    if (p.epi == VC_EPI_GDN) epilogue(std::integral_constant<int, 1>{});
+    else if (p.epi == VC_EPI_IGDN) epilogue(std::integral_constant<int, 2>{});
+    else if (p.act == VC_ACT_SIGMOID) epilogue(std::integral_constant<int, 3>{});
+    else if (p.act == VC_ACT_CLAMP01) epilogue(std::integral_constant<int, 4>{});
+    else epilogue(std::integral_constant<int, 0>{});
+}
+
+// fp16 path, 32-wide tiles: the same epilogue with COALESCED stores.  In the accumulator layout a lane owns one pixel, so
+// one store instruction touches 32 different 128-byte lines, 32 bytes each -- unnoticed behind an fp32 contraction, a
+// fifth to a third of a workgroup's life behind an fp16 one (tools/stamps.py --fp16).  Each wave passes its 32 px x 32 ch
+// accumulator tiles through a private 4.6 KB LDS scratch ([pixel][32 + 4 pad] floats: conflict-free 16-byte writes) and
+// reads them back with consecutive lanes along the channels: lane i gets channels 4(i%8).. of pixel 8j + i/8, so a store
+// instruction writes whole lines (8 consecutive pixels x 128 bytes for a 32-channel tensor).  The arithmetic per value is
+// unchanged -> bit-identical to conv_epilogue.  Plain / ReLU / LeakyReLU / sigmoid / clamp epilogues with 16-byte aligned
+// views (p.vec_out); the caller falls back to conv_epilogue otherwise.  `scratch`: this wave's 32 * 36 floats.
+constexpr int VC_EPI_ROWF = 36;
+constexpr int VC_EPI_SCRATCH_FLOATS = 32 * VC_EPI_ROWF;
+
+template <class C>
+__device__ __forceinline__ void conv_epilogue_coalesced(const ConvArgs &p, typename Mfma<C::MT>::acc_t (&acc)[C::WM][C::WN], int nblk,
+                                                        int wm, int wn, int lane, int oy0, int ox0, int img, float *scratch)
+{
+    typedef Mfma<C::MT> M;
+    constexpr int MT = C::MT, WM = C::WM, WN = C::WN, NT = C::NT;
+    static_assert(MT == 32 && M::NREG == 16, "32 x 32 accumulator tiles");
+    const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+    const int mode = p.act == VC_ACT_SIGMOID ? 3 : (p.act == VC_ACT_CLAMP01 ? 4 : 0);
+    const int wpx = lane & 31, whalf = lane >> 5;          // accumulator layout: pixel, channel half-group
+    const int rq = lane & 7, rpx = lane >> 3;              // read-back layout: channel quad, pixel within a group of 8
+    const int cps = p.Cout >> 2;
+    const bool ps = p.out_mode != VC_OUT_PLAIN;
+    const int sc = ps ? 2 : 1;
+    static_for<0, WM>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int m = wm * WM + t;
+        const int oy = oy0 + m / C::XT;
+        static_for<0, WN>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[t][n][4 * g], acc[t][n][4 * g + 1], acc[t][n][4 * g + 2], acc[t][n][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(&scratch[wpx * VC_EPI_ROWF + 8 * g + 4 * whalf]) = v;
+            }
+            const int co = nblk * C::BN + (wn * WN + n) * NT + 4 * rq;   // first of this lane's 4 consecutive channels
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pix = 8 * j + rpx;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&scratch[pix * VC_EPI_ROWF + 4 * rq]);
+                const int ox = ox0 + (m % C::XT) * MT + pix;
+                if (oy < p.Ho && ox < p.Wo && co < p.Cout) {
+                    const int pos = ps ? co / cps : 0;
+                    const int cch = ps ? co - pos * cps : co;
+                    const int yy = sc * oy + (pos >> 1), xx = sc * ox + (pos & 1);
+                    const long long o_off = (long long)img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
+                    const long long r_off = (long long)img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
+                    if (mode == 0 && p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (mode == 3) v[e] = 1.0f / (1.0f + expf(-v[e]));
+                        else if (mode == 4) v[e] = fminf(fmaxf(v[e], 0.0f), 1.0f);
+                        else v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
+                    }
+                    if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
+                    if (p.res && !(mode == 0 && p.res_first)) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                    if (p.out_f16) {
+                        const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                        *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + o_off) = hv;
+                    } else {
+                        *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
+                    }
+                }
+            }
+        });
+    });
 }
 
 // F16: the "fp16 MFMA conv path" (BASELINE.json configs[4]): activations are converted to half while being
@@ -335,7 +515,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         ? reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(p.in) + (long long)img * p.in_sn)
         : p.in + (long long)img * p.in_sn;
 
-    constexpr int RING = F16 ? vc_ring_depth(KW * KSTEPS, WM, WN, M::NREG) : 1;
+    constexpr int RING = F16 ? vc_ring_depth(KW * KSTEPS, vc_ring_regs_classic(WM, WN, M::NREG, C::MIN_WAVES), WN) : 1;
     f32x4 ring[RING][WN];
     if constexpr (F16) {          // steps 0 .. RING-1 of the first chunk's first kernel row
 #pragma unroll
@@ -356,13 +536,13 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         // no load sits under a branch), then select-zero / transform and write LDS.  This keeps BATCH
         // independent 16-byte loads in flight per lane instead of one load -> wait -> ds_write at a time.
         if (F16 && p.in_f16)
-            stage_chunk<KH, KW, S, CK, C, true, F16, F16>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+            stage_chunk<KH, KW, S, CK, C, true, F16, F16>(p, lds, in_img, c0, oy0, ox0, iy0, ix0, threadIdx.x);
         else if (F16)
-            stage_chunk<KH, KW, S, CK, C, true, true>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+            stage_chunk<KH, KW, S, CK, C, true, true>(p, lds, in_img, c0, oy0, ox0, iy0, ix0, threadIdx.x);
         else if (p.vec4)
-            stage_chunk<KH, KW, S, CK, C, true, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+            stage_chunk<KH, KW, S, CK, C, true, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0, threadIdx.x);
         else
-            stage_chunk<KH, KW, S, CK, C, false, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0);
+            stage_chunk<KH, KW, S, CK, C, false, false>(p, lds, in_img, c0, oy0, ox0, iy0, ix0, threadIdx.x);
         VC_T(t_c);
         __syncthreads();
         VC_T(t_d);
@@ -480,97 +660,16 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     }
 
     VC_T(t_loop_end);
-    // ---- epilogue: (GDN) -> activation -> channel gain -> residual -> store (plain / pixel-shuffle) ----
-    // One lane owns one pixel of the M-tile and, per register quad, 4 consecutive output channels: the residual /
-    // GDN-input loads and the store are single 16-byte accesses.  The mode (GDN / IGDN / sigmoid / clamp / plain)
-    // is resolved ONCE per wave: a per-element switch unrolled over 128 accumulators cost ~40k instructions.
-    const int pxl = M::px(lane);
-    auto epilogue = [&](auto mode_c) {
-        constexpr int MODE = decltype(mode_c)::value;   // 0 plain/relu/lrelu, 1 GDN, 2 IGDN, 3 sigmoid, 4 clamp01
-        // plain / ReLU / LeakyReLU share one formula: v >= 0 ? v : v * neg
-        const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
-        static_for<0, WM>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const int m = wm * WM + t;
-            const int oy = oy0 + m / C::XT;
-            const int ox = ox0 + (m % C::XT) * MT + pxl;
-            const bool pix_ok = (oy < p.Ho) && (ox < p.Wo);
-            const long long mul_pix = (long long)img * p.mul_sn + (long long)oy * p.mul_sh + (long long)ox * p.mul_sw;
-            static_for<0, WN>([&](auto nc) {
-                constexpr int n = decltype(nc)::value;
-#pragma unroll
-                for (int g = 0; g < M::NREG / 4; ++g) {
-                    const int co = nblk * C::BN + (wn * WN + n) * NT + M::crow(4 * g, lane);   // first of 4 consecutive channels
-                    f32x4 v = {acc[t][n][4 * g], acc[t][n][4 * g + 1], acc[t][n][4 * g + 2], acc[t][n][4 * g + 3]};
-                    if (pix_ok && co < p.Cout) {
-                        const int cps = p.Cout >> 2;
-                        const bool ps = p.out_mode != VC_OUT_PLAIN;
-                        const int pos = ps ? co / cps : 0;
-                        const int cch = ps ? co - pos * cps : co;
-                        const int sc = ps ? 2 : 1;
-                        const int yy = sc * oy + (pos >> 1), xx = sc * ox + (pos & 1);
-                        const long long o_off = (long long)img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
-                        const long long r_off = (long long)img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
-                        if (p.vec_out) {
-                            if constexpr (MODE == 1 || MODE == 2) {
-                                const f32x4 x = *reinterpret_cast<const f32x4 *>(p.mul + mul_pix + co);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)   // IEEE sqrt and divide, like the CPU path's x * rsqrt(norm)
-                                    v[e] = (MODE == 1) ? x[e] * (1.0f / sqrtf(v[e])) : x[e] * sqrtf(v[e]);
-                            }
-                            if (MODE == 0 && p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if constexpr (MODE == 3) v[e] = 1.0f / (1.0f + expf(-v[e]));
-                                else if constexpr (MODE == 4) v[e] = fminf(fmaxf(v[e], 0.0f), 1.0f);
-                                else if constexpr (MODE == 0) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
-                            }
-                            if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
-                            if (p.res && !(MODE == 0 && p.res_first)) v += *reinterpret_cast<const f32x4 *>(p.res + r_off);
-                            if (F16 && p.out_f16) {
-                                const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                                *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + o_off) = hv;
-                            } else {
-                                *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                if (co + e < p.Cout) {
-                                    float w = v[e];
-                                    if constexpr (MODE == 1 || MODE == 2) {
-                                        const float x = p.mul[mul_pix + co + e];
-                                        w = (MODE == 1) ? x * (1.0f / sqrtf(w)) : x * sqrtf(w);
-                                    }
-                                    // (pixel-shuffle: a quad may straddle two output positions when cout/4 % 4 != 0)
-                                    const int pe = ps ? (co + e) / cps : 0;
-                                    const int ce = ps ? co + e - pe * cps : co + e;
-                                    const int ye = sc * oy + (pe >> 1), xe = sc * ox + (pe & 1);
-                                    const long long re = (long long)img * p.res_sn + (long long)ye * p.res_sh + (long long)xe * p.res_sw + ce;
-                                    const bool first = MODE == 0 && p.res_first;
-                                    if (first) w += p.res[re];
-                                    if constexpr (MODE == 3) w = 1.0f / (1.0f + expf(-w));
-                                    else if constexpr (MODE == 4) w = fminf(fmaxf(w, 0.0f), 1.0f);
-                                    else if constexpr (MODE == 0) w = w >= 0.0f ? w : w * neg;
-                                    if (p.chscale) w *= p.chscale[co + e];
-                                    if (p.res && !first) w += p.res[re];
-                                    const long long oe = (long long)img * p.out_sn + (long long)ye * p.out_sh + (long long)xe * p.out_sw + ce;
-                                    if (F16 && p.out_f16) reinterpret_cast<_Float16 *>(p.out)[oe] = (_Float16)w;
-                                    else p.out[oe] = w;
-                                }
-                            }
-                        }
-                    }
-                }
-            });
-        });
-    };
-    // (the reference never combines GDN with an activation, nor sigmoid/clamp with GDN)
-    if (p.epi == VC_EPI_GDN) epilogue(std::integral_constant<int, 1>{});
-    else if (p.epi == VC_EPI_IGDN) epilogue(std::integral_constant<int, 2>{});
-    else if (p.act == VC_ACT_SIGMOID) epilogue(std::integral_constant<int, 3>{});
-    else if (p.act == VC_ACT_CLAMP01) epilogue(std::integral_constant<int, 4>{});
-    else epilogue(std::integral_constant<int, 0>{});
+    if constexpr (F16 && C::MT == 32 && G::LDS_FLOATS >= 4 * VC_EPI_SCRATCH_FLOATS) {
+        if (p.vec_out && p.epi == VC_EPI_NONE) {
+            __syncthreads();          // every wave has left the contraction loop: the tile image can serve as scratch
+            conv_epilogue_coalesced<C>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, lds + wave * VC_EPI_SCRATCH_FLOATS);
+        } else {
+            conv_epilogue<C, F16>(p, acc, nblk, wm, wn, lane, oy0, ox0, img);
+        }
+    } else {
+        conv_epilogue<C, F16>(p, acc, nblk, wm, wn, lane, oy0, ox0, img);
+    }
     VC_T(t_end);
     VC_ACC(4, t_end, t_loop_end);   // epilogue
     VC_ACC(5, t_end, t_start);      // whole wave lifetime after the prologue
