@@ -9,7 +9,11 @@ kernels are ignored)."""
 import csv
 import glob
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def mean_counter(directory, counter):
@@ -32,8 +36,10 @@ def main():
         write, nw = mean_counter(wdir, "WRITE_SIZE")
         kernels[label] = {"FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches_averaged": [nf, nw],
                           "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0}
+    from bench import kernel_source_stamp       # bench.py refuses this file once the kernel sources have changed
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on tools/conv_bench.py (VC_AUTOTUNE=0, tile "
                        "configuration pinned to the one bench.py's autotuner settles on); FETCH_SIZE doubled per the gfx950 correction",
+               "kernel_source_stamp": kernel_source_stamp(),
                "kernels": kernels}, open(out, "w"), indent=1)
     print(json.dumps(kernels, indent=1))
 
