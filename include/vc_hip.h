@@ -247,6 +247,11 @@ int vc_gc_dequant(vc_stream s, const int32_t *symbols, vc_view means, const floa
 int vc_bits_reduce(vc_stream s, const double *partial, int slots, int count, double *out);
 /* number of partial-sum slots each entropy launch uses (size bits_partial accordingly) */
 int vc_bits_slots(void);
+/* PSNR as the evaluation loops measure it (LHBDC/test/testing.py:176-182, test/utils.py:32-51): clamp both CHW fp32 images
+ * (row pitch W, plane pitch H*W) to [0,1], x255, round half to even, mean squared error over the [:h,:w] crop of all
+ * channels in double, 10*log10(255^2/mse) -> *psnr_out (device).  scratch: vc_bits_slots() doubles (device). */
+int vc_psnr_uint8(vc_stream s, const float *a_chw, const float *b_chw, int channels, int H, int W, int h, int w,
+                  double *scratch, int slots, double *psnr_out);
 
 /* ------------------------------------------------------------------------------------------
  * Range coder (host).  Replaces compressai._CXX.pmf_to_quantized_cdf and

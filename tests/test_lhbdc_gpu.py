@@ -197,6 +197,22 @@ def test_batch_of_frames_equals_one_by_one(dev, models):
     assert abs(bits - (singles[0][2] + singles[1][2])) < 1e-6 * bits
 
 
+def test_frame_lists_equal_batched_tensors(dev, models):
+    """The level passes of a GOP hand the frames they batch over as LISTS (assembled by the layout kernels, no torch.cat):
+    identical to the same frames concatenated by the caller, bit for bit -- any split of the batch."""
+    _, prod = models
+    g = torch.Generator().manual_seed(23)
+    base = torch.nn.functional.avg_pool2d(torch.rand(3, 3, 200, 266, generator=g), 9, 1)
+    xb, xc, xa = (base[..., :192, i:i + 256].contiguous().to(dev) for i in (0, 1, 2))
+    with torch.no_grad():
+        whole, tot = prod.forward_device(xb, xc, xa)
+        as_list, tot_l = prod.forward_device([xb[0:1], xb[1:2], xb[2:3]], [xc[0:1], xc[1:3]], [xa[0:2], xa[2:3]])
+    assert torch.equal(whole, as_list) and torch.equal(tot, tot_l)
+    from vcamd import hip
+    with pytest.raises(hip.VcError):
+        prod.forward_device([xb[0:1]], [xc[0:1], xc[1:2]], [xa[0:1]])
+
+
 def test_full_size_1080p_properties(dev, models):
     """BASELINE size (1088x1920): (1) encode_B -> container -> decode_B twice gives identical frames
     (deterministic kernels), (2) the real bitstream never exceeds the likelihood estimate of the same latents by

@@ -582,3 +582,24 @@ def test_survey_named_entry_points_forward_to_the_same_kernels(dev):
     hip.check(L.vc_pad(hip.stream(), t.view(), padded.view()), "vc_pad")
     ref_pad = torch.nn.ReflectionPad2d((0, 64 - 45, 0, 48 - 30))(img)
     assert torch.equal(hip.nhwc_to_nchw(padded).cpu(), ref_pad)
+
+
+def test_psnr_uint8_kernel_matches_the_reference_formula(dev):
+    """vc_psnr_uint8 == utils.py:32-51 / testing.py:176-182: clamp, x255, round half to even, MSE of the crop in double."""
+    from vcamd import hip
+    g = torch.Generator().manual_seed(61)
+    a = (torch.rand(2, 3, 128, 192, generator=g) * 1.2 - 0.1)
+    b = (a + 0.05 * torch.randn(2, 3, 128, 192, generator=g))
+    a[0, 0, 0, :4] = torch.tensor([0.5 / 255.0, 1.5 / 255.0, 2.5 / 255.0, 254.5 / 255.0])      # exact ties -> half to even
+    for h, w in ((128, 192), (120, 180), (1, 1)):
+        qa = torch.round(torch.clamp(a[0, :, :h, :w], 0, 1) * 255.0).double()
+        qb = torch.round(torch.clamp(b[0, :, :h, :w], 0, 1) * 255.0).double()
+        mse = torch.mean((qa - qb) ** 2)
+        ref = float(10.0 * torch.log10(255.0 ** 2 / mse)) if mse > 0 else float("inf")
+        got = float(hip.psnr_uint8(a.to(dev), b.to(dev), h, w))
+        assert got == pytest.approx(ref, rel=1e-12, abs=1e-12) or (ref == float("inf") and got == float("inf")), (h, w, got, ref)
+    out = torch.zeros(3, dtype=torch.float64, device=dev)
+    hip.psnr_uint8(a.to(dev), b.to(dev), 128, 192, out=out[1])                   # writes into a caller-provided slot
+    assert float(out[0]) == 0.0 and float(out[2]) == 0.0 and float(out[1]) > 0.0
+    with pytest.raises(hip.VcError):
+        hip.psnr_uint8(a, b, 8, 8)                                               # CPU tensors: no fallback

@@ -335,3 +335,50 @@ extern "C" int vc_select_flow(vc_stream s, const double *sse, int count, double 
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// PSNR of the evaluation loops (LHBDC/test/testing.py:176-182, test/utils.py:32-51): both frames are clamped to
+// [0,1], scaled to 0..255 and rounded (half to even, like torch.round), the squared error is averaged over the
+// un-padded [:h, :w] crop of all channels in double precision, PSNR = 10 log10(255^2 / mse).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ENT_BLOCK) k_sse_uint8(const float *__restrict__ a, const float *__restrict__ b, int C, int H, int W,
+                                                         int h, int w, double *__restrict__ partial)
+{
+    __shared__ double sm[ENT_BLOCK / 64];
+    double acc = 0.0;
+    const long long total = (long long)C * h * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        long long t = i / w;
+        const int y = (int)(t % h);
+        const int c = (int)(t / h);
+        const long long o = ((long long)c * H + y) * W + x;
+        const float qa = rintf(fminf(fmaxf(a[o], 0.0f), 1.0f) * 255.0f);
+        const float qb = rintf(fminf(fmaxf(b[o], 0.0f), 1.0f) * 255.0f);
+        const double d = (double)qa - (double)qb;
+        acc += d * d;
+    }
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ void k_psnr_from_sse(const double *__restrict__ partial, int slots, double count, double *__restrict__ out)
+{
+    __shared__ double sm[ENT_BLOCK / 64];
+    double v = 0.0;
+    for (int j = threadIdx.x; j < slots; j += blockDim.x) v += partial[j];
+    const double r = block_sum(v, sm);
+    if (threadIdx.x == 0) *out = 10.0 * log10(255.0 * 255.0 / (r / count));
+}
+
+extern "C" int vc_psnr_uint8(vc_stream s, const float *a_chw, const float *b_chw, int channels, int H, int W, int h, int w,
+                             double *scratch, int slots, double *psnr_out)
+{
+    if (!a_chw || !b_chw || !scratch || !psnr_out || slots != ENT_SLOTS) return VC_EINVAL;
+    if (channels < 1 || h < 1 || w < 1 || h > H || w > W) return VC_EINVAL;
+    hipLaunchKernelGGL(k_sse_uint8, dim3(ENT_SLOTS), dim3(ENT_BLOCK), 0, as_stream(s), a_chw, b_chw, channels, H, W, h, w, scratch);
+    VC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_psnr_from_sse, dim3(1), dim3(ENT_BLOCK), 0, as_stream(s), scratch, slots, (double)channels * h * w, psnr_out);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}

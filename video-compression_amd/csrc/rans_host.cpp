@@ -132,27 +132,32 @@ extern "C" int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, c
         refill();
         return v;
     };
+    // Symbol lookup: the format's reference decoder scans the table linearly.  Here every table gets a 256-entry
+    // jump table over the top 8 bits of the cumulative value (first bin that can contain it), built once per call
+    // (n_tables x 256 steps, negligible next to the symbols); the scan then starts at most a few bins before the
+    // answer whatever the table length -- the decoder is what a frame's host time is made of (1 M symbols).
+    constexpr int kLutBits = 8;
+    thread_local std::vector<uint16_t> lut;
+    lut.resize(static_cast<size_t>(n_tables) << kLutBits);
+    for (int t = 0; t < n_tables; ++t) {
+        const int32_t *cdf = cdfs + static_cast<size_t>(t) * cdf_stride;
+        const int32_t n = cdf_sizes[t];
+        uint16_t *row = lut.data() + (static_cast<size_t>(t) << kLutBits);
+        int32_t j = 0;
+        for (uint32_t b = 0; b < (1u << kLutBits); ++b) {
+            const uint32_t lo = b << (16 - kLutBits);
+            while (j + 1 < n - 1 && static_cast<uint32_t>(cdf[j + 1]) <= lo) ++j;   // last bin starting at or before lo
+            row[b] = static_cast<uint16_t>(j);
+        }
+    }
     for (size_t i = 0; i < count; ++i) {
         const int32_t t = indexes[i];
         if (static_cast<uint32_t>(t) >= static_cast<uint32_t>(n_tables)) return VC_EINVAL;
         const int32_t *cdf = cdfs + static_cast<size_t>(t) * cdf_stride;
         const int32_t n = cdf_sizes[t], escape = n - 2;
         const uint32_t cum = static_cast<uint32_t>(x & 0xFFFFu);
-        // tables are short for the frequent (small-scale) contexts: linear scan like the format's reference
-        // decoder, switched to bisection for the long ones
-        int32_t sidx;
-        if (n <= 32) {
-            int32_t j = 1;
-            while (j < n && static_cast<uint32_t>(cdf[j]) <= cum) ++j;
-            sidx = j - 1;
-        } else {
-            int32_t lo_i = 0, hi_i = n - 1;  // invariant: cdf[lo_i] <= cum < cdf[hi_i]
-            while (hi_i - lo_i > 1) {
-                const int32_t mid = (lo_i + hi_i) >> 1;
-                if (static_cast<uint32_t>(cdf[mid]) <= cum) lo_i = mid; else hi_i = mid;
-            }
-            sidx = lo_i;
-        }
+        int32_t sidx = lut[(static_cast<size_t>(t) << kLutBits) + (cum >> (16 - kLutBits))];
+        while (sidx + 1 < n - 1 && static_cast<uint32_t>(cdf[sidx + 1]) <= cum) ++sidx;
         const uint32_t start = static_cast<uint32_t>(cdf[sidx]);
         const uint32_t range = static_cast<uint32_t>(cdf[sidx + 1]) - start;
         x = static_cast<uint64_t>(range) * (x >> kProbBits) + (x & 0xFFFFu) - start;

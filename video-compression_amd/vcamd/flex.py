@@ -17,7 +17,7 @@ from . import hip
 from .hip import T
 from .layers import (BitCounter, MeanScaleHyperprior, ResidualBlock, ResidualBlockUpsample, ResidualBlockWithStride,
                      _Prepared, conv3x3, pack_conv, subpel_conv3x3)
-from .lhbdc import _require_cuda, _require_frames
+from .lhbdc import _count, _require_cuda, _require_frames, frame_list
 
 
 # ------------------------------------------------------------------------------------------------
@@ -223,14 +223,14 @@ class BidirFlowRef(nn.Module):
     # -- channels-last stages ----------------------------------------------------------------------
     def _process_t(self, xb_, xa_, xc_=None, t=0.5):
         """b_model.py:35-45 into one 19-channel buffer [Ft0 | Ft1 | x0 | x1 | warp(x0) | warp(x1) | x_cur]."""
-        n, _, h, w = xb_.shape
-        dev = xb_.device
+        xb_, xa_ = frame_list(xb_), frame_list(xa_)         # tensors or lists of frames (no torch.cat of a level's frames)
+        n, (_, _, h, w), dev = _count(xb_), xb_[0].shape, xb_[0].device
         L = hip.lib()
         buf = T.empty(n, h, w, 19, dev)
-        hip.check(L.vc_nchw_to_nhwc(hip.stream(), xb_.data_ptr(), buf.channels(4, 7).view()), "vc_nchw_to_nhwc")
-        hip.check(L.vc_nchw_to_nhwc(hip.stream(), xa_.data_ptr(), buf.channels(7, 10).view()), "vc_nchw_to_nhwc")
+        hip.nchw_frames_to_nhwc(xb_, out=buf.channels(4, 7))
+        hip.nchw_frames_to_nhwc(xa_, out=buf.channels(7, 10))
         if xc_ is not None:
-            hip.check(L.vc_nchw_to_nhwc(hip.stream(), xc_.data_ptr(), buf.channels(16, 19).view()), "vc_nchw_to_nhwc")
+            hip.nchw_frames_to_nhwc(frame_list(xc_), out=buf.channels(16, 19))
         flow = self.flow_predictor.run(buf.channels(4, 10))
         ft0, ft1 = buf.channels(0, 2), buf.channels(2, 4)
         hip.check(L.vc_flex_motion_split(hip.stream(), flow.view(), ft0.view(), ft1.view(), t), "vc_flex_motion_split")
@@ -269,8 +269,8 @@ class BidirFlowRef(nn.Module):
         flow.y, flow.z, res.y, res.z per frame).  A batch codes B independent frames at the SAME rate point (n, l) --
         the frames of one hierarchy level of a GOP (gop.code_gop_flex)."""
         _require_frames(x_before, x_current, x_after)
-        xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
-        dev, b = xc_.device, xc_.shape[0]
+        xb_, xc_, xa_ = (frame_list(t) for t in (x_before, x_current, x_after))
+        dev, b = xc_[0].device, _count(xc_)
         buf = self._process_t(xb_, xa_, xc_)
         bits = BitCounter(dev, max_rows=4 * b)
         t_mv, t_res = ({}, {}) if trace is not None else (None, None)     # parity instrumentation (tests / bench.py)

@@ -30,11 +30,10 @@ FLEX_QUALITIES = [
 
 
 def psnr_uint8(x_hat, x, h, w):
-    """testing.py:176-182 / utils.py:32-51: PSNR of round(clip(.,0,1)*255) on the un-padded crop."""
-    a = torch.round(torch.clamp(x_hat[0, :, :h, :w], 0, 1) * 255.0).double()
-    b = torch.round(torch.clamp(x[0, :, :h, :w], 0, 1) * 255.0).double()
-    mse = torch.mean((a - b) ** 2)
-    return 10.0 * torch.log10(255.0 ** 2 / mse)
+    """testing.py:176-182 / utils.py:32-51: PSNR of round(clip(.,0,1)*255) on the un-padded crop of the first image --
+    one HIP kernel pair (vc_psnr_uint8), result left on the device."""
+    from . import hip
+    return hip.psnr_uint8(x_hat, x, h, w)
 
 
 LEVEL_GROUPS = [[4], [2, 6], [1, 3, 5, 7]]                    # frames of one hierarchy level are independent
@@ -54,9 +53,10 @@ def code_gop_lhbdc(model, gop, dec_first, dec_last, h, w, records=None, video=0,
     stats = {}
     groups = LEVEL_GROUPS if batch_levels else [[o] for o in CODING_ORDER[2:]]
     for group in groups:
-        xb = torch.cat([decoded[DECODING_INFO[o][0]] for o in group], 0)
-        xc = torch.cat([gop[o] for o in group], 0)
-        xa = torch.cat([decoded[DECODING_INFO[o][1]] for o in group], 0)
+        # (lists of frames: the layout kernels assemble the batch -- no torch.cat copies)
+        xb = [decoded[DECODING_INFO[o][0]] for o in group]
+        xc = [gop[o] for o in group]
+        xa = [decoded[DECODING_INFO[o][1]] for o in group]
         x_hat, tot = model.forward_device(xb, xc, xa)
         for i, o in enumerate(group):
             decoded[o] = x_hat[i:i + 1]
@@ -77,9 +77,9 @@ def code_gops_lhbdc(model, gops, bounds, h, w, records=None, video=0, first_gop_
     decoded = [{0: b[0], 8: b[1]} for b in bounds]
     stats = [{} for _ in gops]
     for group in LEVEL_GROUPS:
-        xb = torch.cat([decoded[g][DECODING_INFO[o][0]] for g in range(len(gops)) for o in group], 0)
-        xc = torch.cat([gops[g][o] for g in range(len(gops)) for o in group], 0)
-        xa = torch.cat([decoded[g][DECODING_INFO[o][1]] for g in range(len(gops)) for o in group], 0)
+        xb = [decoded[g][DECODING_INFO[o][0]] for g in range(len(gops)) for o in group]
+        xc = [gops[g][o] for g in range(len(gops)) for o in group]
+        xa = [decoded[g][DECODING_INFO[o][1]] for g in range(len(gops)) for o in group]
         x_hat, tot = model.forward_device(xb, xc, xa)
         i = 0
         for g in range(len(gops)):
@@ -111,9 +111,9 @@ def code_gops_flex(model, gops, bounds, h, w, quality, records=None, video=0, fi
     ng = range(len(gops))
     for group in groups:
         n, l = table[HIER_LEVELS_16[group[0]]]
-        xb = torch.cat([decoded[g][DECODING_INFO_16[o][0]] for g in ng for o in group], 0)
-        xc = torch.cat([gops[g][o] for g in ng for o in group], 0)
-        xa = torch.cat([decoded[g][DECODING_INFO_16[o][1]] for g in ng for o in group], 0)
+        xb = [decoded[g][DECODING_INFO_16[o][0]] for g in ng for o in group]
+        xc = [gops[g][o] for g in ng for o in group]
+        xa = [decoded[g][DECODING_INFO_16[o][1]] for g in ng for o in group]
         x_hat, tot = model.forward_device(xb, xc, xa, n=[n], l=l)
         i = 0
         for g in ng:

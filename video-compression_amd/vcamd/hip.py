@@ -139,6 +139,7 @@ def lib():
     sig("vc_gc_dequant", ci, vp, vp, View, vp, View)
     sig("vc_bits_reduce", ci, vp, vp, ci, ci, vp)
     sig("vc_bits_slots", ci)
+    sig("vc_psnr_uint8", ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp)
     sig("vc_gdn", ci, vp, View, vp, vp, ci, View, View)
     sig("vc_pad", ci, vp, View, View)
     sig("vc_pmf_to_quantized_cdf", ci, vp, ci, ci, vp)
@@ -157,7 +158,7 @@ EXPORTED_SYMBOLS = [
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
-    "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
+    "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_psnr_uint8", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes",
     # the operator spellings of SURVEY.md 8(b), thin forwards (csrc/abi_aliases.cpp)
     "vc_gdn", "vc_spynet_level", "vc_pool", "vc_upsample", "vc_pad", "vc_blend", "vc_factorized_bits", "vc_gaussian_symbols",
@@ -460,6 +461,42 @@ def channel_scale(x, gain, out=None):
     if out is None:
         out = T.empty(x.n, x.h, x.w, x.c, x.buf.device)
     check(lib().vc_channel_scale(stream(), x.view(), gain.data_ptr(), out.view()), "vc_channel_scale")
+    return out
+
+
+def psnr_uint8(x_hat, x, h, w, out=None):
+    """PSNR of the first image of two NCHW fp32 CUDA tensors on the uint8-rounded [:h,:w] crop (vc_psnr_uint8); returns a
+    0-dim float64 device tensor (``out``: a 0-dim float64 view to write into) -- no host synchronisation."""
+    if x_hat.dtype != torch.float32 or x.dtype != torch.float32 or not x_hat.is_cuda or not x.is_cuda:
+        raise VcError("psnr_uint8 takes fp32 CUDA tensors")
+    if x_hat.dim() != 4 or x.shape[1:] != x_hat.shape[1:]:
+        raise VcError("psnr_uint8: NCHW tensors of the same frame size")
+    a, b = x_hat[0], x[0]
+    if not a.is_contiguous() or not b.is_contiguous():
+        a, b = a.contiguous(), b.contiguous()
+    slots = lib().vc_bits_slots()
+    scratch = torch.empty(slots, dtype=torch.float64, device=x.device)
+    if out is None:
+        out = torch.empty((), dtype=torch.float64, device=x.device)
+    check(lib().vc_psnr_uint8(stream(), a.data_ptr(), b.data_ptr(), a.shape[0], a.shape[1], a.shape[2], int(h), int(w),
+                              scratch.data_ptr(), slots, out.data_ptr()), "vc_psnr_uint8")
+    return out
+
+
+def nchw_frames_to_nhwc(frames, out=None):
+    """A list of [k,C,H,W] fp32 CUDA tensors -> ONE batched channels-last window, image by image: the batch of a level pass
+    is assembled by the layout kernel itself (no torch.cat copy of the frames)."""
+    total = sum(int(f.shape[0]) for f in frames)
+    _, c, h, w = frames[0].shape
+    if out is None:
+        out = T.empty(total, h, w, c, frames[0].device)
+    i = 0
+    for f in frames:
+        f = f.contiguous().float()
+        if tuple(f.shape[1:]) != (c, h, w):
+            raise VcError("frames of one pass must have the same shape")
+        check(lib().vc_nchw_to_nhwc(stream(), f.data_ptr(), out.images(i, i + f.shape[0]).view()), "vc_nchw_to_nhwc")
+        i += f.shape[0]
     return out
 
 

@@ -571,6 +571,67 @@ class MeanScaleHyperprior(_Prepared):
         y_strings = [hip.rans_encode(y_sym_h[i], y_idx_h[i], gc_cdf, gc_len, gc_off) for i in range(y.n)]
         return [y_strings, z_strings], (z.h, z.w)
 
+    # -- building blocks of the pipelined bitstream codec (vcamd/bitstream.py) -------------------------------
+    def code_t(self, x, gains=(None, None, None, None), code_ungained_y=False):
+        """ONE analysis pass that yields both what an encoder needs: the reconstruction x_hat (exactly what the decoder
+        will rebuild from the coded integers) and the integers themselves, left on the device for an asynchronous copy:
+        returns (x_hat T, {"y_sym", "y_idx", "z_sym": int32 [n, count], "shape": (hz, wz)}).  Equivalent to
+        forward_t + compress_t without running g_a / h_a / h_s twice."""
+        g, ig, hg, hig = gains
+        L = hip.lib()
+        dev = x.buf.device
+        if g is not None and code_ungained_y:
+            y_raw = run_sequential(self.g_a, x, self._cache["g_a"])
+            y = T.empty(y_raw.n, y_raw.h, y_raw.w, y_raw.c, dev)
+            hip.check(L.vc_channel_scale(hip.stream(), y_raw.view(), g.data_ptr(), y.view()), "vc_channel_scale")
+        else:
+            y_raw = None
+            y = run_sequential(self.g_a, x, self._cache["g_a"], final_chscale=g)
+        z = run_sequential(self.h_a, y, self._cache["h_a"])
+        z_hat = T.empty(z.n, z.h, z.w, z.c, dev)
+        z_sym = torch.empty((z.n, z.c * z.h * z.w), dtype=torch.int32, device=dev)
+        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
+                                  None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
+                                  z_hat.view(), z_sym.data_ptr(), None, 0, None), "vc_eb_forward")
+        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        m = self.M
+        scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
+        y_hat = T.empty(y.n, y.h, y.w, y.c, dev)
+        y_sym = torch.empty((y.n, y.c * y.h * y.w), dtype=torch.int32, device=dev)
+        y_idx = torch.empty_like(y_sym)
+        table = self._scale_table_dev()
+        hip.check(L.vc_gc_forward(hip.stream(), y.view(), scales.view(), means.view(), None, None if ig is None else ig.data_ptr(),
+                                  y_hat.view(), None, 0, None if y_raw is None else y_raw.ptr, y_sym.data_ptr(), y_idx.data_ptr(),
+                                  table.data_ptr(), table.numel(), None), "vc_gc_forward")
+        x_hat = run_sequential(self.g_s, y_hat, self._cache["g_s"])
+        return x_hat, {"y_sym": y_sym, "y_idx": y_idx, "z_sym": z_sym, "shape": (z.h, z.w)}
+
+    def hyper_decode_t(self, z_sym_d, n, shape, gains=(None, None, None, None)):
+        """Decoder, first half (device): hyper-latent symbols [n, C*hz*wz] -> (means T, scale-table indexes int32 device
+        tensor [n, M*hy*wy]) -- everything the host needs to decode the y strings."""
+        g, ig, hg, hig = gains
+        L = hip.lib()
+        device = z_sym_d.device
+        hz, wz = int(shape[0]), int(shape[1])
+        z_hat = T.empty(n, hz, wz, self.N, device)
+        hip.check(L.vc_eb_dequant(hip.stream(), z_sym_d.data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
+                                  None if hig is None else hig.data_ptr(), z_hat.view()), "vc_eb_dequant")
+        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        m = self.M
+        scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
+        idx_d = torch.empty((n, m * gp.h * gp.w), dtype=torch.int32, device=device)
+        table = self._scale_table_dev()
+        hip.check(L.vc_gc_indexes(hip.stream(), scales.view(), table.data_ptr(), table.numel(), idx_d.data_ptr()), "vc_gc_indexes")
+        return means, idx_d
+
+    def synth_decode_t(self, y_sym_d, means, gains=(None, None, None, None), final_act=None):
+        """Decoder, second half (device): y symbols [n, M*hy*wy] + the means of hyper_decode_t -> x_hat T."""
+        g, ig, hg, hig = gains
+        y_hat = T.empty(means.n, means.h, means.w, self.M, y_sym_d.device)
+        hip.check(hip.lib().vc_gc_dequant(hip.stream(), y_sym_d.data_ptr(), means.view(), None if ig is None else ig.data_ptr(),
+                                          y_hat.view()), "vc_gc_dequant")
+        return run_sequential(self.g_s, y_hat, self._cache["g_s"], final_act=final_act)
+
     def decompress_t(self, strings, shape, device, gains=(None, None, None, None), final_act=None, trace=None):
         """``trace``: a dict that receives the decoder's integers ("z_sym", "y_idx", "y_sym": host int32 [n, count])."""
         assert isinstance(strings, list) and len(strings) == 2

@@ -26,19 +26,39 @@ def _require_cuda(x):
         raise hip.VcError("inputs must be CUDA (HIP) tensors: this implementation has no CPU path")
 
 
-def _require_frames(*frames):
-    """The caller pads frames to a multiple of 64 (encode_B.py:49-56, test/utils.py `pad`); the reference fails with
-    shape mismatches deep inside otherwise -- fail early and clearly instead."""
-    shape = None
-    for f in frames:
+def frame_list(x):
+    """A batch of frames as a list of contiguous fp32 [k,3,H,W] tensors.  ``x`` is one NCHW tensor or a list / tuple of
+    them: the level passes of a GOP hand over the frames they batch as a LIST, and the layout kernels assemble the
+    batch image by image (no torch.cat copy)."""
+    items = list(x) if isinstance(x, (list, tuple)) else [x]
+    for f in items:
         _require_cuda(f)
-        if f.dim() != 4 or f.shape[1] != 3:
-            raise hip.VcError(f"expected [N,3,H,W] frames, got {tuple(f.shape)}")
-        if f.shape[2] % 64 or f.shape[3] % 64:
-            raise hip.VcError(f"frame size {f.shape[2]}x{f.shape[3]} is not a multiple of 64: pad it first (pad/process_frame)")
-        if shape is not None and tuple(f.shape) != shape:
+    return [f.contiguous().float() for f in items]
+
+
+def _count(frames):
+    return sum(int(f.shape[0]) for f in frames)
+
+
+def _require_frames(*groups):
+    """The caller pads frames to a multiple of 64 (encode_B.py:49-56, test/utils.py `pad`); the reference fails with
+    shape mismatches deep inside otherwise -- fail early and clearly instead.  Each argument: a tensor or a list of them."""
+    shape, count = None, None
+    for g in groups:
+        items = list(g) if isinstance(g, (list, tuple)) else [g]
+        for f in items:
+            _require_cuda(f)
+            if f.dim() != 4 or f.shape[1] != 3:
+                raise hip.VcError(f"expected [N,3,H,W] frames, got {tuple(f.shape)}")
+            if f.shape[2] % 64 or f.shape[3] % 64:
+                raise hip.VcError(f"frame size {f.shape[2]}x{f.shape[3]} is not a multiple of 64: pad it first (pad/process_frame)")
+            if shape is not None and tuple(f.shape[1:]) != shape:
+                raise hip.VcError("all frames of a triple must have the same shape")
+            shape = tuple(f.shape[1:])
+        n = sum(int(f.shape[0]) for f in items)
+        if count is not None and n != count:
             raise hip.VcError("all frames of a triple must have the same shape")
-        shape = tuple(f.shape)
+        count = n
 
 
 # ------------------------------------------------------------------------------------------------
@@ -257,13 +277,17 @@ class Model(nn.Module):
     def _flows(self, frames, pairs):
         """Batched SPyNet: ``pairs`` = list of (first, second) keys into ``frames`` (NCHW tensors).
         Each distinct frame is pre-processed once; all pairs run as one batch per pyramid level."""
-        n, _, h, w = next(iter(frames.values())).shape
-        dev = next(iter(frames.values())).device
+        frames = {k_: frame_list(v) for k_, v in frames.items()}
+        some = next(iter(frames.values()))
+        n, (_, _, h, w), dev = _count(some), some[0].shape, some[0].device
         k = len(pairs)
         first, second = T.empty(k * n, h, w, 3, dev), T.empty(k * n, h, w, 3, dev)
         for i, (a, b) in enumerate(pairs):
-            self.FlowNet.preprocess_into(frames[a], first.images(i * n, (i + 1) * n))
-            self.FlowNet.preprocess_into(frames[b], second.images(i * n, (i + 1) * n))
+            for dst, key in ((first, a), (second, b)):
+                j = i * n
+                for f in frames[key]:
+                    self.FlowNet.preprocess_into(f, dst.images(j, j + f.shape[0]))
+                    j += f.shape[0]
         return self.FlowNet.flow_t(Network.pyramid(first), Network.pyramid(second))
 
     @staticmethod
@@ -301,9 +325,9 @@ class Model(nn.Module):
         (the four SPyNet fields ba, ab, cb, ca), "mv_hat", "mask", "pred", "resid" as T windows and "mv" / "res" = the
         compressors' traces (MeanScaleHyperprior.forward_t)."""
         _require_frames(x_before, x_current, x_after)
-        xb_, xc_, xa_ = (t.contiguous().float() for t in (x_before, x_current, x_after))
-        n = xc_.shape[0]
-        dev = xc_.device
+        xb_, xc_, xa_ = (frame_list(t) for t in (x_before, x_current, x_after))     # tensors or lists of frames
+        n = _count(xc_)
+        dev = xc_[0].device
         frames = {"b": xb_, "c": xc_, "a": xa_}
         # m.py:38-47 -- four SPyNet calls as one batch: ba, ab, cb, ca
         flows = self._flows(frames, [("b", "a"), ("a", "b"), ("c", "b"), ("c", "a")])
@@ -317,7 +341,7 @@ class Model(nn.Module):
         bits = BitCounter(dev, max_rows=4 * n)
         t_mv, t_res = ({}, {}) if trace is not None else (None, None)
         mv_hat = self.mv_compressor.forward_t(diff, bits, trace=t_mv)
-        xb, xc, xa = hip.nchw_to_nhwc(xb_), hip.nchw_to_nhwc(xc_), hip.nchw_to_nhwc(xa_)
+        xb, xc, xa = hip.nchw_frames_to_nhwc(xb_), hip.nchw_frames_to_nhwc(xc_), hip.nchw_frames_to_nhwc(xa_)
         pred, resid = self._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww, cur=xc, trace=trace)
         res_hat = self.residual_compressor.forward_t(resid, bits, trace=t_res)
         if trace is not None:
@@ -329,7 +353,7 @@ class Model(nn.Module):
 
     def forward(self, x_before, x_current, x_after, train=False):
         x_hat, tot = self.forward_device(x_before, x_current, x_after)
-        n, _, h, w = x_current.shape
+        n, _, h, w = x_hat.shape
         num_pixels = n * h * w
         size = tot.sum()
         rate = (size / num_pixels / 2.0).to(torch.float32)                   # m.py:96,98 (halved)
