@@ -269,6 +269,12 @@ long long vc_rans_encode_with_indexes(const int32_t *symbols, const int32_t *ind
 int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, const int32_t *indexes, size_t count,
                                 const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes,
                                 const int32_t *offsets, int32_t *symbols_out);
+/* compressai.ans.RansDecoder.set_stream + decode_stream (ICIP2024/src/model/elic.py:428-429,566,584: the checkerboard
+ * codec decodes one string in two calls, the second call's indexes depending on the first call's symbols).
+ * state[2] = {coder state, next 32-bit word}; {0, 0} starts a stream; updated in place. */
+int vc_rans_decode_stream(const uint8_t *data, size_t nbytes, uint64_t *state, const int32_t *indexes, size_t count,
+                          const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes,
+                          const int32_t *offsets, int32_t *symbols_out);
 
 /* ------------------------------------------------------------------------------------------
  * Entry points under the operator names SURVEY.md section 8(b) lists for the boundary.  Thin forwards to the

@@ -31,6 +31,9 @@ def _lib():
                                                      i32p, ctypes.c_size_t, i32p, ctypes.c_int,
                                                      i32p, i32p, i32p]
         lib.vco_rans_decode_with_indexes.restype = ctypes.c_int
+        lib.vco_rans_decode_stream.argtypes = [ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint64),
+                                               i32p, ctypes.c_size_t, i32p, ctypes.c_int, i32p, i32p, i32p]
+        lib.vco_rans_decode_stream.restype = ctypes.c_int
         lib.vco_free.argtypes = [ctypes.c_void_p]
         _LIB = lib
     return _LIB
@@ -99,12 +102,45 @@ class RansEncoder:
 
 
 class RansDecoder:
+    """decode_with_indexes (whole string) and set_stream / decode_stream (ICIP2024/src/model/elic.py:428-429,566,584: one
+    string read in several calls, each continuing from the coder state the previous call left)."""
+
     def decode_with_indexes(self, *args):
         return decode_with_indexes(*args).tolist()
 
+    def set_stream(self, data):
+        self._buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        self._state = np.zeros(2, dtype=np.uint64)
+
+    def decode_stream(self, indexes, cdfs, cdf_sizes, offsets):
+        idx = _i32(indexes).reshape(-1)
+        dense = _dense_cdfs(cdfs)
+        sizes, offs = _i32(cdf_sizes).reshape(-1), _i32(offsets).reshape(-1)
+        out = np.zeros(idx.size, dtype=np.int32)
+        rc = _lib().vco_rans_decode_stream(_ptr(self._buf, ctypes.c_uint8), self._buf.size, _ptr(self._state, ctypes.c_uint64),
+                                           _ptr(idx), idx.size, _ptr(dense), dense.shape[1], _ptr(sizes), _ptr(offs), _ptr(out))
+        if rc != 0:
+            raise RuntimeError("oracle rANS stream decode failed")
+        return out.tolist()
+
 
 class BufferedRansEncoder:
-    """Imported by ICIP2024/src/model/compression_bottlenecks.py:11; the ICIP2024 path only estimates rate."""
+    """compressai.ans.BufferedRansEncoder (ICIP2024/src/model/elic.py:329,404-407): encode_with_indexes only queues its
+    symbols; flush() codes everything queued -- in reverse, as one rANS string -- and empties the queue.  One flush over
+    several queued calls therefore equals RansEncoder.encode_with_indexes on the concatenated lists."""
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError("BufferedRansEncoder is not on the hot path")
+    def __init__(self):
+        self._sym, self._idx, self._tables = [], [], None
+
+    def encode_with_indexes(self, symbols, indexes, cdfs, cdf_sizes, offsets):
+        self._sym.extend(int(v) for v in symbols)
+        self._idx.extend(int(v) for v in indexes)
+        self._tables = (cdfs, cdf_sizes, offsets)
+
+    def flush(self):
+        if self._tables is None:
+            data = encode_with_indexes([], [], np.zeros((1, 3), dtype=np.int32), [3], [0])
+        else:
+            data = encode_with_indexes(self._sym, self._idx, *self._tables)
+        self._sym, self._idx = [], []
+        return data

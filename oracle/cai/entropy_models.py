@@ -28,6 +28,19 @@ class EntropyModel(nn.Module):
         self.register_buffer("_quantized_cdf", torch.IntTensor())
         self.register_buffer("_cdf_length", torch.IntTensor())
 
+    # read-only views CompressAI exposes (used by ICIP2024/src/model/elic.py:310-312)
+    @property
+    def offset(self):
+        return self._offset
+
+    @property
+    def quantized_cdf(self):
+        return self._quantized_cdf
+
+    @property
+    def cdf_length(self):
+        return self._cdf_length
+
     # -- quantisation ------------------------------------------------------------------
     @staticmethod
     def quantize(inputs, mode, means=None):

@@ -376,6 +376,32 @@ def gen_icip2024(outdir, frames, seed):
     check("ELIC size", size_o, size_r)
     np.savez_compressed(os.path.join(outdir, "icip2024_elic_a.npz"), seed=np.int64(seed + 1), conv_gain=np.float64(0.7),
                         current=c["current"], x_hat=dec_r.numpy(), size=np.float64(size_r.item()))
+    # ELIC real bitstream (elic.py:307-496) and forward_stage2 (:247-305), run from the reference's own methods with the
+    # stand-in compressai.ans (BufferedRansEncoder / RansDecoder streams); torch.cuda.synchronize is a no-op on CPU here
+    torch.cuda.synchronize = lambda *a, **k: None
+    for mdl in (ref_i, ora_i):
+        mdl.update(force=True)
+    with torch.no_grad():
+        s2_r, s2_o = ref_i.forward_stage2(xc), ora_i.forward_stage2(xc)
+        check("ELIC forward_stage2 x_hat", s2_o["x_hat"], s2_r["x_hat"])
+        for k_ in s2_r["likelihoods"]:
+            check(f"ELIC forward_stage2 lik {k_}", s2_o["likelihoods"][k_], s2_r["likelihoods"][k_])
+        enc_r, enc_o = ref_i.compress(xc), ora_i.compress(xc)
+        if enc_r["strings"][1] != enc_o["strings"][1] or any(enc_r["strings"][0][g] != enc_o["strings"][0][g] for g in range(5)):
+            raise SystemExit("oracle ELIC bitstream differs from the reference")
+        print("    oracle-vs-reference ELIC strings:", [len(enc_r["strings"][0][g][0]) for g in range(5)], len(enc_r["strings"][1][0]),
+              "bytes: identical")
+        dec2_r = ref_i.decompress(enc_r["strings"], enc_r["shape"])
+        dec2_o = ora_i.decompress(enc_o["strings"], enc_o["shape"])
+        check("ELIC decompress x_hat", dec2_o["x_hat"], dec2_r["x_hat"])
+        check("ELIC compress y_hat", torch.cat(enc_o["y_hat"], 1), torch.cat(enc_r["y_hat"], 1))
+        check("ELIC decompress y_hat == compress y_hat", torch.cat(dec2_r["y_hat"], 1), torch.cat(enc_r["y_hat"], 1))
+    store = {f"y_string_{g}": np.frombuffer(enc_r["strings"][0][g][0], dtype=np.uint8) for g in range(5)}
+    np.savez_compressed(os.path.join(outdir, "icip2024_elic_codec_a.npz"), seed=np.int64(seed + 1), conv_gain=np.float64(0.7),
+                        current=c["current"], z_string=np.frombuffer(enc_r["strings"][1][0], dtype=np.uint8),
+                        shape=np.array(tuple(enc_r["shape"]), dtype=np.int64), y_hat=torch.cat(enc_r["y_hat"], 1).numpy(),
+                        decoded=dec2_r["x_hat"].numpy(), stage2_x_hat=s2_r["x_hat"].numpy(),
+                        stage2_size=np.float64(oicip._bits(s2_r["likelihoods"]).item()), **store)
 
     # the sequence loop itself (src/test.py:37-101) on a short synthetic clip: 20 frames = one full GOP-16 + an irregular
     # tail; PNG decoding (prepare_frame) is replaced by in-memory frames, hydra/omegaconf (CLI only) are stubbed

@@ -313,6 +313,110 @@ class ELIC(JointAutoregressiveHierarchicalPriors):
         return {"x_hat": self.g_s(torch.round(y)), "likelihoods": lik}
 
 
+    # ---- forward_stage2 (elic.py:247-305): like forward, but the channel context and the reconstruction use the
+    # mean-shifted quantisation round(y - mu) + mu of the groups already processed ----
+    def forward_stage2(self, x):
+        y = self.g_a(x)
+        z = self.h_a(y)
+        lik = {}
+        _, lik["z"] = self.entropy_bottleneck(z)
+        hyper = self.h_s(torch.round(z))
+        bounds = ELIC_GROUPS + (y.shape[1],)
+        groups = []
+        for i in range(5):
+            cur = y[:, bounds[i]:bounds[i + 1]]
+            half = torch.round(cur).clone()
+            half[:, :, 0::2, 0::2] = 0
+            half[:, :, 1::2, 1::2] = 0
+            ctx = self.context_prediction_models[i](half)
+            ctx[:, :, 0::2, 1::2] = 0
+            ctx[:, :, 1::2, 0::2] = 0
+            parts = [ctx, hyper] if i == 0 else [ctx, self.channel_context_models[i - 1](torch.round(torch.cat(groups, 1))), hyper]
+            scales, means = self.entropy_parameters[i](torch.cat(parts, 1)).chunk(2, 1)
+            _, lik[f"y_{i}"] = self.gaussian_conditional(cur, scales, means=means)
+            groups.append(torch.round(cur - means) + means)
+        return {"x_hat": self.g_s(torch.cat(groups, 1)), "likelihoods": lik}
+
+    # ---- real bitstream (elic.py:307-496): hyper string + ONE string per channel group holding the anchor symbols
+    # (checkerboard positions (even row, odd col) / (odd row, even col), coded against hyper (+ channel) context only)
+    # followed by the non-anchor symbols (coded with the checkerboard context of the decoded anchors) ----
+    @staticmethod
+    def _squeeze(t, anchor):
+        b, c, h, w = t.shape
+        out = torch.zeros([b, c, h, w // 2], dtype=t.dtype)
+        if anchor:
+            out[:, :, 0::2, :] = t[:, :, 0::2, 1::2]
+            out[:, :, 1::2, :] = t[:, :, 1::2, 0::2]
+        else:
+            out[:, :, 0::2, :] = t[:, :, 0::2, 0::2]
+            out[:, :, 1::2, :] = t[:, :, 1::2, 1::2]
+        return out
+
+    @staticmethod
+    def _unsqueeze(t, anchor):
+        b, c, h, w = t.shape
+        out = torch.zeros([b, c, h, w * 2], dtype=t.dtype)
+        if anchor:
+            out[:, :, 0::2, 1::2] = t[:, :, 0::2, :]
+            out[:, :, 1::2, 0::2] = t[:, :, 1::2, :]
+        else:
+            out[:, :, 0::2, 0::2] = t[:, :, 0::2, :]
+            out[:, :, 1::2, 1::2] = t[:, :, 1::2, :]
+        return out
+
+    def _group_params(self, i, ctx, groups, hyper):
+        parts = [ctx, hyper] if i == 0 else [ctx, self.channel_context_models[i - 1](torch.cat(groups, 1)), hyper]
+        return self.entropy_parameters[i](torch.cat(parts, 1)).chunk(2, 1)
+
+    def compress(self, x):
+        from .cai import ans
+        gc = self.gaussian_conditional
+        tables = (gc._quantized_cdf.numpy(), gc._cdf_length.reshape(-1).int().numpy(), gc._offset.reshape(-1).int().numpy())
+        y = self.g_a(x)
+        z = self.h_a(y)
+        z_strings = self.entropy_bottleneck.compress(z)
+        z_hat = self.entropy_bottleneck.decompress(z_strings, z.size()[-2:])
+        hyper = self.h_s(z_hat)
+        bounds = ELIC_GROUPS + (y.shape[1],)
+        groups, strings = [], []
+        for i in range(5):
+            cur = y[:, bounds[i]:bounds[i + 1]]
+            zero_ctx = torch.zeros([cur.size(0), self.M * 2, cur.size(2), cur.size(3)])
+            syms, idxs, parts = [], [], []
+            for anchor in (True, False):
+                ctx = zero_ctx if anchor else self.context_prediction_models[i](parts[0])
+                scales, means = self._group_params(i, ctx, groups, hyper)
+                sq, sq_s, sq_m = self._squeeze(cur, anchor), self._squeeze(scales, anchor), self._squeeze(means, anchor)
+                sym = gc.quantize(sq, "symbols", sq_m)
+                syms += sym.reshape(-1).tolist()
+                idxs += gc.build_indexes(sq_s).reshape(-1).tolist()
+                parts.append(self._unsqueeze(sym + sq_m, anchor))
+            groups.append(parts[0] + parts[1])
+            strings.append([ans.encode_with_indexes(syms, idxs, *tables)])
+        return {"strings": [strings, z_strings], "shape": z.size()[-2:], "y_hat": groups}
+
+    def decompress(self, strings, shape):
+        from .cai import ans
+        gc = self.gaussian_conditional
+        tables = (gc._quantized_cdf.numpy(), gc._cdf_length.reshape(-1).int().numpy(), gc._offset.reshape(-1).int().numpy())
+        z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
+        hyper = self.h_s(z_hat)
+        groups = []
+        for i in range(5):
+            dec = ans.RansDecoder()
+            dec.set_stream(strings[0][i][0])
+            zero_ctx = torch.zeros([z_hat.size(0), self.M * 2, z_hat.size(2) * 4, z_hat.size(3) * 4])
+            parts = []
+            for anchor in (True, False):
+                ctx = zero_ctx if anchor else self.context_prediction_models[i](parts[0])
+                scales, means = self._group_params(i, ctx, groups, hyper)
+                sq_s, sq_m = self._squeeze(scales, anchor), self._squeeze(means, anchor)
+                sym = dec.decode_stream(gc.build_indexes(sq_s).reshape(-1).tolist(), *tables)
+                parts.append(self._unsqueeze(torch.Tensor(sym).reshape(sq_s.shape) + sq_m, anchor))
+            groups.append(parts[0] + parts[1])
+        return {"x_hat": self.g_s(torch.cat(groups, 1)), "y_hat": groups}
+
+
 def image_compress(im, compressors, n):
     """utils.py:306-316: intra-code a frame at quality index n -> (reconstruction, estimated size in bits)."""
     out = compressors[n].eval()(im)

@@ -220,4 +220,59 @@ int vco_rans_decode_with_indexes(const uint8_t *data, size_t nbytes,
     return 0;
 }
 
+/* RansDecoder.set_stream / decode_stream: the same decoder continued over several calls on one string.
+ * state[0] = coder state, state[1] = index of the next unread 32-bit word; {0, 0} starts a stream. */
+int vco_rans_decode_stream(const uint8_t *data, size_t nbytes, uint64_t *state,
+                           const int32_t *indexes, size_t count,
+                           const int32_t *cdfs, int cdf_stride,
+                           const int32_t *cdf_sizes, const int32_t *offsets,
+                           int32_t *out)
+{
+    if (nbytes < 8) return -1;
+    size_t nwords = nbytes / 4;
+    uint32_t *w = (uint32_t *)calloc(nwords + 2, sizeof(uint32_t));
+    if (!w) return -1;
+    memcpy(w, data, nwords * 4);
+    const uint32_t *p = w + state[1];
+    uint64_t x = state[0];
+    if (state[1] == 0) {
+        x = (uint64_t)p[0] | ((uint64_t)p[1] << 32);
+        p += 2;
+    }
+    for (size_t i = 0; i < count; ++i) {
+        const int32_t t = indexes[i];
+        const int32_t *cdf = cdfs + (size_t)t * cdf_stride;
+        const int32_t n = cdf_sizes[t];
+        const int32_t escape = n - 2;
+        const uint32_t cum = (uint32_t)(x & 0xFFFFu);
+        int32_t j = 0;
+        while (j < n && (uint32_t)cdf[j] <= cum) ++j;
+        const int32_t s = j - 1;
+        const uint32_t start = (uint32_t)cdf[s], range = (uint32_t)(cdf[s + 1] - cdf[s]);
+        x = (uint64_t)range * (x >> PROB_BITS) + (x & 0xFFFFu) - start;
+        if (x < RANS_LOW) { x = (x << 32) | *p; p++; }
+        int32_t v = s;
+        if (v == escape) {
+            int32_t got = (int32_t)take_bits(&x, &p, BYPASS_BITS);
+            int32_t nibbles = got;
+            while (got == (int32_t)BYPASS_MAX) {
+                got = (int32_t)take_bits(&x, &p, BYPASS_BITS);
+                nibbles += got;
+            }
+            int32_t raw = 0;
+            for (int32_t k = 0; k < nibbles; ++k) {
+                int32_t nib = (int32_t)take_bits(&x, &p, BYPASS_BITS);
+                raw |= nib << (k * BYPASS_BITS);
+            }
+            v = raw >> 1;
+            if (raw & 1) v = -v - 1; else v += escape;
+        }
+        out[i] = v + offsets[t];
+    }
+    state[0] = x;
+    state[1] = (uint64_t)(p - w);
+    free(w);
+    return 0;
+}
+
 void vco_free(void *p) { free(p); }

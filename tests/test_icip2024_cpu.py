@@ -161,3 +161,28 @@ def test_oracle_sequence_loop_matches_reference_fixture():
     psnr, size = oi.val_sequence_level(clip, [intra] * 5, model, first, typ, int(fx["level"]))
     for o in first:
         assert abs(psnr[o] - fx["psnr"][o]) < 1e-2 and abs(size[o] - fx["size"][o]) / fx["size"][o] < 1e-3
+
+
+def test_oracle_elic_bitstream_reproduces_the_reference_fixture():
+    """oracle.icip2024.ELIC.compress / decompress / forward_stage2 against what the reference's own methods produced
+    (icip2024_elic_codec_a.npz, written by oracle/gen_golden.py with max|d| = 0 and identical strings)."""
+    import numpy as np
+    import torch
+    from helpers import frame_tensor, load_fixture
+    from oracle import icip2024 as oi
+    from vcamd.seeding import seeded_state_dict
+    fx = load_fixture("icip2024_elic_codec_a.npz")
+    ora = oi.ELIC().eval()
+    ora.load_state_dict(seeded_state_dict(ora.state_dict(), seed=int(fx["seed"]), conv_gain=float(fx["conv_gain"])))
+    ora.update(force=True)
+    x = frame_tensor(fx["current"])
+    with torch.no_grad():
+        enc = ora.compress(x)
+        for g in range(5):
+            assert enc["strings"][0][g][0] == fx[f"y_string_{g}"].tobytes(), g
+        assert enc["strings"][1][0] == fx["z_string"].tobytes()
+        dec = ora.decompress(enc["strings"], enc["shape"])
+        s2 = ora.forward_stage2(x)
+    assert np.array_equal(torch.cat(dec["y_hat"], 1).numpy(), fx["y_hat"])
+    assert np.array_equal(dec["x_hat"].numpy(), fx["decoded"])
+    assert np.array_equal(s2["x_hat"].numpy(), fx["stage2_x_hat"])

@@ -332,6 +332,75 @@ def test_elic_intra_codec_matches_reference_fixture_and_oracle(dev):
     assert abs(o["size"].item() - oi._bits(r["likelihoods"]).item()) / o["size"].item() < 2e-3
 
 
+def _elic(dev, fx):
+    from vcamd import icip2024
+    from vcamd.seeding import seeded_state_dict
+    prod = icip2024.ELIC()
+    prod.load_state_dict(seeded_state_dict(prod.state_dict(), seed=int(fx["seed"]), conv_gain=float(fx["conv_gain"])))
+    prod = prod.to(dev).eval()
+    prod.update(force=True)
+    return prod
+
+
+def test_elic_forward_stage2_matches_reference_fixture(dev):
+    """elic.py:247-305 against the reference's own forward_stage2 (icip2024_elic_codec_a.npz)."""
+    fx = load_fixture("icip2024_elic_codec_a.npz")
+    prod = _elic(dev, fx)
+    x = frame_tensor(fx["current"])
+    with torch.no_grad():
+        out = prod.forward_stage2(x.to(dev))
+    ref = torch.from_numpy(fx["stage2_x_hat"])
+    d_psnr = abs(psnr(out["x_hat"].cpu(), x) - psnr(ref, x))
+    rel = abs(out["size"].item() - float(fx["stage2_size"])) / float(fx["stage2_size"])
+    print(f"ELIC forward_stage2: max|d|={(out['x_hat'].cpu() - ref).abs().max():.3e} dPSNR={d_psnr:.2e} size rel={rel:.2e}")
+    assert d_psnr < PSNR_TOL_DB and rel < 2e-3
+
+
+def test_elic_bitstream_against_reference_fixture(dev):
+    """The two-pass checkerboard codec (elic.py:307-596): (1) decompress(compress(x)) rebuilds exactly the latents the
+    encoder coded and the frame g_s gives for them; (2) against the strings the REFERENCE produced for the same image:
+    every string of the same length class, byte-identical wherever no latent sits on a rounding boundary (counted); (3) the
+    HIP decoder reads the reference's strings: the 10 decode_stream calls chain through five context networks, so it
+    either lands on the reference's latents or -- after an index flip -- is reported as such."""
+    fx = load_fixture("icip2024_elic_codec_a.npz")
+    prod = _elic(dev, fx)
+    x = frame_tensor(fx["current"])
+    with torch.no_grad():
+        enc = prod.compress(x.to(dev))
+        dec = prod.decompress(enc["strings"], enc["shape"])
+    assert tuple(enc["shape"]) == tuple(fx["shape"]) and len(enc["strings"][0]) == 5
+    for a, b in zip(enc["y_hat"], dec["y_hat"]):
+        assert torch.equal(a, b)                                   # the decoder recovers the encoder's latents exactly
+    ref_y = torch.from_numpy(fx["y_hat"])
+    mine_y = torch.cat(enc["y_hat"], 1).cpu()
+    moved = int(((mine_y - ref_y).abs() > 0.5).sum())
+    same = [enc["strings"][0][g][0] == fx[f"y_string_{g}"].tobytes() for g in range(5)] + [enc["strings"][1][0] == fx["z_string"].tobytes()]
+    print(f"ELIC compress vs reference: latents that moved by a quantisation step: {moved} of {ref_y.numel()}; strings identical: {same}")
+    assert moved <= max(2, ref_y.numel() // 1000)
+    for g in range(5):
+        ref_len = fx[f"y_string_{g}"].size
+        assert abs(len(enc["strings"][0][g][0]) - ref_len) <= max(8, 0.02 * ref_len), g
+    if moved == 0:
+        assert all(same)
+    ref_dec = torch.from_numpy(fx["decoded"])
+    d_psnr = abs(psnr(dec["x_hat"].cpu(), x) - psnr(ref_dec, x))
+    assert d_psnr < 5e-3
+    # the reference's bitstream through the HIP decoder
+    ref_strings = [[[fx[f"y_string_{g}"].tobytes()] for g in range(5)], [fx["z_string"].tobytes()]]
+    with torch.no_grad():
+        try:
+            other = prod.decompress(ref_strings, tuple(fx["shape"]))
+            y_err = (torch.cat(other["y_hat"], 1).cpu() - ref_y).abs().max().item()
+            x_err = (other["x_hat"].cpu() - ref_dec).abs().max().item()
+            print(f"HIP decode of the reference's ELIC strings: max|d y_hat|={y_err:.3e}, max|d x_hat|={x_err:.3e}")
+            if y_err < 0.25:                                       # no index flip anywhere in the chain: same integers
+                assert x_err < 1e-3
+        except Exception as e:  # noqa: BLE001  (a flipped index desynchronises the range decoder: VC_EDATA)
+            from vcamd import hip
+            assert isinstance(e, hip.VcError)
+            print("HIP decode of the reference's ELIC strings desynchronised:", e)
+
+
 def test_full_size_properties_1080p(dev, models):
     """At BASELINE's size (1080x1920 padded to 1088x1920), size-independent properties instead of the CPU oracle:
     a batch of two frames equals the two single passes bit for bit, the device-side flow-resolution search picks

@@ -118,3 +118,31 @@ def test_out_of_range_table_index_is_rejected_not_dereferenced():
         hip.rans_encode(sym, good, CDF, np.array([9], dtype=np.int32), OFFS)
     with pytest.raises(hip.VcError):                  # one size / offset per table
         hip.rans_encode(sym, good, CDF, np.array([4, 4], dtype=np.int32), OFFS)
+
+
+def test_stream_decoder_continues_across_calls():
+    """RansDecoder.set_stream / decode_stream (ICIP2024/src/model/elic.py:428-429): one string read in several calls, product
+    (vc_rans_decode_stream) and oracle; BufferedRansEncoder.flush over several queued calls == one encode of the lists."""
+    cdfs, sizes, offs, table = _gaussian_tables()
+    rng = np.random.default_rng(5)
+    n = 6000
+    idx = rng.integers(0, 64, n).astype(np.int32)
+    sym = np.round(rng.standard_normal(n) * table[idx]).astype(np.int32)
+    sym[::61] = rng.integers(-5000, 5000, sym[::61].size)
+    enc = ans.BufferedRansEncoder()
+    enc.encode_with_indexes(sym[:2500].tolist(), idx[:2500].tolist(), cdfs, sizes, offs)
+    enc.encode_with_indexes(sym[2500:].tolist(), idx[2500:].tolist(), cdfs, sizes, offs)
+    data = enc.flush()
+    assert data == hip.rans_encode(sym, idx, cdfs, sizes, offs)
+    for cuts in ((0, 2500, n), (0, 1, 17, 4000, n), (0, n)):
+        o = ans.RansDecoder()
+        o.set_stream(data)
+        p = hip.RansStreamDecoder(data)
+        got_o, got_p = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            got_o += o.decode_stream(idx[a:b], cdfs, sizes, offs)
+            got_p += p.decode_stream(idx[a:b], cdfs, sizes, offs).tolist()
+        assert got_o == sym.tolist() and got_p == sym.tolist()
+    with pytest.raises(hip.VcError):                     # reading past the end of the string
+        p = hip.RansStreamDecoder(data)
+        p.decode_stream(np.concatenate([idx, idx, idx, idx]), cdfs, sizes, offs)

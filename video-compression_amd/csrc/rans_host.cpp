@@ -100,24 +100,24 @@ extern "C" long long vc_rans_encode_with_indexes(const int32_t *symbols, const i
     return static_cast<long long>(nbytes);
 }
 
-extern "C" int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, const int32_t *indexes, size_t count,
-                                           const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes,
-                                           const int32_t *offsets, int32_t *out)
+namespace {
+// Decoder core, resumable: `x` / `pos` = coder state and index of the next unread 32-bit word.  A fresh stream starts
+// with pos == 0 (the first two words initialise x).
+int decode_core(const uint8_t *data, size_t nbytes, uint64_t &x, size_t &pos, const int32_t *indexes, size_t count,
+                const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets, int32_t *out)
 {
-    if (!data || nbytes < 8 || (nbytes % 4) || (count && (!indexes || !out)) || !cdfs || !cdf_sizes || !offsets) return VC_EINVAL;
-    if (!tables_ok(cdf_sizes, n_tables, cdf_stride)) return VC_EINVAL;
     const size_t nwords = nbytes / 4;
-    size_t pos = 0;
     auto next_word = [&](uint32_t &w) -> bool {
         if (pos >= nwords) return false;
         std::memcpy(&w, data + 4 * pos, 4);
         ++pos;
         return true;
     };
-    uint32_t lo, hi;
-    next_word(lo);
-    next_word(hi);
-    uint64_t x = static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+    if (pos == 0) {
+        uint32_t lo = 0, hi = 0;
+        if (!next_word(lo) || !next_word(hi)) return VC_EDATA;
+        x = static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+    }
     bool bad = false;
     auto refill = [&]() {
         if (x < kLow) {
@@ -180,6 +180,33 @@ extern "C" int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, c
         out[i] = v + offsets[t];
     }
     return VC_OK;
+}
+}  // namespace
+
+extern "C" int vc_rans_decode_with_indexes(const uint8_t *data, size_t nbytes, const int32_t *indexes, size_t count,
+                                           const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes,
+                                           const int32_t *offsets, int32_t *out)
+{
+    if (!data || nbytes < 8 || (nbytes % 4) || (count && (!indexes || !out)) || !cdfs || !cdf_sizes || !offsets) return VC_EINVAL;
+    if (!tables_ok(cdf_sizes, n_tables, cdf_stride)) return VC_EINVAL;
+    uint64_t x = 0;
+    size_t pos = 0;
+    return decode_core(data, nbytes, x, pos, indexes, count, cdfs, n_tables, cdf_stride, cdf_sizes, offsets, out);
+}
+
+extern "C" int vc_rans_decode_stream(const uint8_t *data, size_t nbytes, uint64_t *state, const int32_t *indexes, size_t count,
+                                     const int32_t *cdfs, int n_tables, int cdf_stride, const int32_t *cdf_sizes,
+                                     const int32_t *offsets, int32_t *out)
+{
+    if (!data || nbytes < 8 || (nbytes % 4) || !state || (count && (!indexes || !out)) || !cdfs || !cdf_sizes || !offsets) return VC_EINVAL;
+    if (!tables_ok(cdf_sizes, n_tables, cdf_stride)) return VC_EINVAL;
+    uint64_t x = state[0];
+    size_t pos = static_cast<size_t>(state[1]);
+    if (pos == 1 || pos > nbytes / 4) return VC_EINVAL;
+    const int rc = decode_core(data, nbytes, x, pos, indexes, count, cdfs, n_tables, cdf_stride, cdf_sizes, offsets, out);
+    state[0] = x;
+    state[1] = pos;
+    return rc;
 }
 
 extern "C" int vc_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf)

@@ -146,6 +146,7 @@ def lib():
     sig("vc_rans_bound", sz, sz)
     sig("vc_rans_encode_with_indexes", cll, vp, vp, sz, vp, ci, ci, vp, vp, vp, sz)
     sig("vc_rans_decode_with_indexes", ci, vp, sz, vp, sz, vp, ci, ci, vp, vp, vp)
+    sig("vc_rans_decode_stream", ci, vp, sz, vp, vp, sz, vp, ci, ci, vp, vp, vp)
     _lib = L
     return L
 
@@ -159,7 +160,7 @@ EXPORTED_SYMBOLS = [
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
     "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_psnr_uint8", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
-    "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes",
+    "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes", "vc_rans_decode_stream",
     # the operator spellings of SURVEY.md 8(b), thin forwards (csrc/abi_aliases.cpp)
     "vc_gdn", "vc_spynet_level", "vc_pool", "vc_upsample", "vc_pad", "vc_blend", "vc_factorized_bits", "vc_gaussian_symbols",
 ]
@@ -603,3 +604,21 @@ def rans_decode(data, indexes, cdfs, cdf_sizes, offsets):
                                             cdfs.shape[0], cdfs.shape[1], sizes.ctypes.data, offs.ctypes.data, out.ctypes.data),
           "vc_rans_decode_with_indexes")
     return out
+
+
+class RansStreamDecoder:
+    """compressai.ans.RansDecoder with set_stream / decode_stream (ICIP2024/src/model/elic.py:428-429): several decode calls
+    over ONE string, each continuing where the previous stopped."""
+
+    def __init__(self, data):
+        self.buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        self.state = np.zeros(2, dtype=np.uint64)
+
+    def decode_stream(self, indexes, cdfs, cdf_sizes, offsets):
+        idx = _i32(indexes).reshape(-1)
+        cdfs, sizes, offs = _tables(cdfs, cdf_sizes, offsets)
+        out = np.empty(idx.size, dtype=np.int32)
+        check(lib().vc_rans_decode_stream(self.buf.ctypes.data, self.buf.size, self.state.ctypes.data, idx.ctypes.data, idx.size,
+                                          cdfs.ctypes.data, cdfs.shape[0], cdfs.shape[1], sizes.ctypes.data, offs.ctypes.data,
+                                          out.ctypes.data), "vc_rans_decode_stream")
+        return out

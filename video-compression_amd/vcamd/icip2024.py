@@ -260,6 +260,13 @@ class JointAutoregressiveHierarchicalPriors(_Seq):
         self.gaussian_conditional = GaussianConditional(None)
         self.N, self.M = int(N), int(M)
 
+    def update(self, scale_table=None, force=False):
+        """compressai JointAutoregressiveHierarchicalPriors.update: range-coder tables of both entropy models."""
+        from .layers import get_scale_table
+        updated = self.gaussian_conditional.update_scale_table(get_scale_table() if scale_table is None else scale_table, force=force)
+        updated |= self.entropy_bottleneck.update(force=force)
+        return updated
+
 
 class _Elic(JointAutoregressiveHierarchicalPriors):
     """Body shared by Offset_ELIC (enc_mult 5, dec_mult 4, three 432-channel offset heads) and Res_ELIC
@@ -462,7 +469,8 @@ ELIC_GROUPS = (0, 16, 32, 64, 128)
 
 
 class ELIC(JointAutoregressiveHierarchicalPriors):
-    """elic.py:85-260, forward (rate estimate) only -- what utils.image_compress calls for the I-frames."""
+    """elic.py:85-596: forward (rate estimate, what utils.image_compress calls for the I-frames), forward_stage2, and the
+    two-pass checkerboard bitstream codec compress / decompress."""
 
     def __init__(self, N=192, M=320, **kwargs):
         super().__init__(N, M)
@@ -490,8 +498,10 @@ class ELIC(JointAutoregressiveHierarchicalPriors):
     def _sub(self, name, i, x, **kw):
         return run_sequential(getattr(self, name)[i], x, self._caches.setdefault(f"{name}.{i}", {}), **kw)
 
-    def forward_device(self, x, bits):
-        """x: T [n,H,W,3] (H, W multiples of 64) -> x_hat T; appends 6 x n rows to ``bits`` (z, y_0..y_4 per image)."""
+    def forward_device(self, x, bits, stage2=False):
+        """x: T [n,H,W,3] (H, W multiples of 64) -> x_hat T; appends 6 x n rows to ``bits`` (z, y_0..y_4 per image).
+        ``stage2`` = forward_stage2 (elic.py:247-305): the channel context sees round(round(y - mu) + mu) of the groups
+        already processed and the synthesis their round(y - mu) + mu, instead of round(y)."""
         L, M = hip.lib(), self.M
         y = self.seq("g_a", x)
         z = self.seq("h_a", y)
@@ -505,25 +515,192 @@ class ELIC(JointAutoregressiveHierarchicalPriors):
         hip.axpby(hyper, None, out=params_in0.channels(2 * M, 4 * M))
         y_round = hip.quantize_mask(y)
         y_half = hip.quantize_mask(y, keep_parity=1)
+        y_hat = T.empty(n, h, w, M, dev) if stage2 else None            # round(y - mu) + mu, group by group
         bounds = ELIC_GROUPS + (M,)
         for i in range(5):
             c0, c1 = bounds[i], bounds[i + 1]
             pin = params_in0 if i == 0 else params_in
-            key = f"ctx.{i}"
-            if key not in self._caches:
-                self._caches[key] = pack_conv(self.context_prediction_models[i])
-            ctx = self._caches[key](y_half.channels(c0, c1), out=pin.channels(0, 2 * M))
+            ctx = self._ctx_conv(i)(y_half.channels(c0, c1), out=pin.channels(0, 2 * M))
             hip.quantize_mask(ctx, out=ctx, keep_parity=0, do_round=False)
             if i > 0:
-                self._sub("channel_context_models", i - 1, y_round.channels(0, c0), out=pin.channels(2 * M, 4 * M))
+                prev = hip.quantize_mask(y_hat.channels(0, c0)) if stage2 else y_round.channels(0, c0)
+                self._sub("channel_context_models", i - 1, prev, out=pin.channels(2 * M, 4 * M))
             gp = self._sub("entropy_parameters", i, pin)
             half = c1 - c0
             for j in range(n):
                 hip.check(L.vc_gc_forward(hip.stream(), y.channels(c0, c1).images(j, j + 1).view(),
                                           gp.channels(0, half).images(j, j + 1).view(),
-                                          gp.channels(half, 2 * half).images(j, j + 1).view(), None, None, hip.NULL_VIEW,
+                                          gp.channels(half, 2 * half).images(j, j + 1).view(), None, None,
+                                          y_hat.channels(c0, c1).images(j, j + 1).view() if stage2 else hip.NULL_VIEW,
                                           bits.next_row_ptr(), bits.slots, None, None, None, None, 0, None), "vc_gc_forward")
-        return self.seq("g_s", y_round)
+        return self.seq("g_s", y_hat if stage2 else y_round)
+
+    def _ctx_conv(self, i):
+        key = f"ctx.{i}"
+        if key not in self._caches:
+            self._caches[key] = pack_conv(self.context_prediction_models[i])
+        return self._caches[key]
+
+    def forward_stage2(self, x):
+        """elic.py:247-305 -- same return structure as forward."""
+        _require_frames(x)
+        bits = BitCounter(x.device, max_rows=6 * x.shape[0])
+        x_hat = hip.nhwc_to_nchw(self.forward_device(hip.nchw_to_nhwc(x), bits, stage2=True))
+        return {"x_hat": x_hat, "size": bits.totals().sum().float()}
+
+    # ---- real bitstream (elic.py:307-496) --------------------------------------------------------------------------
+    # One string for the hyper-latents + ONE string per channel group: the anchor symbols (checkerboard positions with
+    # (row + col) odd, coded against the hyper / channel context only) followed by the non-anchor symbols (coded with the
+    # checkerboard context of the just-decoded anchors).  The networks run on the device; between the two passes of a
+    # group the integers cross to the host, where the squeezed symbol order of the format is assembled and range-coded.
+    @staticmethod
+    def _squeeze_np(t, anchor):
+        """ckbd_anchor_sequeeze / ckbd_nonanchor_sequeeze (elic.py:498-512) on a [n,c,h,w] array."""
+        out = np.empty(t.shape[:3] + (t.shape[3] // 2,), dtype=t.dtype)
+        if anchor:
+            out[:, :, 0::2, :] = t[:, :, 0::2, 1::2]
+            out[:, :, 1::2, :] = t[:, :, 1::2, 0::2]
+        else:
+            out[:, :, 0::2, :] = t[:, :, 0::2, 0::2]
+            out[:, :, 1::2, :] = t[:, :, 1::2, 1::2]
+        return out
+
+    @staticmethod
+    def _unsqueeze_np(t, anchor):
+        out = np.zeros(t.shape[:3] + (t.shape[3] * 2,), dtype=t.dtype)
+        if anchor:
+            out[:, :, 0::2, 1::2] = t[:, :, 0::2, :]
+            out[:, :, 1::2, 0::2] = t[:, :, 1::2, :]
+        else:
+            out[:, :, 0::2, 0::2] = t[:, :, 0::2, :]
+            out[:, :, 1::2, 1::2] = t[:, :, 1::2, :]
+        return out
+
+    def _param_buffers(self, hyper, n, h, w, dev):
+        """Inputs of the entropy-parameter networks, [ctx | (channel ctx) | hyper]: one pair with the checkerboard context
+        held at zero (anchor pass) and one that receives it (non-anchor pass); group 0 has no channel context."""
+        M = self.M
+        bufs = {}
+        for tag in ("a0", "n0"):
+            t = T.empty(n, h, w, 4 * M, dev)
+            hip.axpby(hyper, None, out=t.channels(2 * M, 4 * M))
+            bufs[tag] = t
+        for tag in ("a", "n"):
+            t = T.empty(n, h, w, 6 * M, dev)
+            hip.axpby(hyper, None, out=t.channels(4 * M, 6 * M))
+            bufs[tag] = t
+        for tag in ("a0", "a"):
+            zero = bufs[tag].channels(0, 2 * M)
+            hip.axpby(hyper, None, alpha=0.0, out=zero)          # hyper is finite: 0 * hyper = 0
+        return bufs
+
+    def _scale_table_dev(self):
+        gc = self.gaussian_conditional
+        if gc._packed is None:
+            if gc.scale_table.numel() == 0:
+                raise hip.VcError("scale table is empty: call update(force=True) after loading weights")
+            gc._packed = gc.scale_table.detach().float().contiguous().to(gc.scale_bound.device)
+        return gc._packed
+
+    def compress(self, x):
+        """{"strings": [[[g0], [g1], [g2], [g3], [g4]], [z]], "shape", "y_hat": 5 NCHW tensors} like elic.py:307-414."""
+        _require_frames(x)
+        L, M = hip.lib(), self.M
+        xt = hip.nchw_to_nhwc(x.contiguous().float())
+        y = self.seq("g_a", xt)
+        z = self.seq("h_a", y)
+        dev, n, h, w = y.buf.device, y.n, y.h, y.w
+        eb_cdf, eb_len, eb_off = self.entropy_bottleneck.tables()
+        gc_tables = self.gaussian_conditional.tables()
+        table = self._scale_table_dev()
+        z_hat = T.empty(z.n, z.h, z.w, z.c, dev)
+        z_sym = torch.empty((z.n, z.c * z.h * z.w), dtype=torch.int32, device=dev)
+        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(), None, None,
+                                  z_hat.view(), z_sym.data_ptr(), None, 0, None), "vc_eb_forward")
+        z_index = np.repeat(np.arange(z.c, dtype=np.int32), z.h * z.w)
+        z_strings = [hip.rans_encode(row, z_index, eb_cdf, eb_len, eb_off) for row in z_sym.cpu().numpy()]
+        hyper = self.seq("h_s", z_hat)
+        bufs = self._param_buffers(hyper, n, h, w, dev)
+        y_hat = T.empty(n, h, w, M, dev)
+        bounds = ELIC_GROUPS + (M,)
+        strings = []
+        for i in range(5):
+            c0, c1 = bounds[i], bounds[i + 1]
+            cg = c1 - c0
+            pa, pn = (bufs["a0"], bufs["n0"]) if i == 0 else (bufs["a"], bufs["n"])
+            if i > 0:
+                self._sub("channel_context_models", i - 1, y_hat.channels(0, c0), out=pn.channels(2 * M, 4 * M))
+                hip.axpby(pn.channels(2 * M, 4 * M), None, out=pa.channels(2 * M, 4 * M))
+            syms, idxs, parts = [], [], []
+            for anchor in (True, False):
+                pin = pa if anchor else pn
+                if not anchor:
+                    self._ctx_conv(i)(parts[0], out=pin.channels(0, 2 * M))
+                gp = self._sub("entropy_parameters", i, pin)
+                full = T.empty(n, h, w, cg, dev)
+                sym = torch.empty((n, cg, h, w), dtype=torch.int32, device=dev)
+                idx = torch.empty_like(sym)
+                hip.check(L.vc_gc_forward(hip.stream(), y.channels(c0, c1).view(), gp.channels(0, cg).view(), gp.channels(cg, 2 * cg).view(),
+                                          None, None, full.view(), None, 0, None, sym.data_ptr(), idx.data_ptr(), table.data_ptr(),
+                                          table.numel(), None), "vc_gc_forward")
+                parts.append(hip.quantize_mask(full, keep_parity=1 if anchor else 0, do_round=False))
+                syms.append(self._squeeze_np(sym.cpu().numpy(), anchor).reshape(-1))
+                idxs.append(self._squeeze_np(idx.cpu().numpy(), anchor).reshape(-1))
+            hip.axpby(parts[0], parts[1], out=y_hat.channels(c0, c1))
+            strings.append([hip.rans_encode(np.concatenate(syms), np.concatenate(idxs), *gc_tables)])
+        groups = [hip.nhwc_to_nchw(y_hat.channels(bounds[i], bounds[i + 1])) for i in range(5)]
+        return {"strings": [strings, z_strings], "shape": torch.Size([z.h, z.w]), "y_hat": groups}
+
+    def decompress(self, strings, shape):
+        """{"x_hat", "cost_time", "y_hat"} like elic.py:416-496 (two decode_stream calls per group string)."""
+        import time
+        t0 = time.process_time()
+        L, M = hip.lib(), self.M
+        dev = self.entropy_bottleneck.quantiles.device
+        hz, wz = int(shape[0]), int(shape[1])
+        n = len(strings[1])
+        eb_cdf, eb_len, eb_off = self.entropy_bottleneck.tables()
+        gc_tables = self.gaussian_conditional.tables()
+        table = self._scale_table_dev()
+        z_index = np.repeat(np.arange(self.N, dtype=np.int32), hz * wz)
+        z_sym = np.stack([hip.rans_decode(strings[1][k], z_index, eb_cdf, eb_len, eb_off) for k in range(n)])
+        z_hat = T.empty(n, hz, wz, self.N, dev)
+        hip.check(L.vc_eb_dequant(hip.stream(), torch.from_numpy(z_sym).to(dev).data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
+                                  None, z_hat.view()), "vc_eb_dequant")
+        hyper = self.seq("h_s", z_hat)
+        h, w = hyper.h, hyper.w
+        bufs = self._param_buffers(hyper, n, h, w, dev)
+        y_hat = T.empty(n, h, w, M, dev)
+        bounds = ELIC_GROUPS + (M,)
+        for i in range(5):
+            c0, c1 = bounds[i], bounds[i + 1]
+            cg = c1 - c0
+            pa, pn = (bufs["a0"], bufs["n0"]) if i == 0 else (bufs["a"], bufs["n"])
+            if i > 0:
+                self._sub("channel_context_models", i - 1, y_hat.channels(0, c0), out=pn.channels(2 * M, 4 * M))
+                hip.axpby(pn.channels(2 * M, 4 * M), None, out=pa.channels(2 * M, 4 * M))
+            dec = hip.RansStreamDecoder(strings[0][i][0])
+            parts = []
+            for anchor in (True, False):
+                pin = pa if anchor else pn
+                if not anchor:
+                    self._ctx_conv(i)(parts[0], out=pin.channels(0, 2 * M))
+                gp = self._sub("entropy_parameters", i, pin)
+                idx = torch.empty((n, cg, h, w), dtype=torch.int32, device=dev)
+                hip.check(L.vc_gc_indexes(hip.stream(), gp.channels(0, cg).view(), table.data_ptr(), table.numel(), idx.data_ptr()),
+                          "vc_gc_indexes")
+                sq_idx = self._squeeze_np(idx.cpu().numpy(), anchor)
+                sym = dec.decode_stream(sq_idx.reshape(-1), *gc_tables).reshape(sq_idx.shape)
+                sym_full = torch.from_numpy(self._unsqueeze_np(sym, anchor)).to(dev)
+                full = T.empty(n, h, w, cg, dev)
+                hip.check(L.vc_gc_dequant(hip.stream(), sym_full.data_ptr(), gp.channels(cg, 2 * cg).view(), None, full.view()),
+                          "vc_gc_dequant")
+                parts.append(hip.quantize_mask(full, keep_parity=1 if anchor else 0, do_round=False))
+            hip.axpby(parts[0], parts[1], out=y_hat.channels(c0, c1))
+        x_hat = hip.nhwc_to_nchw(self.seq("g_s", y_hat))
+        torch.cuda.synchronize()
+        groups = [hip.nhwc_to_nchw(y_hat.channels(bounds[i], bounds[i + 1])) for i in range(5)]
+        return {"x_hat": x_hat, "cost_time": time.process_time() - t0, "y_hat": groups}
 
     def forward(self, x):
         """NCHW CUDA tensor in; ``{"x_hat", "size"}`` out (``size`` = the -log2 likelihood sum the reference's
