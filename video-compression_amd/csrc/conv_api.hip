@@ -1,4 +1,5 @@
 // C-ABI front end of the convolution engine: tile-config selection, weight packing, launch.
+#include <stdlib.h>
 #include <string.h>
 #include "conv_mfma.h"
 
@@ -212,6 +213,10 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     const int bn = cfg_bn(cfg);
     a.nblks = round_up(a.Cout, bn) / bn;
     a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
+    {   // rows of tiles per band of the 2-D tile order (VC_TILE_BAND overrides for experiments; 1 = plain row-major)
+        static const int band = [] { const char *e = getenv("VC_TILE_BAND"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 8; }();
+        a.tile_band = band;
+    }
     a.act = d->act; a.slope = d->slope;
     a.epi = d->epi; a.in_xform = d->in_xform; a.out_mode = d->out_mode;
     a.vec4 = ((a.Cin % 4) == 0 && (a.in_sw % 4) == 0 && (a.in_sh % 4) == 0 && (a.in_sn % 4) == 0 &&

@@ -22,6 +22,19 @@
 #include <type_traits>
 #include <utility>
 
+// Tile order inside an image: bands of `band_rows` tile rows (ConvArgs::tile_band, 8) walked column by column, so that the workgroups in flight
+// together on an XCD (consecutive ids) form a ~band x (64/band) block of tiles: a tile's vertical halo is wanted by the
+// NEXT id and its horizontal halo `band` ids later -- both while the lines are still in that XCD's L2 -- instead of a whole
+// tile row (60 tiles at 1080p) later, when they have to come back from the Infinity Cache / HBM.
+__device__ __forceinline__ void vc_tile_xy(int t, int tiles_x, int tiles_y, int band_rows, int &tx, int &ty)
+{
+    const int per_band = band_rows * tiles_x;
+    const int band = t / per_band, r = t - band * per_band;
+    const int rows = min(band_rows, tiles_y - band * band_rows);     // the last band may be shorter
+    tx = r / rows;
+    ty = band * band_rows + (r - tx * rows);
+}
+
 // compile-time loop: keeps accumulator indices static so the tiles stay in registers
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f)
 {
@@ -66,6 +79,7 @@ struct ConvArgs {
     int vec_out;   // out / res / mul / chscale allow 16-byte accesses on groups of 4 consecutive output channels
     int in_f16, out_f16;   // fp16 path only: `in` / `out` point at half-precision tensors (strides in elements)
     int res_first;         // add the residual BEFORE the activation (plain/ReLU/LeakyReLU epilogues only)
+    int tile_band;         // tile rows per band of the 2-D tile order (vc_tile_xy)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -470,11 +484,10 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
     const int nblk = bid % p.nblks;
-    int t1 = bid / p.nblks;
-    const int tx = t1 % p.tiles_x;
-    t1 /= p.tiles_x;
-    const int ty = t1 % p.tiles_y;
-    const int img = t1 / p.tiles_y;
+    const int t1 = bid / p.nblks;
+    const int img = t1 / (p.tiles_x * p.tiles_y);
+    int tx, ty;
+    vc_tile_xy(t1 - img * (p.tiles_x * p.tiles_y), p.tiles_x, p.tiles_y, p.tile_band, tx, ty);
 
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -118,11 +118,10 @@ __global__ void __launch_bounds__(512, 2) conv_ws_kernel(const ConvArgs p)
         int bid = first + local + (item / nch) * peers;
         c0 = (item % nch) * CKC;
         nblk = bid % p.nblks;
-        int t1 = bid / p.nblks;
-        const int tx = t1 % p.tiles_x;
-        t1 /= p.tiles_x;
-        const int ty = t1 % p.tiles_y;
-        img = t1 / p.tiles_y;
+        const int t1 = bid / p.nblks;
+        img = t1 / (p.tiles_x * p.tiles_y);
+        int tx, ty;
+        vc_tile_xy(t1 - img * (p.tiles_x * p.tiles_y), p.tiles_x, p.tiles_y, p.tile_band, tx, ty);
         oy0 = ty * C::TH;
         ox0 = tx * C::TW;
     };

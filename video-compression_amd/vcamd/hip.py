@@ -475,6 +475,7 @@ def psnr_uint8(x_hat, x, h, w, out=None):
     a, b = x_hat[0], x[0]
     if not a.is_contiguous() or not b.is_contiguous():
         a, b = a.contiguous(), b.contiguous()
+    h, w = min(int(h), a.shape[1]), min(int(w), a.shape[2])      # the loops slice [:h, :w]: a crop larger than the frame is the frame
     slots = lib().vc_bits_slots()
     scratch = torch.empty(slots, dtype=torch.float64, device=x.device)
     if out is None:
