@@ -431,6 +431,8 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
     # in separate runs and corrected as tools/pmc_traffic.py documents).  The file is stamped with a hash of the kernel
     # sources it was measured on: a stale one is refused rather than quoted.
     try:
+        if f16 or is_flex or is_icip or args.resolution != "1080p":
+            raise KeyError("the PMC passes measured the fp32 kernels of the headline configuration only")
         with open(TRAFFIC_JSON) as f:
             tj = json.load(f)
         if tj.get("kernel_source_stamp") != kernel_source_stamp():

@@ -135,7 +135,54 @@ __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
         // ---- epilogue: activation -> channel gain -> residual -> 16-byte (8-byte for half) stores ----
         int img, y, x;
         locate(tile, img, y, x);
-        if (x < p.W) {
+        if constexpr (EPI == 0) {
+            // COALESCED stores (the accumulator layout gives a lane one pixel: a store instruction would touch 32 lines,
+            // 32 bytes each).  Each 32 px x 32 ch accumulator tile passes through this wave's LDS scratch and comes back
+            // with consecutive lanes along the channels: lane i = channels 4(i%8).. of pixel 8j + i/8, so an instruction
+            // writes whole 128-byte lines of 8 consecutive pixels.  Same value-by-value arithmetic as below.
+            // (the 64 KiB of fp32 128x128 weights leave room for half a tile per wave if two workgroups are to share a CU:
+            //  PXS pixels go through the scratch at a time)
+            constexpr int PXS = (NT * KQ >= 64) ? 16 : 32;
+            float *scratch = bias_l + NT * 32 + wave * ((PXS + 1) * VC_EPI_ROWF);
+            const int rq = lane & 7, rpx = lane >> 3;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = t * 32 + 4 * rq;
+#pragma unroll
+                for (int part = 0; part < 32 / PXS; ++part) {
+                    // every lane writes, unconditionally: lanes of the other part go to a dump row.  (A divergent `if` around
+                    // the writes lets the compiler duplicate the reads below into both paths -- lanes that skip the branch
+                    // would then read before the others have written; the exchange needs the wave converged.)
+                    const int row = (PXS == 32 || (n / PXS) == part) ? (n % PXS) : PXS;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                        *reinterpret_cast<f32x4 *>(&scratch[row * VC_EPI_ROWF + 8 * g + 4 * h]) = v;
+                    }
+#pragma unroll
+                    for (int j = 0; j < PXS / 8; ++j) {
+                        const int pl = 8 * j + rpx;                       // pixel within the part
+                        f32x4 v = *reinterpret_cast<const f32x4 *>(&scratch[pl * VC_EPI_ROWF + 4 * rq]);
+                        const int xx = x - n + part * PXS + pl;           // x of this lane's read-back pixel
+                        if (xx < p.W && co < p.Cout) {
+                            const long long o_pix = (long long)img * p.out_sn + (long long)y * p.out_sh + (long long)xx * p.out_sw;
+                            const long long r_pix = (long long)img * p.res_sn + (long long)y * p.res_sh + (long long)xx * p.res_sw;
+                            if (p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_pix + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
+                            if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
+                            if (p.res && !p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_pix + co);
+                            if (F16 && p.out_f16) {
+                                const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                                *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + o_pix + co) = hv;
+                            } else {
+                                *reinterpret_cast<f32x4 *>(p.out + o_pix + co) = v;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (x < p.W) {
             const long long o_pix = (long long)img * p.out_sn + (long long)y * p.out_sh + (long long)x * p.out_sw;
             const long long r_pix = (long long)img * p.res_sn + (long long)y * p.res_sh + (long long)x * p.res_sw;
 #pragma unroll
@@ -169,7 +216,7 @@ __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
 
 template <int KQ, int NT, bool F16, bool INH, int EPI = 0> int launch_pw(hipStream_t st, const ConvArgs &a)
 {
-    const size_t lds_bytes = (size_t)(NT * KQ * 256 + NT * 32) * sizeof(float);
+    const size_t lds_bytes = (size_t)(NT * KQ * 256 + NT * 32 + (EPI == 0 ? 4 * (((NT * KQ >= 64) ? 16 : 32) + 1) * VC_EPI_ROWF : 0)) * sizeof(float);
     auto kern = conv_pw_kernel<KQ, NT, F16, INH, EPI>;
     static std::atomic<uint64_t> raised{0};
     if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
