@@ -137,7 +137,8 @@ def physical_cores():
 def launch_children(args):
     """`python bench.py --gpus N` started plainly: run the documented torch.distributed.run command as a child process
     (this process has not touched the GPU), forward rank 0's JSON line, exit with the child's code."""
-    if torch.cuda.device_count() < args.gpus:      # (counting devices does not initialise the GPU)
+    share = bool(int(os.environ.get("VC_BENCH_SHARE_GPU", "0")))
+    if torch.cuda.device_count() < args.gpus and not share:      # (counting devices does not initialise the GPU)
         raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -195,11 +196,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Functional check of the multi-rank path on a box with ONE GPU (tests / debugging, never a measurement):
+    # VC_BENCH_SHARE_GPU=1 maps every rank onto the visible devices round-robin and VC_BENCH_BACKEND=gloo replaces RCCL
+    # (which refuses two ranks on one device); the R-D gather then travels through host memory.
+    backend = os.environ.get("VC_BENCH_BACKEND", "nccl")
+    if bool(int(os.environ.get("VC_BENCH_SHARE_GPU", "0"))):
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from vcamd import flex, hip, lhbdc
     from vcamd import gop as vgop
@@ -304,7 +314,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -351,7 +361,7 @@ def main():
                    "launch": "eager" if args.no_graph else "hip-graph per GOP pass"},
     }
     if world > 1:
-        result["rccl_ranks"] = world
+        result["rccl_ranks" if backend == "nccl" else f"{backend}_ranks"] = world
     result["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)   # of 288 GB, this rank, graphs included
     if strong:
         table = vgop.RdTable()

@@ -387,6 +387,8 @@ def gather_records(records, device, width=None):
         allrows = local
     else:
         world = dist.get_world_size()
+        if dist.get_backend() != "nccl":        # gloo gathers host tensors (CPU tests, single-GPU functional checks)
+            local, device = local.cpu(), torch.device("cpu")
         count = torch.tensor([local.shape[0], width], dtype=torch.int64, device=device)
         counts = [torch.zeros_like(count) for _ in range(world)]
         dist.all_gather(counts, count)
