@@ -189,7 +189,8 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     const bool f16 = (d->cfg & VC_CFG_F16) != 0;
     if (f16 && (!cfg_f16_ok(d->cfg & 0xff, a.Cin) || d->in_xform != VC_IN_NONE)) return VC_EINVAL;
     const bool ws = (d->cfg & VC_CFG_WS) != 0;
-    if (ws && !(f16 && (d->cfg & VC_CFG_EXACT))) return VC_EINVAL;   // fp16 path, tile configuration pinned by the caller
+    // producer/consumer kernel: tile configuration pinned by the caller, plain input (its producers do not square)
+    if (ws && (!(d->cfg & VC_CFG_EXACT) || d->in_xform != VC_IN_NONE)) return VC_EINVAL;
     a.in_f16 = (d->cfg & VC_CFG_IN_F16) ? 1 : 0;
     a.out_f16 = (d->cfg & VC_CFG_OUT_F16) ? 1 : 0;
     if ((a.in_f16 || a.out_f16) && !f16) return VC_EINVAL;   // half-precision tensors exist on the fp16 path only
@@ -239,6 +240,7 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
         if (!conv_pw_eligible(a, k, st, f16)) return VC_EINVAL;
         return conv_dispatch_pw(stream, a, f16);
     }
+    if (ws && !a.vec4) return VC_EINVAL;          // its producers stage with 16-byte loads
     if (ws) cfg |= VC_CFG_WS_BIT;
     switch (k) {
     case 1: return f16 ? conv_dispatch_k1_f16(stream, a, st, cfg, ck) : conv_dispatch_k1_f32(stream, a, st, cfg, ck);

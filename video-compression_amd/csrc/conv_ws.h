@@ -1,4 +1,4 @@
-// fp16-path convolution with PRODUCER / CONSUMER waves and a double-buffered input tile (VC_CFG_WS).
+// Convolution with PRODUCER / CONSUMER waves and a double-buffered input tile (VC_CFG_WS), fp16 path and fp32 path.
 //
 // Why a second kernel shape for the fp16 path: v_mfma_f32_32x32x16_f16 retires a channel chunk in 1/8 of the fp32 time,
 // so in conv_mfma_kernel's  stage -> barrier -> contract  sequence every staging round (a full memory round trip,
@@ -20,16 +20,20 @@
 
 // LDS-only synchronisation: __syncthreads() would also drain vmcnt, i.e. wait for the consumer's prefetched weight
 // fragments (and the producer's in-flight loads) at every item.
+#ifndef VC_WS_RING32
+#define VC_WS_RING32 2          // fp32 path: weight fragments requested up to this many k-steps ahead
+#endif
 #define VC_WS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // One (tile, chunk) item "in flight" in a producer thread's registers: issue() starts the global loads of the whole
 // footprint in ONE round (the producers hold no accumulators), commit() converts and writes the LDS image once the
 // target buffer is free.  Between the two the thread waits at the item barrier, so the memory round trip of item i+2
 // overlaps the consumers' work on item i -- same LDS image as stage_chunk (conv_mfma.h), item for item.
-template <int KH, int KW, int S, int CK, class C> struct WsStage {
+template <int KH, int KW, int S, int CK, class C, bool F16> struct WsStage {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     static constexpr int C4 = CK / 4, ITEMS = G::ROWS_IN * G::COLS_IN * C4, IPT = (ITEMS + 255) / 256;
-    f32x4 v[IPT], v2[IPT];
+    static constexpr int CPI = F16 ? 8 : 4;                   // input channels behind one 16-byte LDS item
+    f32x4 v[IPT], v2[F16 ? IPT : 1];
     unsigned ok;
 
     template <bool INH>
@@ -43,10 +47,12 @@ template <int KH, int KW, int S, int CK, class C> struct WsStage {
             const int col = pc % G::COLS_IN, row = pc / G::COLS_IN;
             const int iy = G::POINT ? (oy0 + row) * S : iy0 + row;
             const int ix = G::POINT ? (ox0 + col) * S : ix0 + col;
-            const int ch = c0 + c4 * 8;
+            const int ch = c0 + c4 * CPI;
             if ((idx < ITEMS) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin) ok |= 1u << j;
             const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-            if (INH) {      // in_img counts halves
+            if constexpr (!F16) {      // fp32 path: one 16-byte load = the 4 channels of the item (Cin % 4 == 0: p.vec4)
+                v[j] = *reinterpret_cast<const f32x4 *>(in_img + (long long)iyc * p.in_sh + (long long)ixc * p.in_sw + min(ch, p.Cin - 4));
+            } else if (INH) {      // in_img counts halves
                 const _Float16 *q = reinterpret_cast<const _Float16 *>(in_img) + (long long)iyc * p.in_sh + (long long)ixc * p.in_sw +
                                     min(ch, p.Cin - 8);
                 v[j] = *reinterpret_cast<const f32x4 *>(q);
@@ -68,7 +74,7 @@ template <int KH, int KW, int S, int CK, class C> struct WsStage {
             const int pos = (G::LS == 2) ? ((col & 1) * G::HALF + (col >> 1)) : col;
             const int dst = (idx < ITEMS) ? (row * G::COLS_L + pos) * G::CKP + c4 * 4 : G::LDS_FLOATS;   // (dump slot)
             f32x4 w = v[j];
-            if (!INH) {
+            if (F16 && !INH) {
                 f16x8 h;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -83,14 +89,14 @@ template <int KH, int KW, int S, int CK, class C> struct WsStage {
     }
 };
 
-template <int KH, int KW, int S, int CK, class C>
+template <int KH, int KW, int S, int CK, class C, bool F16>
 __global__ void __launch_bounds__(512, 2) conv_ws_kernel(const ConvArgs p)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     typedef Mfma<C::MT> M;
-    static_assert(C::MT == 32 || C::MT == 16, "fp16 path tiles");
+    static_assert(C::MT == 32 || C::MT == 16, "32- and 16-wide tiles");
     constexpr int MT = C::MT, WM = C::WM, WN = C::WN, KS = G::KS, KSTEPS = G::KSTEPS, NT = C::NT;
-    constexpr int CKC = 2 * CK, KSC = 2 * KS, TAPS = KH * KW, STEPS_X = KW * KSTEPS;
+    constexpr int CKC = F16 ? 2 * CK : CK, KSC = F16 ? 2 * KS : KS, TAPS = KH * KW, STEPS_X = KW * KSTEPS;
     constexpr int BUF = G::LDS_FLOATS + 4;                 // one input-tile image + the staging dump slot
     constexpr bool COALESCED = C::MT == 32;                // coalesced epilogue through a per-wave LDS scratch behind the buffers
     // HAND-OFF epilogue (32-channel tiles whose fp32 result fits the tile buffer that has just been consumed): the
@@ -129,8 +135,8 @@ __global__ void __launch_bounds__(512, 2) conv_ws_kernel(const ConvArgs p)
     if (threadIdx.x >= 256) {
         // =============================== producers ===============================
         const int tid = threadIdx.x - 256;
-        WsStage<KH, KW, S, CK, C> st;
-        const bool inh = p.in_f16 != 0;
+        WsStage<KH, KW, S, CK, C, F16> st;
+        const bool inh = F16 && p.in_f16 != 0;
         auto issue_item = [&](int item) {
             int nblk, oy0, ox0, img, c0;
             decode(item, nblk, oy0, ox0, img, c0);
@@ -250,8 +256,9 @@ __global__ void __launch_bounds__(512, 2) conv_ws_kernel(const ConvArgs p)
     };
 
     // consumers keep accumulators, three A fragments and the ring -- no staging registers
-    // (one consumer wave per SIMD: nobody else covers an L2 round trip of ~1500 cycles -> up to a whole kernel row ahead)
-    constexpr int RING = vc_ring_depth(STEPS_X, 224 - WM * WN * M::NREG - 12 * WM, WN, STEPS_X);
+    // (one consumer wave per SIMD: nobody else covers an L2 round trip of ~1500 cycles -> fp16: up to a whole kernel row
+    //  ahead; an fp32 step is 8x longer: two steps suffice)
+    constexpr int RING = vc_ring_depth(STEPS_X, 224 - WM * WN * M::NREG - 12 * WM, WN, F16 ? STEPS_X : VC_WS_RING32);
     f32x4 ring[RING][WN];
     typename M::acc_t acc[WM][WN];
 
@@ -305,17 +312,26 @@ __global__ void __launch_bounds__(512, 2) conv_ws_kernel(const ConvArgs p)
                 if constexpr (sx + 2 < STEPS_X) load_a(a2, rowoff, sx + 2);
                 else load_a(a2, rowoff_n, (sx + 2 - STEPS_X) % STEPS_X);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (F16) {
 #pragma unroll
-                for (int t = 0; t < WM; ++t)
+                    for (int t = 0; t < WM; ++t)
 #pragma unroll
-                    for (int n = 0; n < WN; ++n) {
-                        if constexpr (MT == 32)
-                            acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ring[slot][n]),
-                                                                               __builtin_bit_cast(f16x8, a0[t]), acc[t][n], 0, 0, 0);
-                        else
-                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[slot][n]),
-                                                                               __builtin_bit_cast(f16x8, a0[t]), acc[t][n], 0, 0, 0);
-                    }
+                        for (int n = 0; n < WN; ++n) {
+                            if constexpr (MT == 32)
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ring[slot][n]),
+                                                                                   __builtin_bit_cast(f16x8, a0[t]), acc[t][n], 0, 0, 0);
+                            else
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[slot][n]),
+                                                                                   __builtin_bit_cast(f16x8, a0[t]), acc[t][n], 0, 0, 0);
+                        }
+                } else {        // exact fp32 FMA chains, in conv_mfma_kernel's order: e -> M-tile -> N-tile
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < WM; ++t)
+#pragma unroll
+                            for (int n = 0; n < WN; ++n) acc[t][n] = M::run(ring[slot][n][e], a0[t][e], acc[t][n]);
+                }
                 if constexpr (sx + RING < STEPS_X) load_b(ring[slot], wrow, sx + RING);
                 else load_b(ring[slot], wrow_n, sx + RING - STEPS_X);
                 __builtin_amdgcn_sched_barrier(0);
@@ -333,9 +349,9 @@ __global__ void __launch_bounds__(512, 2) conv_ws_kernel(const ConvArgs p)
                 if (p.vec_out && p.epi == VC_EPI_NONE)
                     conv_epilogue_coalesced<C>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, lds + 2 * BUF + wave * VC_EPI_SCRATCH_FLOATS);
                 else
-                    conv_epilogue<C, true>(p, acc, nblk, wm, wn, lane, oy0, ox0, img);
+                    conv_epilogue<C, F16>(p, acc, nblk, wm, wn, lane, oy0, ox0, img);
             } else {
-                conv_epilogue<C, true>(p, acc, nblk, wm, wn, lane, oy0, ox0, img);
+                conv_epilogue<C, F16>(p, acc, nblk, wm, wn, lane, oy0, ox0, img);
             }
         }
         nblk = nblk_n; oy0 = oy0_n; ox0 = ox0_n; img = img_n; c0 = c0_n;
@@ -366,11 +382,11 @@ __global__ void __launch_bounds__(512, 2) conv_ws_kernel(const ConvArgs p)
     VC_ACC(6, 1ull, 0ull);          // consumer waves
 }
 
-template <int KH, int KW, int S, int CK, class C> int launch_conv_ws(hipStream_t st, const ConvArgs &a)
+template <int KH, int KW, int S, int CK, class C, bool F16> int launch_conv_ws(hipStream_t st, const ConvArgs &a)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
     constexpr size_t lds_bytes = (2 * (size_t)(G::LDS_FLOATS + 4) + 4 * VC_EPI_SCRATCH_FLOATS + 4) * sizeof(float);
-    auto kern = conv_ws_kernel<KH, KW, S, CK, C>;
+    auto kern = conv_ws_kernel<KH, KW, S, CK, C, F16>;
     static std::atomic<uint64_t> raised{0};
     if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
     const int grid = a.total_blocks < 256 ? a.total_blocks : 256;      // one persistent workgroup per CU

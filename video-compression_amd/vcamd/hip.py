@@ -252,9 +252,11 @@ CFG_IN_F16 = 0x400
 CFG_OUT_F16 = 0x800
 CFG_RES_FIRST = 0x1000
 CFG_WS = 0x2000           # fp16 path: producer/consumer kernel with a double-buffered tile (csrc/conv_ws.h)
-# Offered to the autotuner only on request: on MI355X the classic fp16 kernel (two workgroups per CU) wins on every layer
-# of the three models -- see DESIGN.md section 8 for the phase measurements -- and every extra candidate costs tuning time.
-WS_KERNELS = bool(int(os.environ.get("VC_WS_KERNELS", "0")))
+# Which precisions offer the producer/consumer variants (csrc/conv_ws.h) to the autotuner: "0" (default), "fp32", "fp16" or
+# "all".  Bit-identical results either way, but measured slower than the classic kernels on every layer of the three
+# models at both precisions (with ONE consumer wave per SIMD the operand feed of the matrix pipe is not
+# covered -- tools/micro/mfma_feed.hip), and every extra candidate costs tuning time: opt-in, kept for the measurements.
+WS_KERNELS = os.environ.get("VC_WS_KERNELS", "0")
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
 # "fp32" (default, exact fp32 FMA chains like the reference) or "fp16" (BASELINE.json configs[4]: half-precision MFMA
 # with fp32 accumulate for every eligible layer; judged on PSNR/bpp tolerance, never the headline number).
@@ -333,7 +335,7 @@ class PackedConv:
         cands = self.candidates
         if flags & CFG_F16 and 5 in cands:
             cands = [c for c in cands if c != 0]     # the 4x1 128-channel fp16 instance spills registers
-        if flags & CFG_F16 and WS_KERNELS and self.k in (3, 7) and self.stride == 1:
+        if WS_KERNELS in ("all", "fp16" if flags & CFG_F16 else "fp32") and self.k in (3, 7) and self.stride == 1:
             # producer/consumer variants of the same tile configurations (bit-identical results; the tuner decides)
             cands = cands + [c | CFG_WS for c in (cands or [self.cfg]) if c in (1, 2, 5, 7)]
         if not AUTOTUNE or len(cands) < 2 or torch.cuda.is_current_stream_capturing():
