@@ -23,8 +23,10 @@ struct DeformArgs {
 // waves of a workgroup then consume every channel of the 128-byte lines they pull in (a group alone uses only
 // cg of the C channels of a pixel), and the per-pixel offset/mask record of that reference is read completely
 // by the workgroup.  Lanes of a wave are the 64 pixels of the tile, so the group (and its weights) is wave-uniform.
-template <int CG, int OG, bool FUSED, bool VEC>
-__global__ void __launch_bounds__(1024) k_deform(DeformArgs a)
+// MAXT: 512 when the half has at most 8 groups (the ICIP2024 model: 16 groups) -- leaves the register file for the batched
+// gathers; 1024 (up to 16 groups per half) keeps 128 registers and gathers one tap at a time.
+template <int CG, int OG, bool FUSED, bool VEC, int RV = 1, int MAXT = 1024>
+__global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
 {
     extern __shared__ float wsm_all[];
     const int half = a.groups / 2;
@@ -51,11 +53,36 @@ __global__ void __launch_bounds__(1024) k_deform(DeformArgs a)
     const int RS = 27 * half + 1;                      // record stride in floats (odd for half = 8: 217)
     float *rec = wsm_all + half * 9 * CG * OG;
     if (FUSED) {
-        const int per_px = 27 * half;
-        for (int i = threadIdx.x; i < 64 * per_px; i += nthreads) {
-            const int px = i / per_px, c = i - px * per_px;
-            const int yy = min(ty0 + (px >> 3), H - 1), xx = min(tx0 + (px & 7), W - 1);
-            rec[px * RS + c] = O.p[view_off(O, n, yy, xx) + c];
+        // `half` threads per pixel, thread s of a pixel takes the RV-float pieces s, s + half, ... of its record: a wave
+        // instruction reads whole contiguous stretches (128 bytes per pixel for RV = 4, half = 8), and the (27 + RV - 1) / RV
+        // loads of a thread are all issued before the first one is waited for.  (The first version walked the record
+        // with one 4-byte load per thread and iteration, 27 dependent global round trips per workgroup: 54 us of its 60.)
+        constexpr int IT = (27 + RV - 1) / RV;
+        const int per_px = 27 * half, pieces = per_px / RV;           // per_px % RV == 0 (checked by the launcher)
+        const int px = threadIdx.x / half, s = threadIdx.x - px * half;
+        const int yy = min(ty0 + (px >> 3), H - 1), xx = min(tx0 + (px & 7), W - 1);
+        const float *src = O.p + view_off(O, n, yy, xx);
+        float v[IT][RV];
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int pc = min(s + j * half, pieces - 1);
+            if constexpr (RV == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(src + 4 * pc);
+                v[j][0] = t.x, v[j][1] = t.y, v[j][2] = t.z, v[j][3] = t.w;
+            } else if constexpr (RV == 2) {
+                const float2 t = *reinterpret_cast<const float2 *>(src + 2 * pc);
+                v[j][0] = t.x, v[j][1] = t.y;
+            } else {
+                v[j][0] = src[pc];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            const int pc = s + j * half;
+            if (pc < pieces) {
+#pragma unroll
+                for (int e = 0; e < RV; ++e) rec[px * RS + RV * pc + e] = v[j][e];     // (odd record stride: scalar LDS writes)
+            }
         }
     }
     __syncthreads();
@@ -76,52 +103,91 @@ __global__ void __launch_bounds__(1024) k_deform(DeformArgs a)
     }
     const float *xbase = X.p + (long long)n * X.sn + gl * CG;
 
-#pragma unroll 3
-    for (int k = 0; k < 9; ++k) {
+    // One tap's sampling geometry.  Nothing below sits under a branch: a corner (or a whole tap) outside the image gets
+    // its address clamped into the image and its VALUE replaced by zero after the load, so the 4 * CG / 4 gathers of all
+    // taps of a batch are issued back to back and their L2 round trips overlap.  (With the loads under `if`s the compiler
+    // waited for each of them in turn: ~45 dependent round trips per wave, 53 us per workgroup at 1088x1920.)
+    struct Tap {
+        const float *p1, *p2, *p3, *p4;
+        float w1, w2, w3, w4, m;
+        bool ok, tl, tr, bl, br;
+    };
+    auto tap = [&](int k) {
+        Tap q;
         float dy = op[2 * k], dx = op[2 * k + 1];
-        float m = 1.0f;
+        q.m = 1.0f;
         if (FUSED) {
             dy = tanhf(dy) * a.magnitude + fv;        // flow.flip(1): (v, u) pairs with (dy, dx)
             dx = tanhf(dx) * a.magnitude + fu;
-            m = 1.0f / (1.0f + expf(-mp[k]));
+            q.m = 1.0f / (1.0f + expf(-mp[k]));
         } else if (mp) {
-            m = mp[k];
+            q.m = mp[k];
         }
         const float py = (float)(y - 1 + k / 3) + dy;
         const float px = (float)(x - 1 + k % 3) + dx;
-        if (!(py > -1.0f && py < (float)H && px > -1.0f && px < (float)W)) continue;   // also rejects NaN
+        q.ok = py > -1.0f && py < (float)H && px > -1.0f && px < (float)W;      // also rejects NaN
         const float fy = floorf(py), fx = floorf(px);
-        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+        const int y0 = q.ok ? (int)fy : 0, x0 = q.ok ? (int)fx : 0, y1 = y0 + 1, x1 = x0 + 1;
         const float lh = py - fy, lw = px - fx, hh = 1.0f - lh, hw = 1.0f - lw;
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        q.w1 = hh * hw, q.w2 = hh * lw, q.w3 = lh * hw, q.w4 = lh * lw;
         const bool t = y0 >= 0, b = y1 <= H - 1, l = x0 >= 0, r = x1 <= W - 1;
-        const float *p1 = xbase + (long long)y0 * X.sh + (long long)x0 * X.sw;
-        const float *p2 = p1 + X.sw, *p3 = p1 + X.sh, *p4 = p3 + X.sw;
-        float val[CG];
-        if (VEC) {
+        q.tl = q.ok && t && l, q.tr = q.ok && t && r, q.bl = q.ok && b && l, q.br = q.ok && b && r;
+        const long long r0 = (long long)max(y0, 0) * X.sh, r1 = (long long)min(y1, H - 1) * X.sh;
+        const long long c0 = (long long)max(x0, 0) * X.sw, c1 = (long long)min(x1, W - 1) * X.sw;
+        q.p1 = xbase + r0 + c0, q.p2 = xbase + r0 + c1, q.p3 = xbase + r1 + c0, q.p4 = xbase + r1 + c1;
+        return q;
+    };
+    if constexpr (VEC) {
+        constexpr int TB = (MAXT > 512 || CG > 8) ? 1 : 3;       // taps per batch (divides 9): 12-24 16-byte gathers in flight per lane
+        constexpr int V = CG / 4;
+#pragma unroll 1
+        for (int k0 = 0; k0 < 9; k0 += TB) {     // (rolled: unrolled, the compiler hoists all 9 * CG * OG weight reads and spills)
+            Tap q[TB];
+            f32x4 v[TB][4][V];
 #pragma unroll
-            for (int c = 0; c < CG; c += 4) {
-                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                const f32x4 v1 = (t && l) ? *reinterpret_cast<const f32x4 *>(p1 + c) : z;
-                const f32x4 v2 = (t && r) ? *reinterpret_cast<const f32x4 *>(p2 + c) : z;
-                const f32x4 v3 = (b && l) ? *reinterpret_cast<const f32x4 *>(p3 + c) : z;
-                const f32x4 v4 = (b && r) ? *reinterpret_cast<const f32x4 *>(p4 + c) : z;
+            for (int j = 0; j < TB; ++j) {
+                q[j] = tap(k0 + j);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) val[c + e] = (w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e]) * m;
+                for (int c = 0; c < V; ++c) {
+                    v[j][0][c] = *reinterpret_cast<const f32x4 *>(q[j].p1 + 4 * c);
+                    v[j][1][c] = *reinterpret_cast<const f32x4 *>(q[j].p2 + 4 * c);
+                    v[j][2][c] = *reinterpret_cast<const f32x4 *>(q[j].p3 + 4 * c);
+                    v[j][3][c] = *reinterpret_cast<const f32x4 *>(q[j].p4 + 4 * c);
+                }
             }
-        } else {
 #pragma unroll
-            for (int c = 0; c < CG; ++c) {
-                const float v1 = (t && l) ? p1[c] : 0.0f, v2 = (t && r) ? p2[c] : 0.0f;
-                const float v3 = (b && l) ? p3[c] : 0.0f, v4 = (b && r) ? p4[c] : 0.0f;
-                val[c] = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * m;
+            for (int j = 0; j < TB; ++j) {
+                const float *wk = wsm + (k0 + j) * CG * OG;
+#pragma unroll
+                for (int c = 0; c < V; ++c) {
+                    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                    const f32x4 v1 = q[j].tl ? v[j][0][c] : z, v2 = q[j].tr ? v[j][1][c] : z;
+                    const f32x4 v3 = q[j].bl ? v[j][2][c] : z, v4 = q[j].br ? v[j][3][c] : z;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // (a tap outside the image contributes nothing, whatever its modulation value)
+                        const float val = q[j].ok ? (q[j].w1 * v1[e] + q[j].w2 * v2[e] + q[j].w3 * v3[e] + q[j].w4 * v4[e]) * q[j].m : 0.0f;
+#pragma unroll
+                        for (int o = 0; o < OG; ++o) acc[o] = fmaf(wk[(4 * c + e) * OG + o], val, acc[o]);
+                    }
+                }
             }
         }
-        const float *wk = wsm + k * CG * OG;
+    } else {
+#pragma unroll 3
+        for (int k = 0; k < 9; ++k) {
+            const Tap q = tap(k);
+            if (!q.ok) continue;
+            const float *wk = wsm + k * CG * OG;
 #pragma unroll
-        for (int c = 0; c < CG; ++c)
+            for (int c = 0; c < CG; ++c) {
+                const float v1 = q.tl ? q.p1[c] : 0.0f, v2 = q.tr ? q.p2[c] : 0.0f;
+                const float v3 = q.bl ? q.p3[c] : 0.0f, v4 = q.br ? q.p4[c] : 0.0f;
+                const float val = (q.w1 * v1 + q.w2 * v2 + q.w3 * v3 + q.w4 * v4) * q.m;
 #pragma unroll
-            for (int o = 0; o < OG; ++o) acc[o] = fmaf(wk[c * OG + o], val[c], acc[o]);
+                for (int o = 0; o < OG; ++o) acc[o] = fmaf(wk[c * OG + o], val, acc[o]);
+            }
+        }
     }
     float *outp = a.out.p + view_off(a.out, n, y, x) + g * OG;
 #pragma unroll
@@ -147,6 +213,18 @@ template <int CG, int OG, bool FUSED> int launch(hipStream_t st, const DeformArg
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
         return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
     };
+    const bool small = half <= 8;
+    if constexpr (FUSED) {
+        // width of the record pieces: what the record length and the alignment of the raw offset tensors allow
+        auto ok = [&](const vc_view &v, int w) {
+            return (27 * half) % w == 0 && reinterpret_cast<uintptr_t>(v.p) % (4 * w) == 0 && v.sn % w == 0 && v.sh % w == 0 && v.sw % w == 0;
+        };
+        const int rv = (ok(a.off1, 4) && ok(a.off2, 4)) ? 4 : ((ok(a.off1, 2) && ok(a.off2, 2)) ? 2 : 1);
+        if (vec && small && rv == 4) return launch_one(k_deform<CG, OG, true, true, 4, 512>);
+        if (rv == 4) return vec ? launch_one(k_deform<CG, OG, true, true, 4>) : launch_one(k_deform<CG, OG, true, false, 4>);
+        if (rv == 2) return vec ? launch_one(k_deform<CG, OG, true, true, 2>) : launch_one(k_deform<CG, OG, true, false, 2>);
+    }
+    if (vec && small) return launch_one(k_deform<CG, OG, FUSED, true, 1, 512>);
     return vec ? launch_one(k_deform<CG, OG, FUSED, true>) : launch_one(k_deform<CG, OG, FUSED, false>);
 }
 
