@@ -22,7 +22,9 @@ PHASES = ["barrier-before-stage", "staging", "barrier-after-stage", "mfma loop",
 def main():
     argv = sys.argv[1:]
     f16 = "--fp16" in argv          # with libvc_hip_stamps16.so (`make stamps16`): the fp16-path instances
-    argv = [a for a in argv if a != "--fp16"]
+    knockout = "--knockout" in argv # time the kernel with phases switched off (garbage results, diagnostic only)
+    half_io = "--half-io" in argv   # fp16 path: half-precision tensors either side
+    argv = [a for a in argv if a not in ("--fp16", "--knockout", "--half-io")]
     if f16:
         hip.set_conv_precision("fp16")
     shapes = argv or ["64,32,7,1,4,1088,1920", "128,128,3,1,1,544,960,5", "128,128,3,1,1,544,960,1"]
@@ -40,10 +42,29 @@ def main():
         if len(f) > 7:
             fl = hip.CFG_F16 if f16 else 0
             pc.tuned = {(n, h, w, fl): f[7] | hip.CFG_EXACT | fl}
-        x = hip.T.empty(n, h, w, cin, dev)
+        io = "f16" if (f16 and half_io) else "f32"
+        x = hip.T.empty(n, h, w, cin, dev, io)
         x.buf.normal_()
-        out = hip.T.empty(n, *pc.out_shape(h, w), dev)
+        out = hip.T.empty(n, *pc.out_shape(h, w), dev, io)
         pc(x, out=out)
+        if knockout:
+            L.vc_debug_set_skip.argtypes = [ctypes.c_int]
+            names = {0: "everything", 1: "first chunk staged only", 2: "no contraction", 4: "no epilogue", 3: "epilogue only (+1 chunk)",
+                     5: "contraction only (+1 chunk)", 6: "staging only"}
+            print(f"conv k{k} {cin}->{cout} @{n}x{h}x{w} cfg={f[7] if len(f) > 7 else 'auto'} io={io}: phase knock-out")
+            for mask in (0, 1, 2, 4, 3, 5, 6):
+                L.vc_debug_set_skip(mask | 8)        # | 8: no stamps (their atomics would dominate the time)
+                pc(x, out=out, act=hip.ACT_LRELU)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    pc(x, out=out, act=hip.ACT_LRELU)
+                e1.record()
+                torch.cuda.synchronize()
+                print(f"   {names[mask]:30s} {e0.elapsed_time(e1) / 10:8.3f} ms")
+            L.vc_debug_set_skip(0)
+            L.vc_debug_read_stamps(buf)
+            continue
         L.vc_debug_read_stamps(buf)                      # discard warm-up / autotune launches
         reps = 5
         for _ in range(reps):

@@ -260,4 +260,9 @@ extern "C" int vc_debug_read_stamps(unsigned long long *out8)
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_vc_stamps), zero, sizeof(zero)) != hipSuccess) return VC_ELAUNCH;
     return VC_OK;
 }
+extern "C" int vc_debug_set_skip(int mask)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return VC_ELAUNCH;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_vc_skip), &mask, sizeof(mask)) == hipSuccess ? VC_OK : VC_ELAUNCH;
+}
 #endif

@@ -48,11 +48,17 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
 // Diagnostic build only (make stamps): per-phase shader-clock totals summed over all waves, read back with
 // vc_debug_read_stamps.  Never compiled into libvc_hip.so.
 __device__ unsigned long long g_vc_stamps[8];
+__device__ int g_vc_skip;
 #define VC_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define VC_ACC(slot, t1, t0) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_vc_stamps[slot], (t1) - (t0)); } while (0)
+#define VC_ACC(slot, t1, t0) do { if ((threadIdx.x & 63) == 0 && !(g_vc_skip & 8)) atomicAdd(&g_vc_stamps[slot], (t1) - (t0)); } while (0)
+// (bit 3 of g_vc_skip switches the stamps themselves off: their atomics on eight hot addresses cost several ms per launch)
+// phase knock-out (vc_debug_set_skip; tools/stamps.py --knockout): bit 0 = stage only the first channel chunk, bit 1 = no
+// contraction, bit 2 = no epilogue.  Results are garbage by design; the kernel time that remains is what the other phases cost.
+#define VC_SKIP(bit) (g_vc_skip & (bit))
 #else
 #define VC_T(var)
 #define VC_ACC(slot, t1, t0)
+#define VC_SKIP(bit) false
 #endif
 
 #define VC_CFG_WS_BIT 0x100      // dispatcher-internal: producer/consumer kernel (conv_ws.h) requested
@@ -548,7 +554,8 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         // Two phases per batch: issue all global loads of the batch (addresses clamped into the image so
         // no load sits under a branch), then select-zero / transform and write LDS.  This keeps BATCH
         // independent 16-byte loads in flight per lane instead of one load -> wait -> ds_write at a time.
-        if (F16 && p.in_f16)
+        if (VC_SKIP(1) && c0 > 0) {
+        } else if (F16 && p.in_f16)
             stage_chunk<KH, KW, S, CK, C, true, F16, F16>(p, lds, in_img, c0, oy0, ox0, iy0, ix0, threadIdx.x);
         else if (F16)
             stage_chunk<KH, KW, S, CK, C, true, true>(p, lds, in_img, c0, oy0, ox0, iy0, ix0, threadIdx.x);
@@ -580,7 +587,8 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
             for (int t = 0; t < WM; ++t) a[t] = *reinterpret_cast<const f32x4 *>(&lds[abase[t] + rowoff + koff + ks * KS]);
         };
-        if constexpr (F16) {
+        if (VC_SKIP(2)) {
+        } else if constexpr (F16) {
             // ---- fp16: weight fragments through a D-deep register ring (filled before the chunk loop and kept full
             // across rows, chunks and the staging barriers), activations one step ahead from LDS ----
             const float *wchunk_n = wlane + (long long)((c0 + CKC < p.cin_pad ? c0 + CKC : c0) / KSC) * 256;
@@ -673,7 +681,8 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     }
 
     VC_T(t_loop_end);
-    if constexpr (F16 && C::MT == 32 && G::LDS_FLOATS >= 4 * VC_EPI_SCRATCH_FLOATS) {
+    if (VC_SKIP(4)) {
+    } else if constexpr (F16 && C::MT == 32 && G::LDS_FLOATS >= 4 * VC_EPI_SCRATCH_FLOATS) {
         if (p.vec_out && p.epi == VC_EPI_NONE) {
             __syncthreads();          // every wave has left the contraction loop: the tile image can serve as scratch
             conv_epilogue_coalesced<C>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, lds + wave * VC_EPI_SCRATCH_FLOATS);
