@@ -465,6 +465,74 @@ __device__ __forceinline__ void conv_epilogue_coalesced(const ConvArgs &p, typen
     });
 }
 
+// Half-precision OUTPUT, two N-tiles at a time: a 32-channel tile is only 64 bytes of a half-precision pixel, so the
+// function above would write every 128-byte line in two halves, by two instructions of 8 bytes per lane (3x3 128->128
+// @4x544x960: the epilogue alone took 0.33 ms for 535 MB -- half the rate of the 7x7 64->32 layer, whose 32-channel
+// pixels are whole lines side by side).  Here a PAIR of N-tiles (64 channels = 128 bytes) passes through a
+// [pixel][64 + 4] scratch and every lane converts and stores 8 consecutive channels = 16 bytes: an instruction writes 8
+// whole lines.  Same arithmetic per value.  Plain output layout only (no pixel shuffle); `scratch`: 32 * 68 floats per wave.
+constexpr int VC_EPI2_ROWF = 68;
+constexpr int VC_EPI2_SCRATCH_FLOATS = 32 * VC_EPI2_ROWF;
+
+template <class C>
+__device__ __forceinline__ void conv_epilogue_coalesced_h2(const ConvArgs &p, typename Mfma<C::MT>::acc_t (&acc)[C::WM][C::WN], int nblk,
+                                                           int wm, int wn, int lane, int oy0, int ox0, int img, float *scratch)
+{
+    typedef Mfma<C::MT> M;
+    constexpr int MT = C::MT, WM = C::WM, WN = C::WN, NT = C::NT;
+    static_assert(MT == 32 && M::NREG == 16 && WN % 2 == 0, "pairs of 32 x 32 accumulator tiles");
+    const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+    const int mode = p.act == VC_ACT_SIGMOID ? 3 : (p.act == VC_ACT_CLAMP01 ? 4 : 0);
+    const int wpx = lane & 31, whalf = lane >> 5;          // accumulator layout: pixel, channel half-group
+    const int rq = lane & 7, rpx = lane >> 3;              // read-back layout: channel octet, pixel within a group of 8
+    static_for<0, WM>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int m = wm * WM + t;
+        const int oy = oy0 + m / C::XT;
+        static_for<0, WN / 2>([&](auto nc) {
+            constexpr int n2 = decltype(nc)::value;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[t][2 * n2 + h][4 * g], acc[t][2 * n2 + h][4 * g + 1], acc[t][2 * n2 + h][4 * g + 2],
+                                     acc[t][2 * n2 + h][4 * g + 3]};
+                    *reinterpret_cast<f32x4 *>(&scratch[wpx * VC_EPI2_ROWF + 32 * h + 8 * g + 4 * whalf]) = v;
+                }
+            const int co = nblk * C::BN + (wn * WN + 2 * n2) * NT + 8 * rq;   // first of this lane's 8 consecutive channels
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pix = 8 * j + rpx;
+                f32x4 v[2];
+                v[0] = *reinterpret_cast<const f32x4 *>(&scratch[pix * VC_EPI2_ROWF + 8 * rq]);
+                v[1] = *reinterpret_cast<const f32x4 *>(&scratch[pix * VC_EPI2_ROWF + 8 * rq + 4]);
+                const int ox = ox0 + (m % C::XT) * MT + pix;
+                if (oy < p.Ho && ox < p.Wo && co < p.Cout) {
+                    const long long o_off = (long long)img * p.out_sn + (long long)oy * p.out_sh + (long long)ox * p.out_sw + co;
+                    const long long r_off = (long long)img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + co;
+                    f16x8 hv;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x4 w = v[q];
+                        if (mode == 0 && p.res_first) w += *reinterpret_cast<const f32x4 *>(p.res + r_off + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (mode == 3) w[e] = 1.0f / (1.0f + expf(-w[e]));
+                            else if (mode == 4) w[e] = fminf(fmaxf(w[e], 0.0f), 1.0f);
+                            else w[e] = w[e] >= 0.0f ? w[e] : w[e] * neg;
+                        }
+                        if (p.chscale) w *= *reinterpret_cast<const f32x4 *>(p.chscale + co + 4 * q);
+                        if (p.res && !(mode == 0 && p.res_first)) w += *reinterpret_cast<const f32x4 *>(p.res + r_off + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hv[4 * q + e] = (_Float16)w[e];
+                    }
+                    *reinterpret_cast<f16x8 *>(reinterpret_cast<_Float16 *>(p.out) + o_off) = hv;
+                }
+            }
+        });
+    });
+}
+
 // F16: the "fp16 MFMA conv path" (BASELINE.json configs[4]): activations are converted to half while being
 // staged, weights are pre-packed as half fragments, v_mfma_f32_32x32x16_f16 accumulates in fp32.  A 16-byte LDS item /
 // weight fragment then carries 8 channels instead of 4 and ONE MFMA consumes it (16x the fp32 matrix rate), so all
@@ -685,7 +753,15 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     } else if constexpr (F16 && C::MT == 32 && G::LDS_FLOATS >= 4 * VC_EPI_SCRATCH_FLOATS) {
         if (p.vec_out && p.epi == VC_EPI_NONE) {
             __syncthreads();          // every wave has left the contraction loop: the tile image can serve as scratch
-            conv_epilogue_coalesced<C>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, lds + wave * VC_EPI_SCRATCH_FLOATS);
+            if constexpr (C::WN % 2 == 0 && G::LDS_FLOATS >= 4 * VC_EPI2_SCRATCH_FLOATS) {
+                // (8-channel pieces: Cout % 8 == 0 and 16-byte aligned half-precision rows)
+                if (p.out_f16 && p.out_mode == VC_OUT_PLAIN && (p.Cout & 7) == 0 && ((p.out_sw | p.out_sh | p.out_sn) & 7) == 0)
+                    conv_epilogue_coalesced_h2<C>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, lds + wave * VC_EPI2_SCRATCH_FLOATS);
+                else
+                    conv_epilogue_coalesced<C>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, lds + wave * VC_EPI_SCRATCH_FLOATS);
+            } else {
+                conv_epilogue_coalesced<C>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, lds + wave * VC_EPI_SCRATCH_FLOATS);
+            }
         } else {
             conv_epilogue<C, F16>(p, acc, nblk, wm, wn, lane, oy0, ox0, img);
         }
