@@ -642,3 +642,86 @@ def test_psnr_uint8_kernel_matches_the_reference_formula(dev):
     assert float(out[0]) == 0.0 and float(out[2]) == 0.0 and float(out[1]) > 0.0
     with pytest.raises(hip.VcError):
         hip.psnr_uint8(a, b, 8, 8)                                               # CPU tensors: no fallback
+
+
+def _sweep_cases(seed, count):
+    """Seeded random convolution problems: ragged heights / widths (tile and band edges), batches, every kernel size and
+    stride the dispatchers instantiate, channel counts on and off the packing granules, residual / activation epilogues."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        k = int(rng.choice([1, 3, 3, 5, 7]))
+        stride = int(rng.choice([1, 2])) if k in (1, 3, 5) else 1
+        cin = int(rng.choice([3, 6, 8, 16, 32, 64, 96, 128, 192]))
+        cout = int(rng.choice([1, 2, 4, 12, 16, 32, 64, 96, 128, 192]))
+        h, w = int(rng.integers(5, 75)), int(rng.integers(5, 140))
+        n = int(rng.choice([1, 1, 2, 3]))
+        act = str(rng.choice(["none", "relu", "lrelu"]))
+        cases.append((cin, cout, k, stride, h, w, n, act, bool(rng.integers(0, 2))))
+    return cases
+
+
+def test_conv2d_random_sweep_every_candidate_configuration(dev):
+    """Every tile configuration the tuner may pick, on random problems: equal to F.conv2d within the fp32 bar and
+    BIT-identical to each other (the 2-D banded tile order, the 16-row tiles, the streaming 1x1 kernel, ragged last tiles)."""
+    from vcamd import hip
+    slope = 0.01
+    for i, (cin, cout, k, stride, h, w, n, act, with_res) in enumerate(_sweep_cases(2024, 36)):
+        x = _rand((n, cin, h, w), 100 + i)
+        wt = _rand((cout, cin, k, k), 200 + i, 1.0 / np.sqrt(cin * k * k))
+        b = _rand((cout,), 300 + i, 0.1)
+        ref = F.conv2d(x, wt, b, stride=stride, padding=k // 2)
+        ref = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, slope)}[act](ref)
+        r = _rand(tuple(ref.shape), 400 + i) if with_res else None
+        if r is not None:
+            ref = ref + r
+        pc = hip.PackedConv(wt, b, stride=stride, device=dev)
+        code = {"none": hip.ACT_NONE, "relu": hip.ACT_RELU, "lrelu": hip.ACT_LRELU}[act]
+        xt = hip.nchw_to_nhwc(x.to(dev))
+        rt = None if r is None else hip.nchw_to_nhwc(r.to(dev))
+        outs = []
+        for cfg in (pc.candidates or [pc.cfg]):
+            pc.tuned = {(xt.n, xt.h, xt.w, 0): cfg | hip.CFG_EXACT}
+            try:
+                outs.append((cfg, hip.nhwc_to_nchw(pc(xt, act=code, slope=slope, res=rt))))
+            except hip.VcError:
+                assert cfg == 6          # only the streaming 1x1 kernel may decline a call it is not eligible for
+        assert outs, f"no configuration ran for case {i}"
+        what = f"sweep {i}: {cin}->{cout} k{k} s{stride} @{n}x{h}x{w} {act}{' +res' if with_res else ''}"
+        _close(outs[0][1], ref, 2e-5, what)
+        for cfg, o in outs[1:]:
+            assert torch.equal(outs[0][1], o), f"{what}: configuration {cfg} differs from {outs[0][0]}"
+
+
+def test_conv2d_half_precision_output_equals_rounded_fp32_output(dev):
+    """fp16 path, VC_CFG_OUT_F16 on random problems (ragged sizes, residuals, every candidate configuration): the stored
+    halves are exactly the fp32-output run rounded to half -- the paired-N-tile coalesced epilogue, the 32-channel one and
+    the plain one must agree bit for bit."""
+    from vcamd import hip
+    hip.set_conv_precision("fp16")
+    try:
+        rng = np.random.default_rng(7)
+        for i in range(16):
+            k = int(rng.choice([1, 3, 3, 7]))
+            cin = int(rng.choice([32, 64, 128]))
+            cout = int(rng.choice([32, 64, 128, 192])) if k != 7 else int(rng.choice([32, 64]))
+            h, w, n = int(rng.integers(6, 60)), int(rng.integers(6, 110)), int(rng.choice([1, 2]))
+            pc = hip.PackedConv(_rand((cout, cin, k, k), 500 + i, 1.0 / np.sqrt(cin * k * k)), _rand((cout,), 600 + i, 0.1), device=dev)
+            assert pc.wpk16 is not None
+            x = hip.nchw_to_nhwc(_rand((n, cin, h, w), 700 + i).to(dev))
+            res = hip.nchw_to_nhwc(_rand((n, cout, h, w), 800 + i).to(dev)) if i % 2 else None
+            for cfg in (pc.candidates or [pc.cfg]):
+                for fl_out in (0, hip.CFG_OUT_F16):
+                    pc.tuned = {(x.n, x.h, x.w, hip.CFG_F16 | fl_out): cfg | hip.CFG_EXACT | hip.CFG_F16 | fl_out}
+                try:
+                    full = pc(x, act=hip.ACT_LRELU, res=res)
+                    half = hip.T.empty(n, h, w, cout, dev, "f16")
+                    pc(x, out=half, act=hip.ACT_LRELU, res=res)
+                except hip.VcError:
+                    assert cfg == 6
+                    continue
+                torch.cuda.synchronize()
+                assert torch.equal(full.buf.view(n, h, w, cout).to(torch.float16), half.buf.view(n, h, w, cout)), \
+                    f"case {i}: {cin}->{cout} k{k} @{n}x{h}x{w} cfg {cfg}"
+    finally:
+        hip.set_conv_precision("fp32")
