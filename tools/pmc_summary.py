@@ -15,7 +15,7 @@ def main():
     out, result = sys.argv[1], {}
     for spec in sys.argv[2:]:
         label, dirs = spec.split("=")
-        sums, counts = {}, {}
+        sums, counts, per = {}, {}, {}
         for d in dirs.split(","):
             for path in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(path)):
@@ -24,10 +24,19 @@ def main():
                     k = row["Counter_Name"]
                     sums[k] = sums.get(k, 0.0) + float(row["Counter_Value"])
                     counts[k] = counts.get(k, 0) + 1
-        avg = {k: sums[k] / counts[k] for k in sums}
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
-            avg["mfma_busy_fraction"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+                    # the same kernel instance serves several shapes: split by grid size as well
+                    name = f'{row["Kernel_Name"]} grid={row.get("Grid_Size", "?")}'
+                    ks, kc = per.setdefault(name, ({}, {}))
+                    ks[k] = ks.get(k, 0.0) + float(row["Counter_Value"])
+                    kc[k] = kc.get(k, 0) + 1
+
+        def derive(a):
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in a and "GRBM_GUI_ACTIVE" in a:
+                a["mfma_busy_fraction"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            return a
+        avg = derive({k: sums[k] / counts[k] for k in sums})
         avg["launches_averaged"] = max(counts.values()) if counts else 0
+        avg["per_kernel"] = {name: derive({k: ks[k] / kc[k] for k in ks}) for name, (ks, kc) in per.items()}
         result[label] = avg
     json.dump({"note": "rocprofv3 --pmc on tools/conv_bench.py (VC_AUTOTUNE=0), per-launch averages over the convolution "
                        "kernel dispatches; GRBM_GUI_ACTIVE is summed over the 8 XCDs", "kernels": result}, open(out, "w"), indent=1)
