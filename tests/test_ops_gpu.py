@@ -725,3 +725,25 @@ def test_conv2d_half_precision_output_equals_rounded_fp32_output(dev):
                     f"case {i}: {cin}->{cout} k{k} @{n}x{h}x{w} cfg {cfg}"
     finally:
         hip.set_conv_precision("fp32")
+
+
+@pytest.mark.parametrize("cin,cout,k,n,h,w", [(16, 2, 7, 4, 70, 130), (32, 1, 5, 1, 33, 65), (32, 4, 3, 2, 40, 100), (8, 3, 7, 1, 20, 77)])
+def test_four_channel_configuration_lds_weights_are_bit_identical(dev, cin, cout, k, n, h, w):
+    """VC_CFG_N4 keeps the layer's weights in LDS when they fit beside the tile image; VC_N4_GLOBAL_WEIGHTS=1 forces the
+    variant that streams them from global memory.  Same MFMA sequence, same operands: the outputs must be equal."""
+    import os
+    from vcamd import hip
+    pc = hip.PackedConv(_rand((cout, cin, k, k), 900 + k, 1.0 / np.sqrt(cin * k * k)), _rand((cout,), 901, 0.1), device=dev)
+    assert pc.cfg == 4
+    x = hip.nchw_to_nhwc(_rand((n, cin, h, w), 902).to(dev))
+    a = hip.nhwc_to_nchw(pc(x, act=hip.ACT_RELU))
+    os.environ["VC_N4_GLOBAL_WEIGHTS"] = "1"
+    try:
+        b = hip.nhwc_to_nchw(pc(x, act=hip.ACT_RELU))
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["VC_N4_GLOBAL_WEIGHTS"]
+    assert torch.equal(a, b)
+    ref = F.relu(F.conv2d(_rand((n, cin, h, w), 902), _rand((cout, cin, k, k), 900 + k, 1.0 / np.sqrt(cin * k * k)), _rand((cout,), 901, 0.1),
+                          padding=k // 2))
+    _close(a, ref, 2e-5, f"N4 {cin}->{cout} k{k}")

@@ -538,9 +538,16 @@ __device__ __forceinline__ void conv_epilogue_coalesced_h2(const ConvArgs &p, ty
 // weight fragment then carries 8 channels instead of 4 and ONE MFMA consumes it (16x the fp32 matrix rate), so all
 // addressing below is unchanged when expressed in 16-byte units: CK stays "LDS floats per pixel", the channel chunk
 // doubles.  32-wide tiles only; everything else (tiny channel counts, GDN) stays on the exact fp32 instances.
-template <int KH, int KW, int S, int CK, class C, bool F16 = false>
+// BLDS (4-channel configuration only): the weights of the whole layer live in LDS.  A 4x4x1 MFMA consumes a weight
+// fragment every 8 cycles; fetched from global memory that is 1 KiB per 64 cycles and SIMD = the CU's whole L1 bandwidth
+// (the matrix pipe sat at 45 %).  The fragment holds only 4 x 4 distinct floats (replicated over the 16 blocks), so the
+// layer's unique weights are TAPS * cin_pad * 16 bytes; every lane reads its channel's 16 bytes with a broadcast
+// ds_read_b128.  Same MFMA sequence, same operands: bit-identical to the global-memory variant.
+template <int KH, int KW, int S, int CK, class C, bool F16 = false, bool BLDS = false>
 __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const ConvArgs p)
 {
+    static_assert(!BLDS || (C::MT == 64 && !F16), "LDS-resident weights: 4x4x1 configuration, fp32");
+    constexpr int FR = BLDS ? 16 : 256;     // floats between consecutive weight fragments
     typedef ConvGeom<KH, KW, S, CK, C> G;
     typedef Mfma<C::MT> M;
     static_assert(!F16 || C::MT == 32 || C::MT == 16, "the fp16 path uses the 32x32x16 / 16x16x32 MFMAs");
@@ -592,8 +599,18 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     }
 
     const int ksteps_total = p.cin_pad / KSC;
-    const long long ntile_stride = (long long)TAPS * ksteps_total * 256;
-    const float *wlane = p.wpk + (long long)(nblk * (C::BN / NT) + wn * WN) * ntile_stride + lane * 4;
+    const long long ntile_stride = (long long)TAPS * ksteps_total * FR;
+    const float *wlane;
+    if constexpr (BLDS) {
+        // lanes 0..3 of every packed fragment of this workgroup's N-tile -> [fragment][channel][4 k] behind the tile image
+        float *wsm = lds + G::LDS_FLOATS + 4;
+        const float *src = p.wpk + (long long)(nblk * (C::BN / NT) + wn * WN) * TAPS * ksteps_total * 256;
+        for (int i = threadIdx.x; i < TAPS * ksteps_total * 4; i += 256)
+            *reinterpret_cast<f32x4 *>(&wsm[4 * i]) = *reinterpret_cast<const f32x4 *>(src + (long long)(i >> 2) * 256 + (i & 3) * 4);
+        wlane = wsm + (lane & 3) * 4;        // (visible after the barrier in front of the first staging)
+    } else {
+        wlane = p.wpk + (long long)(nblk * (C::BN / NT) + wn * WN) * ntile_stride + lane * 4;
+    }
 
     const int pad_y = KH / 2, pad_x = KW / 2;
     const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
@@ -610,7 +627,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
             for (int n = 0; n < WN; ++n)
                 ring[d][n] = *reinterpret_cast<const f32x4 *>(wlane + n * ntile_stride +
-                                                              ((long long)(d / KSTEPS) * ksteps_total + d % KSTEPS) * 256);
+                                                              ((long long)(d / KSTEPS) * ksteps_total + d % KSTEPS) * FR);
     }
 
     VC_T(t_start);
@@ -639,7 +656,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         // The fragments of step s+1 (one 1 KiB global_load_dwordx4 per N-tile, one ds_read_b128 per
         // M-tile) are issued BEFORE the MFMAs of step s, so L2/LDS latency hides behind 8*WM*WN*... cycles
         // of matrix work instead of stalling every step (the compiler alone waits right after issuing).
-        const float *wchunk = wlane + (long long)(c0 / KSC) * 256;
+        const float *wchunk = wlane + (long long)(c0 / KSC) * FR;
         constexpr int STEPS_X = KW * KSTEPS;  // steps per kernel row, fully unrolled
         f32x4 bc[WN], ac[WM], bn[WN], an[WM];
         auto load_b = [&](f32x4(&b)[WN], const float *wrow, int sx) {
@@ -647,7 +664,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
             const int kx = sx / KSTEPS, ks = sx % KSTEPS;
 #pragma unroll
             for (int n = 0; n < WN; ++n)
-                b[n] = *reinterpret_cast<const f32x4 *>(wrow + n * ntile_stride + ((long long)kx * ksteps_total + ks) * 256);
+                b[n] = *reinterpret_cast<const f32x4 *>(wrow + n * ntile_stride + ((long long)kx * ksteps_total + ks) * FR);
         };
         auto load_a = [&](f32x4(&a)[WM], int rowoff, int sx) {
             const int kx = sx / KSTEPS, ks = sx % KSTEPS;
@@ -659,12 +676,12 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         } else if constexpr (F16) {
             // ---- fp16: weight fragments through a D-deep register ring (filled before the chunk loop and kept full
             // across rows, chunks and the staging barriers), activations one step ahead from LDS ----
-            const float *wchunk_n = wlane + (long long)((c0 + CKC < p.cin_pad ? c0 + CKC : c0) / KSC) * 256;
+            const float *wchunk_n = wlane + (long long)((c0 + CKC < p.cin_pad ? c0 + CKC : c0) / KSC) * FR;
             load_a(ac, 0, 0);
 #pragma unroll 1
             for (int ky = 0; ky < KH; ++ky) {
-                const float *wrow = wchunk + (long long)ky * KW * ksteps_total * 256;
-                const float *wrow_n = ky + 1 < KH ? wrow + (long long)KW * ksteps_total * 256 : wchunk_n;
+                const float *wrow = wchunk + (long long)ky * KW * ksteps_total * FR;
+                const float *wrow_n = ky + 1 < KH ? wrow + (long long)KW * ksteps_total * FR : wchunk_n;
                 const int rowoff = ky * G::COLS_L * G::CKP;
                 const int rowoff_n = (ky + 1 < KH ? ky + 1 : ky) * G::COLS_L * G::CKP;
                 static_for<0, STEPS_X>([&](auto sc) {
@@ -697,11 +714,11 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         load_a(ac, 0, 0);
 #pragma unroll 1
         for (int ky = 0; ky < KH; ++ky) {
-            const float *wrow = wchunk + (long long)ky * KW * ksteps_total * 256;
+            const float *wrow = wchunk + (long long)ky * KW * ksteps_total * FR;
             const int rowoff = ky * G::COLS_L * G::CKP;
             // the row after this one (clamped: the last row re-fetches itself, a harmless extra load)
             const int kyn = ky + 1 < KH ? ky + 1 : ky;
-            const float *wrow_n = wchunk + (long long)kyn * KW * ksteps_total * 256;
+            const float *wrow_n = wchunk + (long long)kyn * KW * ksteps_total * FR;
             const int rowoff_n = kyn * G::COLS_L * G::CKP;
             static_for<0, STEPS_X>([&](auto sc) {
                 constexpr int sx = decltype(sc)::value;
@@ -774,11 +791,12 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     VC_ACC(6, 1ull, 0ull);          // waves
 }
 
-template <int KH, int KW, int S, int CK, class C, bool F16 = false> int launch_conv(hipStream_t st, const ConvArgs &a)
+template <int KH, int KW, int S, int CK, class C, bool F16 = false, bool BLDS = false> int launch_conv(hipStream_t st, const ConvArgs &a)
 {
     typedef ConvGeom<KH, KW, S, CK, C> G;
-    constexpr size_t lds_bytes = (G::LDS_FLOATS + 4) * sizeof(float);   // + the staging dump slot
-    auto kern = conv_mfma_kernel<KH, KW, S, CK, C, F16>;
+    const size_t lds_bytes = (G::LDS_FLOATS + 4) * sizeof(float) +       // + the staging dump slot
+                             (BLDS ? (size_t)KH * KW * (a.cin_pad / G::KS) * 64 : 0);
+    auto kern = conv_mfma_kernel<KH, KW, S, CK, C, F16, BLDS>;
     static std::atomic<uint64_t> raised{0};      // per instance; one bit per device (common.h)
     if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.total_blocks), dim3(256), lds_bytes, st, a);
@@ -797,6 +815,11 @@ template <int KH, int KW, int S, int CK> int launch_conv_n4(hipStream_t st, cons
 #if VC_TU_F16
     return VC_EINVAL;
 #else
+    // weights resident in LDS while they leave two workgroups per CU their tile images (<= 32 KiB: cin <= 40 at 7x7)
+    // (VC_N4_GLOBAL_WEIGHTS=1 forces the global-memory variant: A/B runs and the bit-identity test)
+    const char *force = getenv("VC_N4_GLOBAL_WEIGHTS");
+    if ((size_t)KH * KW * (a.cin_pad / 4) * 64 <= 32 * 1024 && !(force && force[0] == '1'))
+        return launch_conv<KH, KW, S, CK, CfgN4, false, true>(st, a);
     return launch_conv<KH, KW, S, CK, CfgN4, false>(st, a);
 #endif
 }
