@@ -4,6 +4,7 @@
 set -u
 F=gpurun_out/final; mkdir -p $F
 bash tools/profile_r02.sh > $F/profile.log 2>&1
+cp gpurun_out/prof_r02/traffic.json profiles/r02/traffic.json   # so that the bench lines below quote THIS build's traffic (copy it back into the repo afterwards)
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $F/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $F/smoke.log 2>&1
 python bench.py --steps 3 --warmup 1 > $F/bench_default.log 2>&1
