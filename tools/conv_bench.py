@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--half-io", action="store_true",
                     help="fp16 path: half-precision input AND output tensors (VC_CFG_IN_F16 / OUT_F16), as inside a chain of "
                          "fp16-path layers; default is fp32 tensors either side (the first / last layer of a chain)")
+    ap.add_argument("--residual", action="store_true", help="add an fp32 residual tensor in the epilogue (bottleneck blocks)")
     ap.add_argument("shapes", nargs="*", default=DEFAULT)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -48,12 +49,16 @@ def main():
         x.buf.normal_()
         ho, wo, co = pc.out_shape(h, w)
         out = hip.T.empty(n, ho, wo, co, dev, io)
+        res = None
+        if args.residual:
+            res = hip.T.empty(n, ho, wo, co, dev)
+            res.buf.normal_()
         for _ in range(2):
-            pc(x, out=out, act=hip.ACT_LRELU)
+            pc(x, out=out, act=hip.ACT_LRELU, res=res)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            pc(x, out=out, act=hip.ACT_LRELU)
+            pc(x, out=out, act=hip.ACT_LRELU, res=res)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps

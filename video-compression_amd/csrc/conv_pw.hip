@@ -145,11 +145,31 @@ __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
             constexpr int PXS = (NT * KQ >= 64) ? 16 : 32;
             float *scratch = bias_l + NT * 32 + wave * ((PXS + 1) * VC_EPI_ROWF);
             const int rq = lane & 7, rpx = lane >> 3;
+            // The residual pieces of a group (one N-tile x PXS pixels) are requested TOGETHER, one group ahead of their use
+            // (addresses clamped, no branch): with one 16-byte load -> wait -> add -> store per piece every wait also sat
+            // behind the previous piece's store (loads and stores retire in order on one counter).
+            constexpr int PJ = PXS / 8, PARTS = 32 / PXS, NG = NT * PARTS;
+            // (the 128-channel fp32 instance only: it runs two waves per SIMD anyway; the narrower, bandwidth-bound instances
+            //  keep their registers -- 16 to 32 more would cost them a wave per SIMD -- and load each piece where it is used)
+            constexpr bool AHEAD = !F16 && NT * KQ >= 64;
+            f32x4 rv[2][PJ];
+            auto request = [&](int gidx, f32x4(&dst)[PJ]) {
+                const int t = gidx / PARTS, part = gidx % PARTS;
+                const int co = min(t * 32 + 4 * rq, p.Cout - 4);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+                for (int j = 0; j < PJ; ++j) {
+                    const int xx = min(x - n + part * PXS + 8 * j + rpx, p.W - 1);
+                    dst[j] = *reinterpret_cast<const f32x4 *>(p.res + (long long)img * p.res_sn + (long long)y * p.res_sh +
+                                                              (long long)xx * p.res_sw + co);
+                }
+            };
+            if (AHEAD && p.res) request(0, rv[0]);
+#pragma unroll
+            for (int gidx = 0; gidx < NG; ++gidx) {
+                const int t = gidx / PARTS, part = gidx % PARTS;
                 const int co = t * 32 + 4 * rq;
-#pragma unroll
-                for (int part = 0; part < 32 / PXS; ++part) {
+                if (AHEAD && p.res && gidx + 1 < NG) request(gidx + 1, rv[(gidx + 1) & 1]);
+                {
                     // every lane writes, unconditionally: lanes of the other part go to a dump row.  (A divergent `if` around
                     // the writes lets the compiler duplicate the reads below into both paths -- lanes that skip the branch
                     // would then read before the others have written; the exchange needs the wave converged.)
@@ -160,18 +180,21 @@ __global__ void __launch_bounds__(256, 2) conv_pw_kernel(const ConvArgs p)
                         *reinterpret_cast<f32x4 *>(&scratch[row * VC_EPI_ROWF + 8 * g + 4 * h]) = v;
                     }
 #pragma unroll
-                    for (int j = 0; j < PXS / 8; ++j) {
+                    for (int j = 0; j < PJ; ++j) {
                         const int pl = 8 * j + rpx;                       // pixel within the part
                         f32x4 v = *reinterpret_cast<const f32x4 *>(&scratch[pl * VC_EPI_ROWF + 4 * rq]);
                         const int xx = x - n + part * PXS + pl;           // x of this lane's read-back pixel
                         if (xx < p.W && co < p.Cout) {
                             const long long o_pix = (long long)img * p.out_sn + (long long)y * p.out_sh + (long long)xx * p.out_sw;
-                            const long long r_pix = (long long)img * p.res_sn + (long long)y * p.res_sh + (long long)xx * p.res_sw;
-                            if (p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_pix + co);
+                            f32x4 r = rv[gidx & 1][j];
+                            if (!AHEAD && p.res)
+                                r = *reinterpret_cast<const f32x4 *>(p.res + (long long)img * p.res_sn + (long long)y * p.res_sh +
+                                                                     (long long)xx * p.res_sw + co);
+                            if (p.res_first) v += r;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
                             if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
-                            if (p.res && !p.res_first) v += *reinterpret_cast<const f32x4 *>(p.res + r_pix + co);
+                            if (p.res && !p.res_first) v += r;
                             if (F16 && p.out_f16) {
                                 const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                                 *reinterpret_cast<f16x4 *>(reinterpret_cast<_Float16 *>(p.out) + o_pix + co) = hv;
