@@ -146,3 +146,85 @@ def test_stream_decoder_continues_across_calls():
     with pytest.raises(hip.VcError):                     # reading past the end of the string
         p = hip.RansStreamDecoder(data)
         p.decode_stream(np.concatenate([idx, idx, idx, idx]), cdfs, sizes, offs)
+
+
+def test_decoder_survives_garbage_and_bit_flips():
+    """A decoder is fed by files: random bytes, truncated strings and valid strings with flipped bits must end in VcError
+    or in SOME symbol array of the requested length -- never in a crash, an out-of-bounds read or an endless loop (the
+    test's own timeout is the endless-loop check)."""
+    cdfs, sizes, offs, table = _gaussian_tables()
+    rng = np.random.default_rng(11)
+    n = 3000
+    idx = rng.integers(0, len(table), n).astype(np.int32)
+    sym = np.round(rng.standard_normal(n) * np.asarray(table)[idx]).astype(np.int32)
+    good = hip.rans_encode(sym, idx, cdfs, sizes, offs)
+    assert hip.rans_decode(good, idx, cdfs, sizes, offs).tolist() == sym.tolist()
+    outcomes = {"error": 0, "symbols": 0}
+
+    def attempt(data):
+        try:
+            out = hip.rans_decode(bytes(data), idx, cdfs, sizes, offs)
+        except hip.VcError:
+            outcomes["error"] += 1
+            return
+        assert out.shape == (n,) and out.dtype == np.int32
+        outcomes["symbols"] += 1
+
+    for _ in range(40):                                   # garbage of every length class
+        attempt(rng.integers(0, 256, int(rng.integers(0, 2 * len(good))), dtype=np.uint8).tobytes())
+    for _ in range(60):                                   # a valid string with a few flipped bits
+        buf = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            buf[int(rng.integers(0, len(buf)))] ^= 1 << int(rng.integers(0, 8))
+        attempt(buf)
+    for cut in (0, 1, 3, 4, 7, 8, len(good) - 4, len(good) - 1):
+        attempt(good[:cut])
+    attempt(good + b"\x00" * 64)                          # trailing bytes behind a valid string
+    assert outcomes["error"] > 0 and outcomes["error"] + outcomes["symbols"] == 40 + 60 + 8 + 1
+    # the resumable decoder takes the same abuse
+    dec = hip.RansStreamDecoder(rng.integers(0, 256, 200, dtype=np.uint8).tobytes())
+    try:
+        dec.decode_stream(idx[:1000], cdfs, sizes, offs)
+        dec.decode_stream(idx[1000:], cdfs, sizes, offs)
+    except hip.VcError:
+        pass
+
+
+def test_container_parser_rejects_inconsistent_headers():
+    from vcamd import lhbdc
+    mv = {"strings": [[b"ab" * 10], [b"c" * 5]], "shape": (4, 6)}
+    res = {"strings": [[b"d" * 30], [b"e" * 7]], "shape": (4, 6)}
+    blob = lhbdc.write_container(None, 1626, mv, res)
+    lm, s_mv, s_res, sh_mv, sh_res = lhbdc.read_container(blob)
+    assert lm == 1626 and s_mv[0][0] == b"ab" * 10 and s_res[1][0] == b"e" * 7 and tuple(sh_mv) == (4, 6)
+    with pytest.raises(hip.VcError):
+        lhbdc.read_container(blob[:10])                   # shorter than the header
+    with pytest.raises(hip.VcError):
+        lhbdc.read_container(blob[:40])                   # header promises more than the file holds
+    bad = bytearray(blob)
+    bad[8:12] = np.array(10 ** 6, dtype=np.uint32).tobytes()
+    with pytest.raises(hip.VcError):
+        lhbdc.read_container(bytes(bad))
+
+
+def test_host_coder_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/rans_host.cpp compiled for the CPU with -fsanitize=address,undefined and driven by tests/native/rans_fuzz.cpp:
+    round trips with escapes, garbage / truncated / bit-flipped strings through both decoders, malformed tables and
+    indexes.  (Sanitizers run on the CPU build only; the GPU pool refuses them.)"""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "rans_fuzz")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-I", os.path.join(root, "include"), os.path.join(root, "tests", "native", "rans_fuzz.cpp"),
+                            os.path.join(root, "video-compression_amd", "csrc", "rans_host.cpp"), "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "no sanitizer report" in run.stdout

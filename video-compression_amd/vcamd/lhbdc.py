@@ -480,6 +480,8 @@ def read_container(blob):
     shape_res = torch.Size(np.frombuffer(blob[16:20], dtype=np.uint16).astype(int).tolist())
     len0_res = u32(20)
     p = 24
+    if p + len0_mv + len1_mv + len0_res > len(blob):      # (the last string runs to the end of the file: decode_B.py:99)
+        raise hip.VcError("bits_B container: the declared string lengths exceed the file")
     s0 = bytes(blob[p:p + len0_mv]); p += len0_mv
     s1 = bytes(blob[p:p + len1_mv]); p += len1_mv
     s2 = bytes(blob[p:p + len0_res]); p += len0_res
