@@ -4,6 +4,7 @@
 // strings and of valid strings with flipped bits, (3) the resumable decoder on the same inputs, (4) malformed tables and
 // indexes.  Every call must return VC_OK or an error code; the sanitizers turn any out-of-bounds access, misaligned
 // or overflowing arithmetic into a non-zero exit.
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,18 @@ int main()
         for (int i = 0; i <= bins; ++i) cdfs[t * stride + i] = (int32_t)c[i];
         sizes[t] = bins + 1;
         offs[t] = -(bins / 2);
+    }
+    {   // table construction refuses what is not a probability vector (NaN, negative, > 1, all zero) instead of converting it
+        const float nan = std::nanf(""), inf = 1.0f / 0.0f;
+        const float bad[][3] = {{nan, 0.5f, 0.5f}, {-0.25f, 0.75f, 0.5f}, {inf, 0.f, 0.f}, {2.0f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {1e30f, 1e30f, 0.f}};
+        uint32_t c[4];
+        for (const auto &pm : bad)
+            if (vc_pmf_to_quantized_cdf(pm, 3, 16, c) == VC_OK) { std::puts("bad pmf accepted"); return 7; }
+        const float tiny[3] = {1.0f, 1e-9f, 0.0f};       // zero-probability bins borrow from the widest one ("steal" branch)
+        if (vc_pmf_to_quantized_cdf(tiny, 3, 16, c) != VC_OK || c[0] != 0 || c[3] != 65536 || !(c[1] < c[2] && c[2] < c[3])) {
+            std::puts("steal branch failed");
+            return 8;
+        }
     }
     long ok = 0, err = 0;
     for (int round = 0; round < 200; ++round) {

@@ -218,7 +218,7 @@ def test_host_coder_under_address_and_ub_sanitizers(tmp_path):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     exe = str(tmp_path / "rans_fuzz")
-    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=all",
                             "-I", os.path.join(root, "include"), os.path.join(root, "tests", "native", "rans_fuzz.cpp"),
                             os.path.join(root, "video-compression_amd", "csrc", "rans_host.cpp"), "-o", exe],
                            capture_output=True, text=True)
@@ -228,3 +228,11 @@ def test_host_coder_under_address_and_ub_sanitizers(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "no sanitizer report" in run.stdout
+
+
+def test_table_construction_refuses_what_is_not_a_probability_vector():
+    for bad in ([float("nan"), 0.5, 0.5], [-0.25, 0.75, 0.5], [float("inf"), 0.0, 0.0], [2.0, 0.0, 0.0], [0.0, 0.0, 0.0]):
+        with pytest.raises(hip.VcError):
+            hip.pmf_to_quantized_cdf(np.array(bad, dtype=np.float32))
+    cdf = hip.pmf_to_quantized_cdf(np.array([1.0, 1e-9, 0.0], dtype=np.float32))     # zero bins steal from the widest one
+    assert cdf[0] == 0 and cdf[-1] == 65536 and np.all(np.diff(cdf.astype(np.int64)) > 0)

@@ -214,7 +214,11 @@ extern "C" int vc_pmf_to_quantized_cdf(const float *pmf, int n, int precision, u
     if (!pmf || !cdf || n < 1 || precision != 16) return VC_EINVAL;
     const uint32_t one = 1u << precision;
     std::vector<uint32_t> freq(static_cast<size_t>(n) + 1, 0u);
-    for (int i = 0; i < n; ++i) freq[i + 1] = static_cast<uint32_t>(std::round(pmf[i] * static_cast<float>(one)));
+    for (int i = 0; i < n; ++i) {
+        // a probability; anything else (NaN from a broken checkpoint, negative, > 1) has no defined conversion to an integer
+        if (!(pmf[i] >= 0.0f && pmf[i] <= 1.0f)) return VC_EDATA;
+        freq[i + 1] = static_cast<uint32_t>(std::round(pmf[i] * static_cast<float>(one)));
+    }
     const uint32_t total = std::accumulate(freq.begin(), freq.end(), 0u);
     if (total == 0) return VC_EDATA;
     for (auto &f : freq) f = static_cast<uint32_t>((static_cast<uint64_t>(one) * f) / total);
