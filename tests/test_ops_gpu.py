@@ -747,3 +747,28 @@ def test_four_channel_configuration_lds_weights_are_bit_identical(dev, cin, cout
     ref = F.relu(F.conv2d(_rand((n, cin, h, w), 902), _rand((cout, cin, k, k), 900 + k, 1.0 / np.sqrt(cin * k * k)), _rand((cout,), 901, 0.1),
                           padding=k // 2))
     _close(a, ref, 2e-5, f"N4 {cin}->{cout} k{k}")
+
+
+def test_conv2d_on_tensors_beyond_2_31_elements(dev):
+    """9 x 2176 x 3840 x 32 = 2.4e9 elements per tensor (a level-batched 2160p pass): offsets must be 64-bit everywhere.
+    The last image (the one whose elements lie beyond 2^31) is checked against F.conv2d on crops."""
+    from vcamd import hip
+    n, h, w, c = 9, 2176, 3840, 32
+    assert n * h * w * c > 2 ** 31
+    wt = _rand((c, c, 3, 3), 950, 1.0 / np.sqrt(c * 9))
+    b = _rand((c,), 951, 0.1)
+    pc = hip.PackedConv(wt, b, device=dev)
+    x = hip.T.empty(n, h, w, c, dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x.buf.copy_(torch.randn(x.buf.numel() // 8, generator=g, device=dev).repeat(8))      # (8 equal slabs: cheap to generate)
+    out = pc(x, act=hip.ACT_RELU)
+    torch.cuda.synchronize()
+    xv, ov = x.buf.view(n, h, w, c), out.buf.view(n, h, w, c)
+    for img, y0, x0 in ((n - 1, h - 40, w - 70), (n - 1, 0, 0), (5, 1000, 2000), (0, 17, 33)):
+        crop = xv[img, max(y0 - 1, 0):y0 + 33, max(x0 - 1, 0):x0 + 65].permute(2, 0, 1)[None].cpu()
+        ref = F.relu(F.conv2d(crop, wt, b, padding=1))
+        oy, ox = (1 if y0 > 0 else 0), (1 if x0 > 0 else 0)          # rows / columns whose halo lies inside the crop
+        got = ov[img, y0:y0 + 30, x0:x0 + 60].permute(2, 0, 1)[None].cpu()
+        _close(got, ref[:, :, oy:oy + 30, ox:ox + 60], 2e-5, f"image {img} at ({y0},{x0})")
+    del x, out
+    torch.cuda.empty_cache()
