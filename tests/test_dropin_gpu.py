@@ -53,17 +53,18 @@ def _script_encode(model, x_after, x_current, x_before):
     flow_cb = _pad64(F.avg_pool2d(model.FlowNet(x_current, x_before), 4))
     flow_ca = _pad64(F.avg_pool2d(model.FlowNet(x_current, x_after), 4))
     diff_flow = torch.cat([flow_cb - flow_ab, flow_ca - flow_ba], dim=1)
-    flow_result = model.mv_compressor(diff_flow)
-    assert set(flow_result) >= {"x_hat", "likelihoods"} and set(flow_result["likelihoods"]) == {"y", "z"}
-    cb_hat, ca_hat = torch.chunk(flow_result["x_hat"], 2, dim=1)
+    coded = model.mv_compressor(diff_flow)
+    assert set(coded) >= {"x_hat", "likelihoods"} and set(coded["likelihoods"]) == {"y", "z"}
+    cb_hat, ca_hat = torch.chunk(coded["x_hat"], 2, dim=1)
     cb_hat = model.upsample_flow((cb_hat + flow_ab)[:, :, :hh, :ww])
     ca_hat = model.upsample_flow((ca_hat + flow_ba)[:, :, :hh, :ww])
     mv_bits = model.mv_compressor.compress(diff_flow)
     fw, bw = model.backwarp(x_before, cb_hat), model.backwarp(x_after, ca_hat)
-    mask = model.masknet(torch.cat([fw, bw], dim=1)).repeat([1, 3, 1, 1])
+    one_channel = model.masknet(torch.cat((fw, bw), 1))
+    mask = one_channel.expand(-1, 3, -1, -1)
     pred = mask * fw + (1.0 - mask) * bw
     res_bits = model.residual_compressor.compress(x_current - pred)
-    return mv_bits, res_bits, flow_result["x_hat"]
+    return mv_bits, res_bits, coded["x_hat"]
 
 
 def _script_decode(model, x_before, x_after, string_flow, string_res, shape_flow, shape_res):
@@ -73,7 +74,7 @@ def _script_decode(model, x_before, x_after, string_flow, string_res, shape_flow
     cb_hat = model.upsample_flow((cb_hat + flow_ab)[:, :, :hh, :ww])
     ca_hat = model.upsample_flow((ca_hat + flow_ba)[:, :, :hh, :ww])
     fw, bw = model.backwarp(x_before, cb_hat), model.backwarp(x_after, ca_hat)
-    mask = model.masknet(torch.cat([fw, bw], dim=1)).repeat([1, 3, 1, 1])
+    mask = model.masknet(torch.cat((fw, bw), 1)).expand(-1, 3, -1, -1)
     res_hat = model.residual_compressor.decompress(string_res, shape_res)["x_hat"]
     return res_hat + (mask * fw + (1.0 - mask) * bw), flow_hat
 
