@@ -128,3 +128,64 @@ def test_script_decoder_reads_the_reference_container(dev, model):
     assert abs(psnr(dec.cpu()[..., :h, :w], src) - psnr(ref_dec[..., :h, :w], src)) < 5e-3
     u8 = lhbdc.float_to_uint8(dec[0].cpu().numpy())[:h, :w]
     assert (np.abs(u8.astype(int) - fx["decoded_u8"].astype(int)) > 1).mean() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Flex-Rate: the module-level sequence of Flex-Rate.../test/encode_B.py:73-109 and decode_B.py:74-96
+# (`model.process`, the gained compressors called with ([n], l), `model.backwarp`, `model.Mask` + sigmoid, the weighted blend)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def flex_model(dev):
+    from vcamd import flex
+    from vcamd.seeding import seeded_state_dict
+    m = flex.BidirFlowRef(n=4)
+    m.load_state_dict(seeded_state_dict(m.state_dict(), seed=1234))
+    m = m.to(dev).eval()
+    m.flow_compressor.update(force=True)
+    m.residual_compressor.update(force=True)
+    return m
+
+
+def _flex_prediction(model, x_before, x_after, refinement):
+    mv_b, mv_a, _ = model.process(x_before, x_after)
+    mv_b, mv_a = mv_b + refinement[:, 0:2], mv_a + refinement[:, 2:4]
+    warped_b, warped_a = model.backwarp(x_before, mv_b), model.backwarp(x_after, mv_a)
+    gate = torch.sigmoid(model.Mask(torch.cat((mv_b, mv_a, x_before, x_after, warped_b, warped_a), 1)))
+    wb, wa = 0.5 * gate[:, 0:1], 0.5 * gate[:, 1:2]
+    return (wb * warped_b + wa * warped_a) / (wb + wa + 1e-8)
+
+
+def test_flex_cli_call_sequence_through_the_public_modules(dev, flex_model):
+    from vcamd import flex
+    m = flex_model
+    fx = load_fixture("flex_codec_a.npz")
+    n, l = int(fx["n"]), float(fx["l"])
+    xb, xc, xa = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    with torch.no_grad():
+        _, _, context = m.process(xb, xa)
+        codec_in = torch.cat((context, xc), 1)
+        mv_bits = m.flow_compressor.compress(codec_in, [n], l)
+        coded = m.flow_compressor(codec_in, [n], l, False)
+        assert set(coded) >= {"x_hat", "likelihoods"}
+        pred = _flex_prediction(m, xb, xa, coded["x_hat"])
+        res_bits = m.residual_compressor.compress(xc - pred, [n], l)
+        fused_mv, fused_res = flex.encode_B(m, xb, xc, xa, n=n, l=l)
+    assert tuple(mv_bits["shape"]) == tuple(fused_mv["shape"]) == tuple(fx["flow_shape"])
+    assert tuple(res_bits["shape"]) == tuple(fused_res["shape"]) == tuple(fx["res_shape"])
+    for mine, fused, ref in ((mv_bits["strings"][0][0], fused_mv["strings"][0][0], fx["flow_y"]),
+                             (mv_bits["strings"][1][0], fused_mv["strings"][1][0], fx["flow_z"]),
+                             (res_bits["strings"][0][0], fused_res["strings"][0][0], fx["res_y"]),
+                             (res_bits["strings"][1][0], fused_res["strings"][1][0], fx["res_z"])):
+        assert abs(len(mine) - ref.size) <= max(8, 0.01 * ref.size)
+        assert abs(len(mine) - len(fused)) <= max(8, 0.01 * len(fused))
+    # decoder side on the strings just written, and on the REFERENCE's own strings
+    src = frame_tensor(fx["current"])
+    ref_dec = torch.from_numpy(fx["decoded"])
+    for s_mv, s_res in ((mv_bits["strings"], res_bits["strings"]),
+                        ([[fx["flow_y"].tobytes()], [fx["flow_z"].tobytes()]], [[fx["res_y"].tobytes()], [fx["res_z"].tobytes()]])):
+        with torch.no_grad():
+            refinement = m.flow_compressor.decompress(s_mv, mv_bits["shape"], [n], l)["x_hat"]
+            dec = m.residual_compressor.decompress(s_res, res_bits["shape"], [n], l)["x_hat"] + _flex_prediction(m, xb, xa, refinement)
+            fused = flex.decode_B(m, xb, xa, s_mv, s_res, mv_bits["shape"], res_bits["shape"], n, l)
+        assert abs(psnr(dec.cpu(), src) - psnr(ref_dec, src)) < 5e-3
+        assert abs(psnr(dec.cpu(), src) - psnr(fused.cpu(), src)) < 1e-3
