@@ -67,7 +67,12 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
                         next-tile prefetch; 32 <= cin <= 128, cout <= 128, plain/ReLU/LeakyReLU epilogue (+ gain,
                         residual); reads the packed weights of N128/N64/N32 and gives bit-identical results */,
        VC_CFG_N32T16 = 7 /* 7x7 stride 1: 16-row tiles of 32 channels (22 x 38 input footprint per 16 x 32 outputs
-                        instead of 14 x 38 per 8 x 32); same packed weights as N32, bit-identical results */ };
+                        instead of 14 x 38 per 8 x 32); same packed weights as N32, bit-identical results */,
+       VC_CFG_DMA = 8 /* fp16 path only (VC_CFG_F16 | VC_CFG_IN_F16), 3x3 / 7x7 stride 1, cin a multiple of 32, cout 32, 64
+                        or a multiple of 128, plain / ReLU / LeakyReLU / sigmoid / clamp epilogue (+ gain, residual, pixel
+                        shuffle): one persistent 512-thread workgroup per CU, both operands streamed into LDS by
+                        global_load_lds with counted vmcnt across raw barriers (csrc/conv_dma.h); reads the packed weights
+                        of the 32-wide configurations and gives bit-identical results */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
  * same packed weights and produces bit-identical results); without it the library narrows the block for
  * small feature maps by itself. */
@@ -87,11 +92,6 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
 /* OR into vc_conv_desc.cfg: add `res` BEFORE the (plain / ReLU / LeakyReLU) activation instead of after it --
  * out = relu(conv(x) + res), the ResidualUnit of compressai.layers.AttentionBlock (ICIP2024/src/model/elic.py:97-121). */
 #define VC_CFG_RES_FIRST 0x1000
-/* With VC_CFG_F16 only (3x3 / 7x7 stride-1 instances): producer/consumer kernel -- four waves stage the NEXT (tile,
- * channel-chunk) item into the second half of a double-buffered LDS tile while four waves contract the current one; one
- * persistent workgroup per CU.  Bit-identical to the classic fp16 kernel of the same tile configuration. */
-#define VC_CFG_WS 0x2000
-
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */
     vc_view out;           /* [n,ho,wo,cout]  (PIXELSHUFFLE2: [n,2ho,2wo,cout/4]) */

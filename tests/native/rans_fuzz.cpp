@@ -51,6 +51,30 @@ int main()
             return 8;
         }
     }
+    {   // symbols as the GPU produces them from inf / NaN / huge latents ((int32_t)rintf(...)): the encoder must refuse what
+        // has no defined encoding (|value| >= 2^27) without overflowing on the way, and still code the largest legal escape
+        const int32_t extreme[] = {INT32_MIN, INT32_MIN + 1, INT32_MAX, INT32_MAX - 1, -(1 << 27) - 64, (1 << 27) + 64, 1 << 30};
+        for (int32_t s : extreme)
+            for (int t = 0; t < T; ++t) {
+                const int32_t one_sym[1] = {s}, one_idx[1] = {t};
+                std::vector<uint8_t> buf(vc_rans_bound(1));
+                if (vc_rans_encode_with_indexes(one_sym, one_idx, 1, cdfs.data(), T, stride, sizes.data(), offs.data(), buf.data(),
+                                                buf.size()) != VC_EINVAL) { std::puts("extreme symbol accepted"); return 9; }
+            }
+        const int32_t legal[] = {(1 << 27) - 64, -(1 << 27) + 64};
+        for (int32_t s : legal) {
+            const int32_t one_sym[1] = {s}, one_idx[1] = {0};
+            int32_t back[1] = {0};
+            std::vector<uint8_t> buf(vc_rans_bound(1));
+            const long long len = vc_rans_encode_with_indexes(one_sym, one_idx, 1, cdfs.data(), T, stride, sizes.data(), offs.data(),
+                                                              buf.data(), buf.size());
+            if (len < 0 || vc_rans_decode_with_indexes(buf.data(), (size_t)len, one_idx, 1, cdfs.data(), T, stride, sizes.data(),
+                                                       offs.data(), back) != VC_OK || back[0] != s) {
+                std::puts("largest legal escape failed");
+                return 10;
+            }
+        }
+    }
     long ok = 0, err = 0;
     for (int round = 0; round < 200; ++round) {
         const size_t n = rnd() % 3000;

@@ -152,57 +152,20 @@ def test_conv2d_fp16_path(dev, cin, cout, k, stride, h, w, act, ps):
     _close(out, exact, 5e-3, "fp16 conv vs exact fp32")
 
 
-WS_CASES = [  # cin, cout, k, n, h, w, base tile configs to compare
-    (64, 32, 7, 2, 50, 70, (2, 7)), (32, 64, 7, 1, 34, 60, (1, 2, 7)), (128, 128, 3, 1, 40, 72, (1, 2, 5)), (128, 128, 3, 3, 17, 33, (5,)),
-    (256, 128, 3, 1, 16, 40, (1, 5)), (128, 512, 3, 1, 17, 30, (1, 2, 5)), (64, 64, 3, 1, 300, 280, (1, 2)), (128, 32, 7, 1, 20, 36, (2, 7)),
+DMA_CASES = [  # cin, cout, k, n, h, w, classic tile configs to compare with
+    (128, 128, 3, 1, 40, 72, (5, 1)), (128, 128, 3, 3, 17, 33, (5,)), (64, 32, 7, 2, 50, 70, (7, 2)), (32, 64, 7, 1, 34, 60, (1, 2)),
+    (64, 128, 3, 1, 33, 31, (5,)), (256, 128, 3, 1, 16, 40, (1, 5)), (128, 512, 3, 1, 17, 30, (5,)), (192, 128, 3, 2, 20, 36, (5,)),
+    (128, 128, 3, 2, 160, 288, (5,)),
 ]
 
 
-@pytest.mark.parametrize("cin,cout,k,n,h,w,cfgs", WS_CASES)
-def test_producer_consumer_fp32_kernel_is_bit_identical(dev, cin, cout, k, n, h, w, cfgs):
-    """The same kernel shape on the exact fp32 path (where it is the faster one on the big layers): bit-identical to the
-    classic kernel of the same tile configuration -- plain, residual-first, pixel-shuffle and channel-gain epilogues."""
-    from vcamd import hip
-    ps = cout == 512
-    x = _rand((n, cin, h, w), 61)
-    wt = _rand((cout, cin, k, k), 62, 1.0 / np.sqrt(cin * k * k))
-    b = _rand((cout,), 63, 0.1)
-    pc = hip.PackedConv(wt, b, pixelshuffle=ps, device=dev)
-    xt = hip.nchw_to_nhwc(x.to(dev))
-    ho, wo, co = pc.out_shape(h, w)
-    res = hip.nchw_to_nhwc(_rand((n, co, ho, wo), 64).to(dev))
-    gain = _rand((cout,), 65).abs().to(dev)
-    seen = 0
-    for base in cfgs:
-        if base not in pc.candidates and base != pc.cfg:
-            continue
-        outs = {}
-        for ws in (0, hip.CFG_WS):
-            pc.tuned = {(n, h, w, 0): base | ws | hip.CFG_EXACT}
-            outs[ws] = [pc(xt, act=hip.ACT_LRELU, slope=0.01).buf.clone(), pc(xt, act=hip.ACT_RELU, res=res).buf.clone(),
-                        pc(xt, act=hip.ACT_RELU, res=res, res_first=True).buf.clone()]
-            if not ps:
-                outs[ws].append(pc(xt, act=hip.ACT_NONE, chscale=gain).buf.clone())
-        for a, c in zip(outs[0], outs[hip.CFG_WS]):
-            assert torch.equal(a, c), (base, (a - c).abs().max().item())
-        seen += 1
-    assert seen > 0
-    # GDN-style calls (squared input) are not offered by this kernel: refused, never silently wrong
-    d = hip.ConvDesc()
-    with pytest.raises(hip.VcError):
-        pc.tuned = {(n, h, w, 0, hip.ACT_NONE, hip.EPI_GDN): pc.cfg | hip.CFG_WS | hip.CFG_EXACT}
-        if cin == cout and not ps:
-            pc(xt, epi=hip.EPI_GDN, mul=xt, in_xform=hip.IN_SQUARE)
-        else:
-            raise hip.VcError("n/a")
-
-
-@pytest.mark.parametrize("cin,cout,k,n,h,w,cfgs", WS_CASES)
-def test_producer_consumer_fp16_kernel_is_bit_identical(dev, cin, cout, k, n, h, w, cfgs):
-    """VC_CFG_WS (csrc/conv_ws.h): persistent workgroups, producer waves staging the next (tile, chunk) item into the
-    second LDS buffer, consumer waves contracting -- same geometry and accumulation order as the classic fp16 kernel of
-    the same tile configuration, so every result must be equal bit for bit: plain / residual / pixel-shuffle epilogues,
-    fp32 and half-precision inputs and outputs, ragged sizes, several images, more tiles than CUs."""
+@pytest.mark.parametrize("cin,cout,k,n,h,w,cfgs", DMA_CASES)
+def test_lds_dma_fp16_kernel_is_bit_identical(dev, cin, cout, k, n, h, w, cfgs):
+    """VC_CFG_DMA (csrc/conv_dma.h): one persistent workgroup per CU, both operands streamed into LDS by global_load_lds
+    behind counted vmcnt waits, the two waves of a SIMD half a phase apart.  Same accumulation order (32-channel chunk,
+    tap, k-step) and the same epilogue arithmetic as the classic fp16 instances, so every result must be equal bit for
+    bit: plain / residual / residual-first / sigmoid / channel-gain / pixel-shuffle epilogues, half and fp32 outputs,
+    ragged sizes (partial tiles in both directions), several images, more tiles than workgroups, several channel blocks."""
     from vcamd import hip
     from vcamd.hip import T
     ps = cout == 512
@@ -214,31 +177,46 @@ def test_producer_consumer_fp16_kernel_is_bit_identical(dev, cin, cout, k, n, h,
         pc = hip.PackedConv(wt, b, pixelshuffle=ps, device=dev)
     finally:
         hip.set_conv_precision("fp32")
-    assert pc.wpk16 is not None
+    assert pc.wpk16 is not None and hip.CFG_DMA in pc.candidates
     xt = hip.nchw_to_nhwc(x.to(dev))
     ho, wo, co = pc.out_shape(h, w)
     res = hip.nchw_to_nhwc(_rand((n, co, ho, wo), 54).to(dev))
+    gain = _rand((cout,), 55).abs().to(dev)
     fl = hip.CFG_F16
+    # a half-precision copy of the input, produced the way the models produce one: by an fp16-path layer's epilogue
+    ident = torch.zeros(cin, cin, 1, 1)
+    ident[torch.arange(cin), torch.arange(cin), 0, 0] = 1.0
+    hip.set_conv_precision("fp16")
+    try:
+        to_half = hip.PackedConv(ident, torch.zeros(cin), device=dev)
+    finally:
+        hip.set_conv_precision("fp32")
+    xh = to_half(xt, out_f16=True)
+    assert xh.dtype == "f16"
     seen = 0
-    for base in cfgs:
-        if base not in pc.candidates and base != pc.cfg:
+    outs = {}
+    for cfg in tuple(cfgs) + (hip.CFG_DMA,):
+        if cfg not in pc.candidates and cfg != pc.cfg:
             continue
-        outs = {}
-        for ws in (0, hip.CFG_WS):
-            pc.tuned = {(n, h, w, fl): base | ws | hip.CFG_EXACT | fl,
-                        (n, h, w, fl | hip.CFG_OUT_F16): base | ws | hip.CFG_EXACT | fl | hip.CFG_OUT_F16,
-                        (n, h, w, fl | hip.CFG_IN_F16): base | ws | hip.CFG_EXACT | fl | hip.CFG_IN_F16}
-            plain = pc(xt, act=hip.ACT_LRELU, slope=0.01)
-            with_res = pc(xt, act=hip.ACT_RELU, res=res)
-            half = pc(xt, act=hip.ACT_RELU, out_f16=True)                # half-precision output ...
-            assert half.dtype == "f16"
-            outs[ws] = [plain.buf.clone(), with_res.buf.clone(), half.buf.clone()]
-            if cout == cin and not ps:                                    # ... consumed as a half-precision input
-                outs[ws].append(pc(half, act=hip.ACT_NONE).buf.clone())
-        for a, c in zip(outs[0], outs[hip.CFG_WS]):
-            assert torch.equal(a, c), (base, (a.float() - c.float()).abs().max().item())
-        seen += 1
-    assert seen > 0
+        fi = fl | hip.CFG_IN_F16
+        pc.tuned = {(n, h, w, fi): cfg | hip.CFG_EXACT | fi, (n, h, w, fi | hip.CFG_OUT_F16): cfg | hip.CFG_EXACT | fi | hip.CFG_OUT_F16}
+        for a in (hip.ACT_SIGMOID,):
+            pc.tuned[(n, h, w, fi, a, hip.EPI_NONE)] = cfg | hip.CFG_EXACT | fi
+        o = [pc(xh, act=hip.ACT_LRELU, slope=0.01, out_f16=True), pc(xh, act=hip.ACT_RELU, res=res),
+             pc(xh, act=hip.ACT_RELU, res=res, res_first=True, out_f16=True), pc(xh, act=hip.ACT_SIGMOID)]
+        assert o[0].dtype == "f16" and o[1].dtype == "f32"
+        if not ps:
+            o.append(pc(xh, act=hip.ACT_NONE, chscale=gain))
+        outs[cfg] = [t.buf.clone() for t in o]
+        seen += cfg != hip.CFG_DMA
+    assert seen > 0 and hip.CFG_DMA in outs
+    for cfg, ref in outs.items():
+        for a, c in zip(ref, outs[hip.CFG_DMA]):
+            assert torch.equal(a, c), (cfg, (a.float() - c.float()).abs().max().item())
+    # an fp32 input is not offered by this kernel (the DMA cannot convert): refused, never silently wrong
+    pc.tuned = {(n, h, w, fl): hip.CFG_DMA | hip.CFG_EXACT | fl}
+    with pytest.raises(hip.VcError):
+        pc(xt, act=hip.ACT_NONE)
 
 
 def test_conv_residual_and_channel_slices(dev):

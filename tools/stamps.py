@@ -72,12 +72,6 @@ def main():
         L.vc_debug_read_stamps(buf)
         waves = buf[6] / reps
         print(f"conv k{k} {cin}->{cout} @{n}x{h}x{w} cfg={f[7] if len(f) > 7 else 'auto'}: waves/launch={waves:.0f}")
-        if len(f) > 7 and f[7] & hip.CFG_WS:
-            print("   (producer/consumer kernel: consumer waves only; 'barrier-after-stage' = waiting for the producers, 'mfma loop' = "
-                  "contraction of all items, no staging in these waves)")
-        if len(f) > 7 and f[7] & hip.CFG_WS:
-            print(f"   producers (per producer wave = per consumer wave): commit {buf[0] / buf[6]:.0f}, issue {buf[1] / buf[6]:.0f}, "
-                  f"waiting at the item barrier {buf[7] / buf[6]:.0f}")
         for i, name in enumerate(PHASES):
             print(f"   {name:22s} {buf[i] / buf[6]:12.0f} cycles/wave  {100.0 * buf[i] / buf[5]:5.1f}% of lifetime")
 

@@ -107,7 +107,7 @@ extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout,
 static inline bool cfg_f16_ok(int cfg, int cin)
 {
     return (cfg == VC_CFG_N128 || cfg == VC_CFG_N64 || cfg == VC_CFG_N32 || cfg == VC_CFG_N128B || cfg == VC_CFG_N16 ||
-            cfg == VC_CFG_PW || cfg == VC_CFG_N32T16) && (cin % 8) == 0;
+            cfg == VC_CFG_PW || cfg == VC_CFG_N32T16 || cfg == VC_CFG_DMA) && (cin % 8) == 0;
 }
 
 extern "C" size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride)
@@ -188,9 +188,6 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.chscale = d->chscale;
     const bool f16 = (d->cfg & VC_CFG_F16) != 0;
     if (f16 && (!cfg_f16_ok(d->cfg & 0xff, a.Cin) || d->in_xform != VC_IN_NONE)) return VC_EINVAL;
-    const bool ws = (d->cfg & VC_CFG_WS) != 0;
-    // producer/consumer kernel: tile configuration pinned by the caller, plain input (its producers do not square)
-    if (ws && (!(d->cfg & VC_CFG_EXACT) || d->in_xform != VC_IN_NONE)) return VC_EINVAL;
     a.in_f16 = (d->cfg & VC_CFG_IN_F16) ? 1 : 0;
     a.out_f16 = (d->cfg & VC_CFG_OUT_F16) ? 1 : 0;
     if ((a.in_f16 || a.out_f16) && !f16) return VC_EINVAL;   // half-precision tensors exist on the fp16 path only
@@ -240,8 +237,8 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
         if (!conv_pw_eligible(a, k, st, f16)) return VC_EINVAL;
         return conv_dispatch_pw(stream, a, f16);
     }
-    if (ws && !a.vec4) return VC_EINVAL;          // its producers stage with 16-byte loads
-    if (ws) cfg |= VC_CFG_WS_BIT;
+    if (cfg == VC_CFG_DMA)                  // fp16-path LDS-DMA pipeline: only ever chosen explicitly (autotuner)
+        return f16 ? conv_dispatch_dma(stream, a, k, st) : VC_EINVAL;
     switch (k) {
     case 1: return f16 ? conv_dispatch_k1_f16(stream, a, st, cfg, ck) : conv_dispatch_k1_f32(stream, a, st, cfg, ck);
     case 3: return f16 ? conv_dispatch_k3_f16(stream, a, st, cfg, ck) : conv_dispatch_k3_f32(stream, a, st, cfg, ck);

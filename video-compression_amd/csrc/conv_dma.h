@@ -1,0 +1,388 @@
+// fp16-path convolution as a one-workgroup-per-CU LDS-DMA pipeline (VC_CFG_DMA; stride 1, half-precision input).
+//
+// Why a different kernel: on the fp16 path a k-step is 16x shorter than on the fp32 path, and in conv_mfma_kernel the
+// phases of a workgroup (stage a chunk through registers / contract it with weight fragments fetched from L2 by every
+// wave / store) ADD UP instead of overlapping (0.24 + 0.56 + 0.27 ms for 3x3 128->128 x4).  Here
+//   * ONE persistent 512-thread workgroup per CU walks a list of 16 x 32-pixel output tiles (2 waves per SIMD);
+//   * BOTH operands reach LDS by global_load_lds_dwordx4 (no VGPR staging, no per-wave weight loads from L2):
+//       A: the tile's input footprint, one 32-channel chunk at a time, double-buffered -- the next chunk streams in
+//          while the current one is contracted; image borders read a zero page, so the image needs no select pass;
+//       B: the weights of one phase (8 fragments of 1 KiB = 16 MFMAs per wave) per ring slot, RING slots, fetched
+//          RING-2 phases ahead; every byte of B enters the CU once per tile instead of once per wave;
+//   * the loads are retired with COUNTED s_waitcnt vmcnt(N) across raw s_barriers (cdna guide, "Pipelining across
+//     barriers"); N is a compile-time function of the phase (schedule tables in DmaCfg);
+//   * the two waves of a SIMD run the phases half a phase apart (waves 0-3 contract while waves 4-7 read their
+//     fragments from LDS and vice versa): the matrix pipe always has a wave whose operands are already in registers;
+//   * LDS images are lane-linear (what the DMA writes); the bank-conflict-free layout of the A image comes from
+//     permuting the per-lane SOURCE addresses (16-byte channel groups XOR-ed with bits of the column).
+// Accumulation order per output = (32-channel chunk, tap, k-step), the order of the classic fp16 instances, and the
+// epilogue arithmetic is theirs too: results are bit-identical (tests/test_ops_gpu.py).
+#pragma once
+#include "conv_mfma.h"
+
+// zero page: source of halo pixels outside the image and of padding fragments; dump: where the stores of pixels outside
+// the output go, so that every wave issues the same number of stores per tile (they are counted by the vmcnt waits)
+static __device__ __attribute__((aligned(1024))) unsigned char g_vc_dma_zero[2048];
+static __device__ __attribute__((aligned(1024))) unsigned char g_vc_dma_dump[1024];
+
+template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_> struct DmaCfg {
+    static constexpr int KH = KH_, KW = KW_, TAPS = KH_ * KW_, NCHUNK = NCHUNK_, NT = NT_, RING = RING_;
+    static constexpr int MT = 32, TH = 16, XT = 1, TW = 32;
+    static constexpr int WAVES = 8, WAVES_N = (NT_ == 4) ? 2 : 1, WAVES_M = WAVES / WAVES_N;
+    static constexpr int WM = TH / WAVES_M, WN = NT_ / WAVES_N;
+    static constexpr int BN = NT_ * 32;
+    // a phase = 8 weight fragments (8 KiB, one DMA instruction per wave) = UPP (chunk, tap) units of 2 k-steps
+    static constexpr int UPP = 4 / NT_;
+    static constexpr int UT = NCHUNK_ * TAPS, PT = (UT + UPP - 1) / UPP;
+    static constexpr int ROWS_IN = TH + KH_ - 1, COLS = TW + KW_ - 1, PIX = ROWS_IN * COLS;
+    static constexpr int NA = (PIX * 4 + 511) / 512;          // DMA instructions per wave and chunk image (512 lanes x 16 B)
+    static constexpr int A_BYTES = NA * 8192;
+    static constexpr int B_OFF = 2 * A_BYTES, B_BYTES = RING_ * 8192;
+    static constexpr int BIAS_OFF = B_OFF + B_BYTES;
+    static constexpr int LDS_FIXED = BIAS_OFF;                // + 4 * Cout (padded) at launch
+    static constexpr int NST = WM * WN * 4;                   // stores per wave and tile
+    static_assert(NT_ == 1 || NT_ == 2 || NT_ == 4, "1, 2 or 4 N-tiles of 32 channels per workgroup");
+    static_assert(PT % RING_ == 0, "ring slot of a phase must be a compile-time constant");
+    static_assert(8 * VC_EPI_SCRATCH_FLOATS * 4 <= A_BYTES, "epilogue scratch lives in the chunk buffer that has just been finished");
+
+    static constexpr int pf(int c) { return c * TAPS / UPP; }                  // first / last phase reading chunk c
+    static constexpr int pl(int c) { return ((c + 1) * TAPS - 1) / UPP; }
+    // While chunk c is contracted, chunk c+1 (or chunk 0 of the next tile) streams into the other buffer.  Its pieces
+    // may start two phases after the last read of that buffer and must be OLDER than the weight load whose wait
+    // publishes the chunk's first phase.
+    static constexpr int wlo(int c) { return c == 0 ? 1 : pl(c - 1) + 2; }
+    static constexpr int whi(int c) { return (c + 1 == NCHUNK ? PT : pf(c + 1)) - RING + 2; }
+    static constexpr int piece_phase(int c, int k) { return wlo(c) + k / 2; }
+    static constexpr bool windows_ok()
+    {
+        for (int c = 0; c < NCHUNK; ++c)
+            if (piece_phase(c, NA - 1) > whi(c) || wlo(c) < 0) return false;
+        return true;
+    }
+    static_assert(windows_ok(), "the chunk image does not fit its issue window");
+    static constexpr int nA(int p)          // A pieces issued in phase p (before the phase's weight load)
+    {
+        int n = 0;
+        for (int c = 0; c < NCHUNK; ++c)
+            for (int k = 0; k < NA; ++k) n += piece_phase(c, k) == p;
+        return n;
+    }
+    // vmcnt for the wait of phase p: the weights of phase p+1 were issued in phase p-RING+3; everything issued after
+    // them may still be in flight (A pieces are issued before the weight load of their phase; the NST stores of the
+    // previous tile's epilogue lie between its last phase and phase 0).
+    static constexpr int nwait(int p)
+    {
+        int n = 0;
+        for (int j = p - RING + 4; j <= p; ++j) n += nA((j + PT) % PT) + 1;
+        if (p - RING + 3 < 0) n += NST;
+        return n;
+    }
+    static constexpr bool waits_ok()
+    {
+        for (int p = 0; p < PT; ++p)
+            if (nwait(p) > 63) return false;
+        return true;
+    }
+    static_assert(waits_ok(), "vmcnt is a 6-bit counter");
+};
+
+#define VC_DMA_FENCE() asm volatile("" ::: "memory")
+#define VC_DMA_BARRIER()                   \
+    do {                                   \
+        VC_DMA_FENCE();                    \
+        __builtin_amdgcn_s_barrier();      \
+        VC_DMA_FENCE();                    \
+    } while (0)
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to lds_byte_addr + 16 * lane
+// (M0 is compiler-reserved: written, used and restored inside one statement -- cdna guide 5.7)
+__device__ __forceinline__ void vc_glds16(const void *src, unsigned lds_byte_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_byte_addr)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void vc_wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct DmaTile {
+    int img, oy0, ox0, nblk;
+    bool valid;
+};
+
+// Epilogue of conv_epilogue_coalesced (same arithmetic per value, same LDS exchange) with UNCONDITIONAL stores: a pixel
+// or channel outside the output is written to the dump page instead of being skipped, so that the number of vector-memory
+// operations a wave issues per tile is a constant the counted waits can rely on.
+template <class C, int MODE>     // MODE 0 plain / ReLU / LeakyReLU, 3 sigmoid, 4 clamp01
+__device__ __forceinline__ void dma_epilogue_mode(const ConvArgs &p, f32x16 (&acc)[C::WM][C::WN], int nblk, int wm, int wn, int lane,
+                                                  int oy0, int ox0, int img, float *scratch)
+{
+    constexpr int WM = C::WM, WN = C::WN;
+    const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+    const int wpx = lane & 31, whalf = lane >> 5;          // accumulator layout: pixel, channel half-group
+    const int rq = lane & 7, rpx = lane >> 3;              // read-back layout: channel quad, pixel within a group of 8
+    const int cps = p.Cout >> 2;
+    const bool ps = p.out_mode != VC_OUT_PLAIN;
+    const int sc = ps ? 2 : 1;
+    const bool res_first = MODE == 0 && p.res_first;
+    float *const dump = reinterpret_cast<float *>(g_vc_dma_dump) + 4 * lane;
+    static_for<0, WM>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int oy = oy0 + wm * WM + t;
+        static_for<0, WN>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[t][n][4 * g], acc[t][n][4 * g + 1], acc[t][n][4 * g + 2], acc[t][n][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(&scratch[wpx * VC_EPI_ROWF + 8 * g + 4 * whalf]) = v;
+            }
+            const int co = nblk * C::BN + (wn * WN + n) * 32 + 4 * rq;   // first of this lane's 4 consecutive channels
+            const int pos = ps ? co / cps : 0;
+            const int cch = ps ? co - pos * cps : co;
+            f32x4 gain = {1.f, 1.f, 1.f, 1.f};
+            if (p.chscale) gain = *reinterpret_cast<const f32x4 *>(p.chscale + min(co, p.Cout - 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pix = 8 * j + rpx;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&scratch[pix * VC_EPI_ROWF + 4 * rq]);
+                const int ox = ox0 + pix;
+                const bool ok = oy < p.Ho && ox < p.Wo && co < p.Cout;
+                const int yy = sc * oy + (pos >> 1), xx = sc * ox + (pos & 1);
+                const long long o_off = (long long)img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
+                f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                if (p.res) {
+                    const long long r_off = (long long)img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
+                    if (ok) r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                }
+                if (res_first) v += r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (MODE == 3) v[e] = 1.0f / (1.0f + expf(-v[e]));
+                    else if constexpr (MODE == 4) v[e] = fminf(fmaxf(v[e], 0.0f), 1.0f);
+                    else v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
+                }
+                if (p.chscale) v *= gain;
+                if (p.res && !res_first) v += r;
+                if (p.out_f16) {
+                    const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    _Float16 *dst = ok ? reinterpret_cast<_Float16 *>(p.out) + o_off : reinterpret_cast<_Float16 *>(dump);
+                    *reinterpret_cast<f16x4 *>(dst) = hv;
+                } else {
+                    float *dst = ok ? p.out + o_off : dump;
+                    *reinterpret_cast<f32x4 *>(dst) = v;
+                }
+            }
+        });
+    });
+}
+
+template <class C>
+__device__ __forceinline__ void dma_epilogue(const ConvArgs &p, f32x16 (&acc)[C::WM][C::WN], int nblk, int wm, int wn, int lane,
+                                             int oy0, int ox0, int img, float *scratch)
+{
+    if (p.act == VC_ACT_SIGMOID) dma_epilogue_mode<C, 3>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, scratch);
+    else if (p.act == VC_ACT_CLAMP01) dma_epilogue_mode<C, 4>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, scratch);
+    else dma_epilogue_mode<C, 0>(p, acc, nblk, wm, wn, lane, oy0, ox0, img, scratch);
+}
+
+template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(const ConvArgs p)
+{
+    constexpr int KW = C::KW, TAPS = C::TAPS, NCHUNK = C::NCHUNK, NT = C::NT, RING = C::RING;
+    constexpr int WM = C::WM, WN = C::WN, UPP = C::UPP, UT = C::UT, PT = C::PT, NA = C::NA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];   // the kernel's only LDS object: starts at LDS address 0
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                       // the two waves of a SIMD belong to different groups
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- persistent tile list: the 32 workgroups that share an XCD (ids equal mod 8) walk one contiguous range of the
+    // banded tile order together, so halos and weights are shared in that XCD's L2 ----
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int total = per_img * p.N * p.nblks;
+    const int xcd = blockIdx.x & 7, xl = blockIdx.x >> 3;
+    const int tq = total >> 3, tr = total & 7;
+    const int x_start = xcd * tq + min(xcd, tr), x_count = tq + (xcd < tr ? 1 : 0);
+    auto tile_at = [&](int it) {
+        DmaTile t;
+        const int k = it * 32 + xl;
+        t.valid = k < x_count;
+        const int idx = x_start + (t.valid ? k : 0);
+        t.nblk = idx % p.nblks;
+        const int t1 = idx / p.nblks;
+        t.img = t1 / per_img;
+        int tx, ty;
+        vc_tile_xy(t1 - t.img * per_img, p.tiles_x, p.tiles_y, p.tile_band, tx, ty);
+        t.oy0 = ty * C::TH;
+        t.ox0 = tx * C::TW;
+        return t;
+    };
+    DmaTile cur = tile_at(0);
+    if (!cur.valid) return;
+
+    const unsigned char *const in_b = reinterpret_cast<const unsigned char *>(p.in);
+    const unsigned char *const wpk = reinterpret_cast<const unsigned char *>(p.wpk);
+    const int kst = p.cin_pad >> 4;                  // packed k-steps (16 channels) per tap
+    const unsigned char *const zero_lane = g_vc_dma_zero + 16 * lane;
+
+    // ---- issue helpers ----
+    // Piece k of a chunk image: lane (k, tid) fills LDS slot s = 512 k + tid = 4 * pixel + quarter; the quarter holds channel
+    // group (quarter ^ swizzle(column)) of the pixel -- the permutation is applied to the SOURCE address.  What does not
+    // depend on the tile is kept per lane: the byte offset of the lane's 16 bytes from the footprint's first pixel, and
+    // its (row, column) for the border test; a tile contributes a scalar base.
+    int a_off[NA], a_rc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int s = k * 512 + tid;
+        const int q = s >> 2;
+        const int row = q / C::COLS, col = q - row * C::COLS;
+        const int g = (s & 3) ^ ((col >> 2) & 3);
+        a_off[k] = 2 * (row * (int)p.in_sh + col * (int)p.in_sw + g * 8);
+        a_rc[k] = q < C::PIX ? (row | (col << 8)) : 0x7f7f7f;       // (a row / column no image reaches)
+    }
+    auto tile_base = [&](const DmaTile &t) {           // address of the footprint's first pixel (may lie outside the tensor)
+        return in_b + 2 * ((long long)t.img * p.in_sn + (long long)(t.oy0 - C::KH / 2) * p.in_sh + (long long)(t.ox0 - KW / 2) * p.in_sw);
+    };
+    auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {
+        const unsigned iy = (unsigned)(t.oy0 - C::KH / 2 + (a_rc[k] & 0xff)), ix = (unsigned)(t.ox0 - KW / 2 + (a_rc[k] >> 8));
+        const bool ok = t.valid && iy < (unsigned)p.H && ix < (unsigned)p.W;
+        const unsigned char *sp = ok ? tbase + (a_off[k] + c * 64) : zero_lane;
+        vc_glds16(sp, (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
+    };
+    // Weights of tile-phase pb (>= PT: of the next tile, same layer): wave w fetches fragment w of the phase =
+    // (unit w / (2 NT), k-step (w / NT) % 2, N-tile w % NT) from the packed [n-tile][tap][k-step] array.
+    const int b_uu = wave / (2 * NT), b_ks = (wave / NT) & 1, b_nt = wave % NT;
+    const unsigned char *const b_lane_src = wpk + ((long long)b_nt * TAPS * kst + b_ks) * 1024 + 16 * lane;
+    auto issue_b = [&](int pb, int nblk_cur, int nblk_next) {
+        const int pp = pb >= PT ? pb - PT : pb;
+        const int nblk = pb >= PT ? nblk_next : nblk_cur;
+        const int u = pp * UPP + (UPP > 1 ? b_uu : 0);
+        const int c = u / TAPS, tap = u - c * TAPS;
+        const long long soff = ((long long)nblk * NT * TAPS * kst + tap * kst + 2 * c) * 1024;
+        const unsigned char *sp = (UPP * PT == UT || u < UT) ? b_lane_src + soff : zero_lane;
+        vc_glds16(sp, (unsigned)(C::B_OFF + (pp % RING) * 8192 + wave * 1024));
+    };
+
+    // ---- prologue: bias of every channel block, first chunk image, weights of the first RING-2 phases ----
+    float *const ldsf = reinterpret_cast<float *>(lds8);
+    for (int i = tid; i < p.nblks * C::BN; i += 512) ldsf[C::BIAS_OFF / 4 + i] = p.bias[i];
+    DmaTile nxt = tile_at(1);
+    const unsigned char *cur_base = tile_base(cur), *nxt_base = tile_base(nxt);
+#pragma unroll
+    for (int k = 0; k < NA; ++k) issue_a(cur, cur_base, 0, k, 0);
+#pragma unroll
+    for (int pb = 0; pb < RING - 2; ++pb) issue_b(pb, cur.nblk, cur.nblk);
+    vc_wait_vmcnt<0>();
+    __syncthreads();
+
+    // ---- per-lane LDS read offsets ----
+    int a_lane[KW][2];
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int col = li + kx;
+            a_lane[kx][ks] = (wm * WM * C::COLS + col) * 64 + (((2 * ks + lh) ^ ((col >> 2) & 3)) << 4);
+        }
+    const int b_lane = C::B_OFF + wn * WN * 1024 + lane * 16;
+
+    f32x16 acc[WM][WN];
+    int gchunk = 0;                                  // chunks contracted so far: parity = buffer of the current chunk
+    for (int it = 0;; ++it) {
+        // ---- accumulators start at the bias ----
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(&ldsf[C::BIAS_OFF / 4 + cur.nblk * C::BN + (wn * WN + n) * 32 + 8 * g + 4 * lh]);
+#pragma unroll
+                for (int t = 0; t < WM; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][n][4 * g + e] = b[e];
+            }
+        if (grp == 1) VC_DMA_BARRIER();              // waves 4-7 run half a phase behind waves 0-3
+
+        static_for<0, PT>([&](auto pc) {
+            constexpr int ph = decltype(pc)::value;
+            // -- R: loads of later phases, then this phase's fragments --
+            static_for<0, NCHUNK>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                static_for<0, NA>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (C::piece_phase(c, k) == ph) {
+                        // chunk c+1 of this tile, or chunk 0 of the next one, into the buffer chunk c does not use
+                        if constexpr (c + 1 < NCHUNK) issue_a(cur, cur_base, c + 1, k, (gchunk + c + 1) & 1);
+                        else issue_a(nxt, nxt_base, 0, k, (gchunk + c + 1) & 1);
+                    }
+                });
+            });
+            issue_b(ph + RING - 2, cur.nblk, nxt.nblk);
+            f32x4 af[UPP][2][WM], bf[UPP][2][WN];
+            static_for<0, UPP>([&](auto uc) {
+                constexpr int uu = decltype(uc)::value;
+                constexpr int u = ph * UPP + uu;
+                if constexpr (u < UT) {
+                    constexpr int c = u / TAPS, tap = u % TAPS, ky = tap / KW, kx = tap % KW;
+                    const int a_off = ((gchunk + c) & 1) * C::A_BYTES;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                        for (int n = 0; n < WN; ++n)
+                            bf[uu][ks][n] = *reinterpret_cast<const f32x4 *>(lds8 + b_lane + (ph % RING) * 8192 + ((uu * 2 + ks) * NT + n) * 1024);
+#pragma unroll
+                        for (int t = 0; t < WM; ++t)
+                            af[uu][ks][t] = *reinterpret_cast<const f32x4 *>(lds8 + a_lane[kx][ks] + a_off + (t + ky) * C::COLS * 64);
+                    }
+                }
+            });
+            vc_wait_vmcnt<C::nwait(ph)>();           // this wave's part of the next phase's weights (and everything older) has landed
+            VC_DMA_BARRIER();
+            // -- M: 16 MFMAs per wave while the other group reads --
+            __builtin_amdgcn_s_setprio(1);
+            static_for<0, UPP>([&](auto uc) {
+                constexpr int uu = decltype(uc)::value;
+                if constexpr (ph * UPP + uu < UT) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int t = 0; t < WM; ++t)
+#pragma unroll
+                            for (int n = 0; n < WN; ++n)
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[uu][ks][n]),
+                                                                                   __builtin_bit_cast(f16x8, af[uu][ks][t]), acc[t][n], 0, 0, 0);
+                }
+            });
+            __builtin_amdgcn_s_setprio(0);
+            VC_DMA_BARRIER();
+        });
+        if (grp == 0) VC_DMA_BARRIER();              // (waves 4-7 finish their last phase)
+
+        // ---- epilogue through the buffer of the chunk that has just been finished ----
+        gchunk += NCHUNK;
+        float *scratch = reinterpret_cast<float *>(lds8 + ((gchunk - 1) & 1) * C::A_BYTES) + wave * VC_EPI_SCRATCH_FLOATS;
+        dma_epilogue<C>(p, acc, cur.nblk, wm, wn, lane, cur.oy0, cur.ox0, cur.img, scratch);
+        if (!nxt.valid) break;
+        cur = nxt;
+        cur_base = nxt_base;
+        nxt = tile_at(it + 2);
+        nxt_base = tile_base(nxt);
+    }
+    vc_wait_vmcnt<0>();                              // no DMA may land in LDS that already belongs to another workgroup
+}
+
+template <class C> int launch_conv_dma(hipStream_t st, const ConvArgs &a)
+{
+    const size_t lds_bytes = C::LDS_FIXED + (size_t)a.nblks * C::BN * sizeof(float);
+    if (lds_bytes > 160 * 1024) return VC_EINVAL;
+    auto kern = conv_dma_kernel<C>;
+    static vc_lds_raised raised;
+    if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds_bytes, st, a);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
+}

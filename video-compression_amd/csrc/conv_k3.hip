@@ -1,16 +1,7 @@
 // 3x3 convolutions: analysis/synthesis transforms, hyper-networks, U-Nets (stride 1 and 2).
-#include "conv_ws.h"
+#include "conv_mfma.h"
 int VC_DISPATCH(k3)(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck)
 {
-    if (cfg & VC_CFG_WS_BIT) {
-        if (stride != 1 || ck != 32) return VC_EINVAL;
-        switch (cfg & 0xff) {
-        case VC_CFG_N128B: return launch_conv_ws<3, 3, 1, 32, CfgN128b, VC_TU_F16 != 0>(st, a);
-        case VC_CFG_N64: return launch_conv_ws<3, 3, 1, 32, CfgN64, VC_TU_F16 != 0>(st, a);
-        case VC_CFG_N32: return launch_conv_ws<3, 3, 1, 32, CfgN32, VC_TU_F16 != 0>(st, a);
-        }
-        return VC_EINVAL;
-    }
     if (cfg == VC_CFG_N4) return (stride == 1 && ck == 16) ? launch_conv_n4<3, 3, 1, 16>(st, a) : VC_EINVAL;
     if (stride == 1 && ck == 32) {
         switch (cfg) {

@@ -1,16 +1,7 @@
 // 7x7 convolutions of SPyNet's Basic blocks (LHBDC/model/flow.py:52-62).
-#include "conv_ws.h"
+#include "conv_mfma.h"
 int VC_DISPATCH(k7)(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck)
 {
-    if (cfg & VC_CFG_WS_BIT) {
-        if (stride != 1 || ck != 16) return VC_EINVAL;
-        switch (cfg & 0xff) {
-        case VC_CFG_N32T16: return launch_conv_ws<7, 7, 1, 16, CfgN32T16, VC_TU_F16 != 0>(st, a);
-        case VC_CFG_N64: return launch_conv_ws<7, 7, 1, 16, CfgN64, VC_TU_F16 != 0>(st, a);
-        case VC_CFG_N32: return launch_conv_ws<7, 7, 1, 16, CfgN32, VC_TU_F16 != 0>(st, a);
-        }
-        return VC_EINVAL;
-    }
     if (cfg == VC_CFG_N4) return (stride == 1 && ck == 8) ? launch_conv_n4<7, 7, 1, 8>(st, a) : VC_EINVAL;
     if (stride != 1) return VC_EINVAL;
     if (ck == 8 && cfg == VC_CFG_N32) return launch_conv_p<7, 7, 1, 8, CfgN32>(st, a);

@@ -61,8 +61,6 @@ __device__ int g_vc_skip;
 #define VC_SKIP(bit) false
 #endif
 
-#define VC_CFG_WS_BIT 0x100      // dispatcher-internal: producer/consumer kernel (conv_ws.h) requested
-
 struct ConvArgs {
     const float *in;
     long long in_sn, in_sh, in_sw;
@@ -215,8 +213,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
 
 // INH: the input tensor itself is stored in half precision (VC_CFG_IN_F16): an item is ONE 16-byte load of 8
 // channels and needs no conversion -- the producer's epilogue already rounded exactly as this stage would have.
-// WIDE (producer waves of conv_ws.h, which hold no accumulators): the whole footprint in ONE round of loads when it fits.
-template <int KH, int KW, int S, int CK, class C, bool VEC, bool F16, bool INH = false, bool WIDE = false>
+template <int KH, int KW, int S, int CK, class C, bool VEC, bool F16, bool INH = false>
 __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const float *in_img, int c0, int oy0, int ox0,
                                             int iy0, int ix0, int tid)
 {
@@ -226,9 +223,7 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
     constexpr int ITEMS = G::ROWS_IN * G::COLS_IN * C4;
     constexpr int IPT = (ITEMS + 255) / 256;                    // items per thread
     constexpr int BATCH0 = (IPT + 1) / 2 > 8 ? 8 : (IPT + 1) / 2;   // two rounds per chunk when registers allow
-    constexpr int BATCH1 = (F16 && !INH) ? (BATCH0 > 4 ? 4 : BATCH0) : BATCH0; // (an fp16 item from fp32 data is two 16-byte loads)
-    constexpr int WIDE_MAX = INH ? 24 : 12;
-    constexpr int BATCH = !WIDE ? BATCH1 : (IPT <= WIDE_MAX ? IPT : (IPT + (IPT + WIDE_MAX - 1) / WIDE_MAX - 1) / ((IPT + WIDE_MAX - 1) / WIDE_MAX));
+    constexpr int BATCH = (F16 && !INH) ? (BATCH0 > 4 ? 4 : BATCH0) : BATCH0; // (an fp16 item from fp32 data is two 16-byte loads)
 #pragma unroll
     for (int b0 = 0; b0 < IPT; b0 += BATCH) {
         f32x4 v[BATCH], v2[(F16 && !INH) ? BATCH : 1];
@@ -296,7 +291,6 @@ __device__ __forceinline__ void stage_chunk(const ConvArgs &p, float *lds, const
 }
 
 // ---- epilogue: (GDN) -> activation -> channel gain -> residual -> store (plain / pixel-shuffle) ----
-// Shared by the classic kernel and the producer/consumer kernel (conv_ws.h).
 template <class C, bool F16>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &p, typename Mfma<C::MT>::acc_t (&acc)[C::WM][C::WN], int nblk, int wm,
                                               int wn, int lane, int oy0, int ox0, int img)
@@ -619,7 +613,13 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         ? reinterpret_cast<const float *>(reinterpret_cast<const _Float16 *>(p.in) + (long long)img * p.in_sn)
         : p.in + (long long)img * p.in_sn;
 
-    constexpr int RING = F16 ? vc_ring_depth(KW * KSTEPS, vc_ring_regs_classic(WM, WN, M::NREG, C::MIN_WAVES), WN) : 1;
+    // fp16 path, 64-channel chunks of a multi-tap kernel (3x3 stride 1): the chunk is contracted as two 32-channel halves,
+    // each over all taps, so that every output sums its k-steps in the order (32-channel chunk, tap, k-step) -- the order
+    // of the 32-channel-chunk instances (5x5, 7x7) and of the LDS-DMA kernel (conv_dma.h), which is therefore
+    // bit-identical to this one.  (1x1: a single tap, the order is the same either way.)
+    constexpr int SUBS = (F16 && KSTEPS == 4 && KH * KW > 1) ? 2 : 1;
+    constexpr int KSS = KSTEPS / SUBS;               // k-steps per tap and pass
+    constexpr int RING = F16 ? vc_ring_depth(KW * KSS, vc_ring_regs_classic(WM, WN, M::NREG, C::MIN_WAVES), WN) : 1;
     f32x4 ring[RING][WN];
     if constexpr (F16) {          // steps 0 .. RING-1 of the first chunk's first kernel row
 #pragma unroll
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
             for (int n = 0; n < WN; ++n)
                 ring[d][n] = *reinterpret_cast<const f32x4 *>(wlane + n * ntile_stride +
-                                                              ((long long)(d / KSTEPS) * ksteps_total + d % KSTEPS) * FR);
+                                                              ((long long)(d / KSS) * ksteps_total + d % KSS) * FR);
     }
 
     VC_T(t_start);
@@ -675,20 +675,35 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         if (VC_SKIP(2)) {
         } else if constexpr (F16) {
             // ---- fp16: weight fragments through a D-deep register ring (filled before the chunk loop and kept full
-            // across rows, chunks and the staging barriers), activations one step ahead from LDS ----
+            // across rows, passes, chunks and the staging barriers), activations one step ahead from LDS ----
+            constexpr int STEPS_R = KW * KSS;         // steps per kernel row and pass, fully unrolled
+            auto load_bs = [&](f32x4(&b)[WN], const float *wrow, int sx) {
+                const int kx = sx / KSS, ks = sx % KSS;
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+                    b[n] = *reinterpret_cast<const f32x4 *>(wrow + n * ntile_stride + ((long long)kx * ksteps_total + ks) * FR);
+            };
+            auto load_as = [&](f32x4(&a)[WM], int rowoff, int sx) {
+                const int kx = sx / KSS, ks = sx % KSS;
+                const int koff = (G::LS == 2) ? ((kx & 1) * G::HALF + (kx >> 1)) * G::CKP : kx * G::CKP;
+#pragma unroll
+                for (int t = 0; t < WM; ++t) a[t] = *reinterpret_cast<const f32x4 *>(&lds[abase[t] + rowoff + koff + ks * KS]);
+            };
             const float *wchunk_n = wlane + (long long)((c0 + CKC < p.cin_pad ? c0 + CKC : c0) / KSC) * FR;
-            load_a(ac, 0, 0);
+            load_as(ac, 0, 0);
 #pragma unroll 1
-            for (int ky = 0; ky < KH; ++ky) {
-                const float *wrow = wchunk + (long long)ky * KW * ksteps_total * FR;
-                const float *wrow_n = ky + 1 < KH ? wrow + (long long)KW * ksteps_total * FR : wchunk_n;
-                const int rowoff = ky * G::COLS_L * G::CKP;
-                const int rowoff_n = (ky + 1 < KH ? ky + 1 : ky) * G::COLS_L * G::CKP;
-                static_for<0, STEPS_X>([&](auto sc) {
+            for (int r = 0; r < SUBS * KH; ++r) {     // (pass, kernel row); a pass starts KSS k-steps further into the chunk
+                const int sub = r / KH, ky = r - sub * KH;
+                const int rn = r + 1, subn = rn / KH, kyn = rn - subn * KH;
+                const float *wrow = wchunk + ((long long)ky * KW * ksteps_total + sub * KSS) * FR;
+                const float *wrow_n = rn < SUBS * KH ? wchunk + ((long long)kyn * KW * ksteps_total + subn * KSS) * FR : wchunk_n;
+                const int rowoff = ky * G::COLS_L * G::CKP + sub * KSS * KS;
+                const int rowoff_n = rn < SUBS * KH ? kyn * G::COLS_L * G::CKP + subn * KSS * KS : rowoff;
+                static_for<0, STEPS_R>([&](auto sc) {
                     constexpr int sx = decltype(sc)::value;
                     constexpr int slot = sx % RING;
-                    if constexpr (sx + 1 < STEPS_X) load_a(an, rowoff, sx + 1);
-                    else load_a(an, rowoff_n, 0);
+                    if constexpr (sx + 1 < STEPS_R) load_as(an, rowoff, sx + 1);
+                    else load_as(an, rowoff_n, 0);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < WM; ++t)
@@ -701,9 +716,9 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                                 acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ring[slot][n]),
                                                                                    __builtin_bit_cast(f16x8, ac[t]), acc[t][n], 0, 0, 0);
                         }
-                    // refill the slot just consumed with the fragment RING steps ahead (same row, next row or next chunk)
-                    if constexpr (sx + RING < STEPS_X) load_b(ring[slot], wrow, sx + RING);
-                    else load_b(ring[slot], wrow_n, sx + RING - STEPS_X);
+                    // refill the slot just consumed with the fragment RING steps ahead (same row, next row / pass or next chunk)
+                    if constexpr (sx + RING < STEPS_R) load_bs(ring[slot], wrow, sx + RING);
+                    else load_bs(ring[slot], wrow_n, sx + RING - STEPS_R);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < WM; ++t) ac[t] = an[t];
@@ -797,7 +812,7 @@ template <int KH, int KW, int S, int CK, class C, bool F16 = false, bool BLDS = 
     const size_t lds_bytes = (G::LDS_FLOATS + 4) * sizeof(float) +       // + the staging dump slot
                              (BLDS ? (size_t)KH * KW * (a.cin_pad / G::KS) * 64 : 0);
     auto kern = conv_mfma_kernel<KH, KW, S, CK, C, F16, BLDS>;
-    static std::atomic<uint64_t> raised{0};      // per instance; one bit per device (common.h)
+    static vc_lds_raised raised;          // largest size raised per device (common.h)
     if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3(a.total_blocks), dim3(256), lds_bytes, st, a);
     return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
@@ -837,6 +852,8 @@ template <int KH, int KW, int S, int CK> int launch_conv_n4(hipStream_t st, cons
 // streaming 1x1 kernel (conv_pw.hip): same packed weights as the 32-wide configurations
 bool conv_pw_eligible(const ConvArgs &a, int k, int stride, bool f16);
 int conv_dispatch_pw(hipStream_t st, const ConvArgs &a, bool f16);
+// fp16-path LDS-DMA pipeline (conv_dma.hip): same packed weights again; sets the tile geometry of `a` itself
+int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride);
 VC_DECLARE_DISPATCH(k1)
 VC_DECLARE_DISPATCH(k3)
 VC_DECLARE_DISPATCH(k5)

@@ -241,7 +241,7 @@ template <int KQ, int NT, bool F16, bool INH, int EPI = 0> int launch_pw(hipStre
 {
     const size_t lds_bytes = (size_t)(NT * KQ * 256 + NT * 32 + (EPI == 0 ? 4 * (((NT * KQ >= 64) ? 16 : 32) + 1) * VC_EPI_ROWF : 0)) * sizeof(float);
     auto kern = conv_pw_kernel<KQ, NT, F16, INH, EPI>;
-    static std::atomic<uint64_t> raised{0};
+    static vc_lds_raised raised;          // largest size raised per device (common.h)
     if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
     const long long ntiles = (long long)a.N * a.H * ((a.W + 31) / 32);
     long long blocks = (ntiles + 3) / 4;

@@ -73,16 +73,19 @@ extern "C" long long vc_rans_encode_with_indexes(const int32_t *symbols, const i
         if (static_cast<uint32_t>(t) >= static_cast<uint32_t>(n_tables)) return VC_EINVAL;
         const int32_t *cdf = cdfs + static_cast<size_t>(t) * cdf_stride;
         const int32_t escape = cdf_sizes[t] - 2;
-        int32_t v = symbols[i] - offsets[t];
+        // (64-bit: a symbol rounded from an inf / NaN latent is INT_MIN or huge, and `symbol - offset`, `-2 v - 1`,
+        //  `2 (v - escape)` must not overflow before the range check below refuses it)
+        const int64_t v = static_cast<int64_t>(symbols[i]) - offsets[t];
         if (v >= 0 && v < escape) {
             enc.put(static_cast<uint32_t>(cdf[v]), static_cast<uint32_t>(cdf[v + 1] - cdf[v]));
             continue;
         }
         // out-of-table value: sign/magnitude folded into `raw`, sent as nibbles after the escape bin
-        const uint32_t raw = v < 0 ? static_cast<uint32_t>(-2 * v - 1) : static_cast<uint32_t>(2 * (v - escape));
+        const int64_t raw64 = v < 0 ? -2 * v - 1 : 2 * (v - escape);
         // (the format's own encoder counts nibbles with `raw >> (n*4)` on a 32-bit value: undefined from 2^28 on, so
         //  magnitudes that need an eighth nibble have no defined encoding -- refuse them)
-        if (raw >> 28) return VC_EINVAL;
+        if (raw64 >> 28) return VC_EINVAL;
+        const uint32_t raw = static_cast<uint32_t>(raw64);
         int32_t nibbles = 0;
         while ((raw >> (nibbles * kBypassBits)) != 0) ++nibbles;
         for (int32_t j = nibbles - 1; j >= 0; --j) enc.put_nibble((raw >> (j * kBypassBits)) & kBypassMax);

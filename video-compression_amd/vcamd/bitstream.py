@@ -29,7 +29,7 @@ import torch
 from . import hip
 from .gop import DECODING_INFO, LEVEL_GROUPS
 from .hip import T
-from .lhbdc import Model, _cli_predictors, _count, frame_list, read_container
+from .lhbdc import Model, _cli_predictors, _count, check_container_shapes, frame_list, read_container
 
 
 def _pack_container(lmbda, mv_shape, res_shape, mv_y, mv_z, res_y, res_z):
@@ -141,13 +141,14 @@ class LhbdcStreamCodec:
         mv_shape, res_shape = tuple(parsed[0][3]), tuple(parsed[0][4])
         if any(tuple(p[3]) != mv_shape or tuple(p[4]) != res_shape for p in parsed):
             raise hip.VcError("frames of one pass must have the same latent shapes")
+        check_container_shapes(mv_shape, res_shape, xb_[0].shape[-2], xb_[0].shape[-1])   # before anything is allocated from them
         zi_mv, zi_res = self.t_mv.z_index(*mv_shape), self.t_res.z_index(*res_shape)
         # 1. hyper-latents: fixed tables, a few thousand symbols per frame -- decoded at once, in parallel
         fz = [self.pool.submit(lambda p=p: (hip.rans_decode(p[1][1][0], zi_mv, *self.t_mv.eb),
                                             hip.rans_decode(p[2][1][0], zi_res, *self.t_res.eb))) for p in parsed]
         zs = [f.result() for f in fz]
-        z_mv = torch.from_numpy(np.stack([z[0] for z in zs])).to(dev, non_blocking=True)
-        z_res = torch.from_numpy(np.stack([z[1] for z in zs])).to(dev, non_blocking=True)
+        z_mv = torch.from_numpy(np.stack([z[0] for z in zs])).to(dev)
+        z_res = torch.from_numpy(np.stack([z[1] for z in zs])).to(dev)
         # 2. device: both hyper-syntheses FIRST (tiny), their indexes start travelling to the host ...
         means_mv, idx_mv = m.mv_compressor.hyper_decode_t(z_mv, n, mv_shape)
         means_res, idx_res = m.residual_compressor.hyper_decode_t(z_res, n, res_shape)
@@ -160,10 +161,10 @@ class LhbdcStreamCodec:
         i_mv, i_res = h_idx_mv.numpy(), h_idx_res.numpy()
         f_mv = [self.pool.submit(hip.rans_decode, parsed[i][1][0][0], i_mv[i], *self.t_mv.gc) for i in range(n)]
         f_res = [self.pool.submit(hip.rans_decode, parsed[i][2][0][0], i_res[i], *self.t_res.gc) for i in range(n)]
-        y_mv = torch.from_numpy(np.stack([f.result() for f in f_mv])).to(dev, non_blocking=True)
+        y_mv = torch.from_numpy(np.stack([f.result() for f in f_mv])).to(dev)
         mv_hat = m.mv_compressor.synth_decode_t(y_mv, means_mv)
         pred, _ = m._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww)
-        y_res = torch.from_numpy(np.stack([f.result() for f in f_res])).to(dev, non_blocking=True)
+        y_res = torch.from_numpy(np.stack([f.result() for f in f_res])).to(dev)
         res_hat = m.residual_compressor.synth_decode_t(y_res, means_res)
         return hip.nhwc_to_nchw(hip.axpby(res_hat, pred))
 

@@ -251,12 +251,7 @@ CFG_F16 = 0x200
 CFG_IN_F16 = 0x400
 CFG_OUT_F16 = 0x800
 CFG_RES_FIRST = 0x1000
-CFG_WS = 0x2000           # fp16 path: producer/consumer kernel with a double-buffered tile (csrc/conv_ws.h)
-# Which precisions offer the producer/consumer variants (csrc/conv_ws.h) to the autotuner: "0" (default), "fp32", "fp16" or
-# "all".  Bit-identical results either way, but measured slower than the classic kernels on every layer of the three
-# models at both precisions (with ONE consumer wave per SIMD the operand feed of the matrix pipe is not
-# covered -- tools/micro/mfma_feed.hip), and every extra candidate costs tuning time: opt-in, kept for the measurements.
-WS_KERNELS = os.environ.get("VC_WS_KERNELS", "0")
+CFG_DMA = 8               # fp16 path: LDS-DMA pipeline, one persistent workgroup per CU (csrc/conv_dma.h); half-precision input only
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
 # "fp32" (default, exact fp32 FMA chains like the reference) or "fp16" (BASELINE.json configs[4]: half-precision MFMA
 # with fp32 accumulate for every eligible layer; judged on PSNR/bpp tolerance, never the headline number).
@@ -326,6 +321,9 @@ class PackedConv:
             self.candidates.append(6)          # VC_CFG_PW: streaming 1x1 kernel (skipped by the tuner when the call is not eligible)
         if self.candidates and kh == 7 and stride == 1:
             self.candidates.append(7)          # VC_CFG_N32T16: 16-row tiles (less halo per output)
+        if (self.candidates and kh in (3, 7) and stride == 1 and cin % 32 == 0 and (cout in (32, 64) or cout % 128 == 0)
+                and os.environ.get("VC_DMA_KERNELS", "1") != "0"):
+            self.candidates.append(CFG_DMA)    # fp16 path, half-precision input (the library refuses shapes it has no instance for)
         # every alternative must read THIS packing: same channel chunk (the zero padding of cin depends on it)
         self.candidates = [c for c in self.candidates if L.vc_conv_chunk(c, kh, stride, cin) == ck]
 
@@ -335,9 +333,8 @@ class PackedConv:
         cands = self.candidates
         if flags & CFG_F16 and 5 in cands:
             cands = [c for c in cands if c != 0]     # the 4x1 128-channel fp16 instance spills registers
-        if WS_KERNELS in ("all", "fp16" if flags & CFG_F16 else "fp32") and self.k in (3, 7) and self.stride == 1:
-            # producer/consumer variants of the same tile configurations (bit-identical results; the tuner decides)
-            cands = cands + [c | CFG_WS for c in (cands or [self.cfg]) if c in (1, 2, 5, 7)]
+        if not (flags & CFG_F16 and flags & CFG_IN_F16):
+            cands = [c for c in cands if c != CFG_DMA]   # the LDS-DMA pipeline copies half-precision pixels as they are
         if not AUTOTUNE or len(cands) < 2 or torch.cuda.is_current_stream_capturing():
             return (cands[0] if cands else self.cfg) | flags
         best, best_ms = self.cfg, float("inf")

@@ -665,7 +665,8 @@ class ELIC(JointAutoregressiveHierarchicalPriors):
         z_index = np.repeat(np.arange(self.N, dtype=np.int32), hz * wz)
         z_sym = np.stack([hip.rans_decode(strings[1][k], z_index, eb_cdf, eb_len, eb_off) for k in range(n)])
         z_hat = T.empty(n, hz, wz, self.N, dev)
-        hip.check(L.vc_eb_dequant(hip.stream(), torch.from_numpy(z_sym).to(dev).data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
+        z_sym_d = torch.from_numpy(z_sym).to(dev)       # (bound to a local: must outlive the launch that reads it)
+        hip.check(L.vc_eb_dequant(hip.stream(), z_sym_d.data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
                                   None, z_hat.view()), "vc_eb_dequant")
         hyper = self.seq("h_s", z_hat)
         h, w = hyper.h, hyper.w

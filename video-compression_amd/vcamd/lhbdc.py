@@ -429,10 +429,29 @@ def encode_B(model, x_after, x_current, x_before, trace=None):
     return mv_bits, {"strings": strings, "shape": torch.Size(shape)}
 
 
+def expected_latent_shapes(h, w):
+    """Hyper-latent (z) shapes of the motion and the residual codec for an h x w frame (both already multiples of 64,
+    as every caller pads): the motion codec sees the flows pooled by 4 and re-padded to a multiple of 64 (m.py:38-47)."""
+    hp, wp = h // 4, w // 4
+    return ((hp + _pad64(hp)) // 64, (wp + _pad64(wp)) // 64), (h // 64, w // 64)
+
+
+def check_container_shapes(shape_flow, shape_res, h, w):
+    """The uint16 shapes of a bits_B header size every buffer of the decoder (index tensors, latents) BEFORE the range
+    decoder can notice a corrupt string: a hostile 65535 x 65535 would ask for tens of GB.  The shapes are a function of
+    the frame size alone, so anything else is refused here."""
+    want_mv, want_res = expected_latent_shapes(h, w)
+    got_mv, got_res = tuple(int(v) for v in shape_flow), tuple(int(v) for v in shape_res)
+    if got_mv != want_mv or got_res != want_res:
+        raise hip.VcError(f"bits_B container: latent shapes {got_mv} / {got_res} do not belong to a {h}x{w} frame "
+                          f"(expected {want_mv} / {want_res})")
+
+
 def decode_B(x_before, x_after, model, string_flow, string_res, shape_flow, shape_res, trace=None):
     """decode_B.py:63-86.  ``trace``: a dict that receives {"mv": {...}, "res": {...}} = the decoder's integers."""
     for t in (x_before, x_after):
         _require_cuda(t)
+    check_container_shapes(shape_flow, shape_res, x_before.shape[-2], x_before.shape[-1])
     xb_, xa_ = x_before.contiguous().float(), x_after.contiguous().float()
     n = xb_.shape[0]
     dev = xb_.device
