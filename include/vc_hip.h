@@ -127,6 +127,13 @@ int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d);
  * ---------------------------------------------------------------------------------------- */
 int vc_nchw_to_nhwc(vc_stream s, const float *src_nchw, vc_view dst);
 int vc_nhwc_to_nchw(vc_stream s, vc_view src, float *dst_nchw);
+/* Frame ingest / output of the test loop and the CLI scripts.
+ * vc_u8hwc_to_f32nchw_pad: 8-bit RGB [h][w][3] (a decoded PNG, device memory) -> fp32 NCHW [3][hp][wp] = x/255 with
+ *   nn.ReflectionPad2d((0, wp-w, 0, hp-h)): `normalize` + `pad` of LHBDC/encode_B.py:39-64, test/utils.py:190-203.
+ * vc_f32nchw_to_u8hwc: the top-left h x w window of an fp32 NCHW [3][hp][wp] frame -> 8-bit RGB [h][w][3] with
+ *   np.round(np.clip(x,0,1)*255): `float_to_uint8` + crop of LHBDC/decode_B.py:35-38,122-123. */
+int vc_u8hwc_to_f32nchw_pad(vc_stream s, const uint8_t *src_hwc, int h, int w, float *dst_nchw, int hp, int wp);
+int vc_f32nchw_to_u8hwc(vc_stream s, const float *src_nchw, int hp, int wp, uint8_t *dst_hwc, int h, int w);
 
 /* ------------------------------------------------------------------------------------------
  * Resampling / pooling / padding

@@ -67,6 +67,19 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[cfg].append(e0.elapsed_time(e1) / args.reps)
+        if hasattr(hip.lib(), "vc_debug_dma_stamps") and os.environ.get("VC_DMA_VARIANT") in ("64", "192", "320", "832", "72", "68", "76", "96", "65"):
+            import ctypes
+            buf = (ctypes.c_ulonglong * 8)()
+            hip.lib().vc_debug_dma_stamps.argtypes = [ctypes.c_void_p]
+            hip.lib().vc_debug_dma_stamps(buf)
+            pc.tuned = {(n, h, w, fl | of): hip.CFG_DMA | hip.CFG_EXACT | fl | of}
+            pc(x, out=out, act=hip.ACT_LRELU)
+            hip.lib().vc_debug_dma_stamps(buf)
+            names = ["DMA issue", "fragment reads (issue + return)", "vmcnt wait", "barrier after R", "MFMA issue", "barrier after M",
+                     "epilogue", "wave lifetime"]
+            waves = 256 * 8
+            for i, nm in enumerate(names):
+                print(f"   {nm:34s} {buf[i] / waves:12.0f} cycles/wave  {100.0 * buf[i] / max(1, buf[7]):5.1f}% of lifetime")
         flop = 2.0 * n * ho * wo * cout * cin * k * k
         tc, td = min(times[ccfg]), min(times[hip.CFG_DMA])
         print(f"conv k{k} {cin:4d}->{cout:4d} @{n}x{h}x{w}: bit-identical={same} (max|d|={maxd:.3g})  classic cfg{ccfg} {tc:7.3f} ms "

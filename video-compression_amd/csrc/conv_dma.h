@@ -25,7 +25,12 @@
 static __device__ __attribute__((aligned(1024))) unsigned char g_vc_dma_zero[2048];
 static __device__ __attribute__((aligned(1024))) unsigned char g_vc_dma_dump[1024];
 
-template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_> struct DmaCfg {
+// KO_: diagnostic knock-out mask (tools/dma_check.py --ko; results are garbage by design, the time that remains is what the
+// other parts cost): 1 no epilogue, 2 no vmcnt waits, 4 no MFMAs, 8 no fragment reads, 16 no DMA, 32 no stagger, 64 cycle stamps, 128 no s_setprio around the MFMAs, 256 DMA issue BEFORE the fragment reads,
+// 512 M0 not restored, 1024 no A DMA, 2048 no B DMA, 4096 two A pieces per phase, 8192 weights by 64-bit lane addresses,
+// 16384 no fast epilogue.  Shipped instances use 0.
+template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0> struct DmaCfg {
+    static constexpr int KO = KO_;
     static constexpr int KH = KH_, KW = KW_, TAPS = KH_ * KW_, NCHUNK = NCHUNK_, NT = NT_, RING = RING_;
     static constexpr int MT = 32, TH = 16, XT = 1, TW = 32;
     static constexpr int WAVES = 8, WAVES_N = (NT_ == 4) ? 2 : 1, WAVES_M = WAVES / WAVES_N;
@@ -40,7 +45,9 @@ template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_> struct DmaCfg {
     static constexpr int B_OFF = 2 * A_BYTES, B_BYTES = RING_ * 8192;
     static constexpr int BIAS_OFF = B_OFF + B_BYTES;
     static constexpr int LDS_FIXED = BIAS_OFF;                // + 4 * Cout (padded) at launch
-    static constexpr int NST = WM * WN * 4;                   // stores per wave and tile
+    // stores per wave and tile the counted waits may rely on: the fast epilogue issues WM * WN * 2 (16 bytes per lane),
+    // the general one twice as many (a wait that counts too few younger operations only waits a little longer)
+    static constexpr int NST = WM * WN * 2;
     static_assert(NT_ == 1 || NT_ == 2 || NT_ == 4, "1, 2 or 4 N-tiles of 32 channels per workgroup");
     static_assert(PT % RING_ == 0, "ring slot of a phase must be a compile-time constant");
     static_assert(8 * VC_EPI_SCRATCH_FLOATS * 4 <= A_BYTES, "epilogue scratch lives in the chunk buffer that has just been finished");
@@ -52,7 +59,13 @@ template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_> struct DmaCfg {
     // publishes the chunk's first phase.
     static constexpr int wlo(int c) { return c == 0 ? 1 : pl(c - 1) + 2; }
     static constexpr int whi(int c) { return (c + 1 == NCHUNK ? PT : pf(c + 1)) - RING + 2; }
-    static constexpr int piece_phase(int c, int k) { return wlo(c) + k / 2; }
+    static constexpr int ppp(int c)          // pieces per phase: as few as the window allows (they come from HBM; a burst blocks the issuing waves)
+    {
+        const int room = whi(c) - wlo(c) + 1;
+        const int need = room > 0 ? (NA + room - 1) / room : NA;
+        return (KO & 4096) ? (need > 2 ? need : 2) : need;
+    }
+    static constexpr int piece_phase(int c, int k) { return wlo(c) + k / ppp(c); }
     static constexpr bool windows_ok()
     {
         for (int c = 0; c < NCHUNK; ++c)
@@ -87,6 +100,11 @@ template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_> struct DmaCfg {
 };
 
 #define VC_DMA_FENCE() asm volatile("" ::: "memory")
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VC_DMA_KEEP(x) asm volatile("" ::"v"(x))      // diagnostic builds: keeps a value alive whose consumer was knocked out
+#else
+#define VC_DMA_KEEP(x) ((void)(x))
+#endif
 #define VC_DMA_BARRIER()                   \
     do {                                   \
         VC_DMA_FENCE();                    \
@@ -96,18 +114,49 @@ template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_> struct DmaCfg {
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to lds_byte_addr + 16 * lane
 // (M0 is compiler-reserved: written, used and restored inside one statement -- cdna guide 5.7)
-__device__ __forceinline__ void vc_glds16(const void *src, unsigned lds_byte_addr)
+template <bool RESTORE_M0 = true> __device__ __forceinline__ void vc_glds16(const void *src, unsigned lds_byte_addr)
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(lds_byte_addr)
+    if constexpr (RESTORE_M0) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(lds_byte_addr)
+                     : "memory");
+    } else {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
+    }
+}
+// the same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the address operand the issuing
+// wave has to move is half as wide, which halves the issue cost next to a SIMD partner that is issuing MFMAs
+// (tools/micro/glds_rate.hip: 31 vs 77 cycles)
+__device__ __forceinline__ void vc_glds16_sbase(const void *uniform_base, unsigned lane_off, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(uniform_base), "s"(lds_byte_addr)
                  : "memory");
 }
 template <int N> __device__ __forceinline__ void vc_wait_vmcnt()
 {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+
+#ifdef VC_DMA_DIAG
+// diagnostic build only: shader-clock totals per segment, summed over all waves (KO bit 64; vc_debug_dma_stamps reads them)
+__device__ unsigned long long g_vc_dma_stamps[8];
+#define VC_DMA_STAMP(var)                                                                             \
+    unsigned var = 0;                                                                                 \
+    if constexpr (C::KO & 64) {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t__;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                   \
+        var = (unsigned)t__;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+#define VC_DMA_ACC(slot, t1, t0) \
+    if constexpr (C::KO & 64) st_sum[slot] += (t1) - (t0)
+#else
+#define VC_DMA_STAMP(var)
+#define VC_DMA_ACC(slot, t1, t0)
+#endif
 
 struct DmaTile {
     int img, oy0, ox0, nblk;
@@ -177,6 +226,53 @@ __device__ __forceinline__ void dma_epilogue_mode(const ConvArgs &p, f32x16 (&ac
                 }
             }
         });
+    });
+}
+
+// Fast epilogue for the common case inside a chain of fp16-path layers: half-precision output, plain / ReLU / LeakyReLU
+// (slope in [0, 1]), no residual / gain / pixel shuffle, tile entirely inside the output.  Per M-tile the wave's
+// 32 px x (32 WN) channels are activated and rounded in the accumulator layout, pass through a private 32 x (64 WN)-byte
+// LDS image (16-byte chunks XOR-ed with the pixel index: conflict-free ds_read_b128) and leave as 16 bytes per lane =
+// whole 128-byte lines per 8 lanes: WM * WN * 2 store instructions per wave and tile instead of WM * WN * 4 of 8 bytes.
+// Same value per output as dma_epilogue_mode<0>: max(v, v * neg) == (v >= 0 ? v : v * neg) for 0 <= neg <= 1, one
+// round-to-nearest conversion.
+template <class C>
+__device__ __forceinline__ void dma_epilogue_fast(const ConvArgs &p, f32x16 (&acc)[C::WM][C::WN], int nblk, int wm, int wn, int lane,
+                                                  int oy0, int ox0, int img, unsigned char *scratch)
+{
+    constexpr int WM = C::WM, WN = C::WN;
+    constexpr int CH16 = 4 * WN;                 // 16-byte chunks (8 channels) per pixel of this wave's channel range
+    constexpr int ROWB = 16 * CH16;              // bytes per pixel in the exchange image
+    constexpr int PPI = 64 / CH16;               // pixels per store instruction
+    const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+    const int wpx = lane & 31, wh = lane >> 5;
+    const int rc = lane % CH16, rp = lane / CH16;
+    // (wave-uniform) first output element of the wave's channel range in the tile's first pixel
+    _Float16 *const obase = reinterpret_cast<_Float16 *>(p.out) + (long long)img * p.out_sn + (long long)oy0 * p.out_sh +
+                            (long long)ox0 * p.out_sw + nblk * C::BN + wn * WN * 32;
+    static_for<0, WM>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        static_for<0, WN>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[t][n][4 * g + e];
+                    h[e] = (_Float16)fmaxf(v, v * neg);
+                }
+                const int c = 4 * n + g;
+                *reinterpret_cast<f16x4 *>(scratch + wpx * ROWB + ((c ^ (wpx & (CH16 - 1))) << 4) + 8 * wh) = h;
+            }
+        });
+        const long long row = (long long)(wm * WM + t) * p.out_sh;
+#pragma unroll
+        for (int j = 0; j < 32 / PPI; ++j) {
+            const int px = PPI * j + rp;
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(scratch + px * ROWB + ((rc ^ (px & (CH16 - 1))) << 4));
+            *reinterpret_cast<f32x4 *>(obase + row + (long long)px * p.out_sw + 8 * rc) = d;
+        }
     });
 }
 
@@ -253,20 +349,24 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         const unsigned iy = (unsigned)(t.oy0 - C::KH / 2 + (a_rc[k] & 0xff)), ix = (unsigned)(t.ox0 - KW / 2 + (a_rc[k] >> 8));
         const bool ok = t.valid && iy < (unsigned)p.H && ix < (unsigned)p.W;
         const unsigned char *sp = ok ? tbase + (a_off[k] + c * 64) : zero_lane;
-        vc_glds16(sp, (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
+        if constexpr (!(C::KO & (16 | 1024))) vc_glds16<!(C::KO & 512)>(sp, (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
     };
     // Weights of tile-phase pb (>= PT: of the next tile, same layer): wave w fetches fragment w of the phase =
     // (unit w / (2 NT), k-step (w / NT) % 2, N-tile w % NT) from the packed [n-tile][tap][k-step] array.
     const int b_uu = wave / (2 * NT), b_ks = (wave / NT) & 1, b_nt = wave % NT;
-    const unsigned char *const b_lane_src = wpk + ((long long)b_nt * TAPS * kst + b_ks) * 1024 + 16 * lane;
+    const long long b_wave_frag = (long long)b_nt * TAPS * kst + b_ks;       // wave-uniform
+    const unsigned lane16 = 16 * lane;
     auto issue_b = [&](int pb, int nblk_cur, int nblk_next) {
         const int pp = pb >= PT ? pb - PT : pb;
         const int nblk = pb >= PT ? nblk_next : nblk_cur;
         const int u = pp * UPP + (UPP > 1 ? b_uu : 0);
         const int c = u / TAPS, tap = u - c * TAPS;
-        const long long soff = ((long long)nblk * NT * TAPS * kst + tap * kst + 2 * c) * 1024;
-        const unsigned char *sp = (UPP * PT == UT || u < UT) ? b_lane_src + soff : zero_lane;
-        vc_glds16(sp, (unsigned)(C::B_OFF + (pp % RING) * 8192 + wave * 1024));
+        const long long frag = b_wave_frag + (long long)nblk * NT * TAPS * kst + tap * kst + 2 * c;
+        const unsigned char *sbase = (UPP * PT == UT || u < UT) ? wpk + frag * 1024 : g_vc_dma_zero;
+        if constexpr (!(C::KO & (16 | 2048))) {
+            if constexpr (C::KO & 8192) vc_glds16<false>(sbase + lane16, (unsigned)(C::B_OFF + (pp % RING) * 8192 + wave * 1024));
+            else vc_glds16_sbase(sbase, lane16, (unsigned)(C::B_OFF + (pp % RING) * 8192 + wave * 1024));
+        }
     };
 
     // ---- prologue: bias of every channel block, first chunk image, weights of the first RING-2 phases ----
@@ -292,6 +392,10 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         }
     const int b_lane = C::B_OFF + wn * WN * 1024 + lane * 16;
 
+#ifdef VC_DMA_DIAG
+    unsigned st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    VC_DMA_STAMP(t_begin);
     f32x16 acc[WM][WN];
     int gchunk = 0;                                  // chunks contracted so far: parity = buffer of the current chunk
     for (int it = 0;; ++it) {
@@ -306,28 +410,41 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[t][n][4 * g + e] = b[e];
             }
-        if (grp == 1) VC_DMA_BARRIER();              // waves 4-7 run half a phase behind waves 0-3
+        if (grp == 1 && !(C::KO & 32)) VC_DMA_BARRIER();              // waves 4-7 run half a phase behind waves 0-3
 
         static_for<0, PT>([&](auto pc) {
             constexpr int ph = decltype(pc)::value;
-            // -- R: loads of later phases, then this phase's fragments --
+            VC_DMA_STAMP(t0);
+            // -- R: loads of later phases, and this phase's fragments --
+            auto issue_loads = [&]() {
             static_for<0, NCHUNK>([&](auto cc) {
-                constexpr int c = decltype(cc)::value;
-                static_for<0, NA>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    if constexpr (C::piece_phase(c, k) == ph) {
-                        // chunk c+1 of this tile, or chunk 0 of the next one, into the buffer chunk c does not use
-                        if constexpr (c + 1 < NCHUNK) issue_a(cur, cur_base, c + 1, k, (gchunk + c + 1) & 1);
-                        else issue_a(nxt, nxt_base, 0, k, (gchunk + c + 1) & 1);
-                    }
+                    constexpr int c = decltype(cc)::value;
+                    static_for<0, NA>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (C::piece_phase(c, k) == ph) {
+                            // chunk c+1 of this tile, or chunk 0 of the next one, into the buffer chunk c does not use
+                            if constexpr (c + 1 < NCHUNK) issue_a(cur, cur_base, c + 1, k, (gchunk + c + 1) & 1);
+                            else issue_a(nxt, nxt_base, 0, k, (gchunk + c + 1) & 1);
+                        }
+                    });
                 });
-            });
-            issue_b(ph + RING - 2, cur.nblk, nxt.nblk);
+                issue_b(ph + RING - 2, cur.nblk, nxt.nblk);
+            };
+            if constexpr (C::KO & 256) issue_loads();
+            VC_DMA_STAMP(t1);
             f32x4 af[UPP][2][WM], bf[UPP][2][WN];
             static_for<0, UPP>([&](auto uc) {
                 constexpr int uu = decltype(uc)::value;
                 constexpr int u = ph * UPP + uu;
-                if constexpr (u < UT) {
+                if constexpr (u < UT && (C::KO & 8)) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) bf[uu][ks][n] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)lane;
+#pragma unroll
+                        for (int t = 0; t < WM; ++t) af[uu][ks][t] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(lane + t);
+                    }
+                } else if constexpr (u < UT) {
                     constexpr int c = u / TAPS, tap = u % TAPS, ky = tap / KW, kx = tap % KW;
                     const int a_off = ((gchunk + c) & 1) * C::A_BYTES;
 #pragma unroll
@@ -341,13 +458,26 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
                     }
                 }
             });
-            vc_wait_vmcnt<C::nwait(ph)>();           // this wave's part of the next phase's weights (and everything older) has landed
+            VC_DMA_STAMP(t1b);
+            if constexpr (!(C::KO & 256)) issue_loads();
+            VC_DMA_STAMP(t2);                        // (a stamp waits for the fragment reads: t2 - t1 = LDS reads issued and returned)
+            if constexpr (!(C::KO & 2)) vc_wait_vmcnt<C::nwait(ph)>();           // this wave's part of the next phase's weights (and everything older) has landed
+            VC_DMA_STAMP(t3);
             VC_DMA_BARRIER();
+            VC_DMA_STAMP(t4);
             // -- M: 16 MFMAs per wave while the other group reads --
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (!(C::KO & 128)) __builtin_amdgcn_s_setprio(1);
             static_for<0, UPP>([&](auto uc) {
                 constexpr int uu = decltype(uc)::value;
-                if constexpr (ph * UPP + uu < UT) {
+                if constexpr (ph * UPP + uu < UT && (C::KO & 4)) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)       // keep the fragments alive without the matrix work
+#pragma unroll
+                        for (int t = 0; t < WM; ++t) {
+                            VC_DMA_KEEP(af[uu][ks][t]);
+                            VC_DMA_KEEP(bf[uu][ks][t % WN]);
+                        }
+                } else if constexpr (ph * UPP + uu < UT) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -358,15 +488,42 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
                                                                                    __builtin_bit_cast(f16x8, af[uu][ks][t]), acc[t][n], 0, 0, 0);
                 }
             });
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (!(C::KO & 128)) __builtin_amdgcn_s_setprio(0);
+            VC_DMA_STAMP(t5);
             VC_DMA_BARRIER();
+            VC_DMA_STAMP(t6);
+            VC_DMA_ACC(0, t1, t0);   // DMA issue (before the fragment reads, or after them: KO bit 256)
+            VC_DMA_ACC(0, t2, t1b);
+            VC_DMA_ACC(1, t1b, t1);  // fragment reads
+            VC_DMA_ACC(2, t3, t2);   // vmcnt wait
+            VC_DMA_ACC(3, t4, t3);   // barrier after R
+            VC_DMA_ACC(4, t5, t4);   // MFMA issue
+            VC_DMA_ACC(5, t6, t5);   // barrier after M
         });
-        if (grp == 0) VC_DMA_BARRIER();              // (waves 4-7 finish their last phase)
+        if (grp == 0 && !(C::KO & 32)) VC_DMA_BARRIER();              // (waves 4-7 finish their last phase)
 
         // ---- epilogue through the buffer of the chunk that has just been finished ----
         gchunk += NCHUNK;
         float *scratch = reinterpret_cast<float *>(lds8 + ((gchunk - 1) & 1) * C::A_BYTES) + wave * VC_EPI_SCRATCH_FLOATS;
-        dma_epilogue<C>(p, acc, cur.nblk, wm, wn, lane, cur.oy0, cur.ox0, cur.img, scratch);
+        VC_DMA_STAMP(t_e0);
+        if constexpr (C::KO & 1) {
+#pragma unroll
+            for (int t = 0; t < WM; ++t)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) VC_DMA_KEEP(acc[t][n]);
+        } else {
+            const bool fast = !(C::KO & 16384) && p.out_f16 && !p.res && !p.chscale && p.out_mode == VC_OUT_PLAIN &&
+                              (p.act == VC_ACT_NONE || p.act == VC_ACT_RELU || (p.act == VC_ACT_LRELU && p.slope >= 0.0f && p.slope <= 1.0f)) &&
+                              cur.oy0 + C::TH <= p.Ho && cur.ox0 + C::TW <= p.Wo && (p.out_sw & 7) == 0 && (p.out_sh & 7) == 0 &&
+                              (p.out_sn & 7) == 0;
+            if (fast)
+                dma_epilogue_fast<C>(p, acc, cur.nblk, wm, wn, lane, cur.oy0, cur.ox0, cur.img,
+                                     reinterpret_cast<unsigned char *>(scratch - wave * VC_EPI_SCRATCH_FLOATS) + wave * 4096);
+            else
+                dma_epilogue<C>(p, acc, cur.nblk, wm, wn, lane, cur.oy0, cur.ox0, cur.img, scratch);
+        }
+        VC_DMA_STAMP(t_e1);
+        VC_DMA_ACC(6, t_e1, t_e0);   // epilogue
         if (!nxt.valid) break;
         cur = nxt;
         cur_base = nxt_base;
@@ -374,6 +531,14 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         nxt_base = tile_base(nxt);
     }
     vc_wait_vmcnt<0>();                              // no DMA may land in LDS that already belongs to another workgroup
+#ifdef VC_DMA_DIAG
+    if constexpr (C::KO & 64) {
+        VC_DMA_STAMP(t_end);
+        st_sum[7] = t_end - t_begin;                 // wave lifetime
+        if (lane == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_vc_dma_stamps[i], (unsigned long long)st_sum[i]);
+    }
+#endif
 }
 
 template <class C> int launch_conv_dma(hipStream_t st, const ConvArgs &a)

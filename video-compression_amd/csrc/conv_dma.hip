@@ -1,6 +1,7 @@
 // Dispatcher of the fp16-path LDS-DMA convolution pipeline (conv_dma.h, VC_CFG_DMA).
 //   3x3 stride 1: analysis / synthesis transforms and residual blocks (LHBDC/model/layers.py:123-166,
 //                 ICIP2024/src/model/compression_bottlenecks.py:72-551);  7x7: SPyNet's Basic blocks (LHBDC/model/flow.py:52-62).
+#include <stdlib.h>
 #include "conv_dma.h"
 
 static bool dma_views_ok(const ConvArgs &a)
@@ -20,7 +21,50 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
     a.nblks = a.Cout / (32 * nt);
     a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
     if (k == 3) {
-        if (nt == 4 && nchunk == 4) return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6>>(st, a);
+        if (nt == 4 && nchunk == 4) {
+#ifdef VC_DMA_DIAG      // diagnostic build only (make dma_diag): knock-out / ring-depth variants of the north-star instance
+            const char *e = getenv("VC_DMA_VARIANT");
+            const int v = e ? atoi(e) : 0;
+            switch (v) {
+            case 1: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 1>>(st, a);
+            case 2: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 2>>(st, a);
+            case 3: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 3>>(st, a);
+            case 7: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 7>>(st, a);
+            case 11: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 11>>(st, a);
+            case 19: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 19>>(st, a);
+            case 27: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 27>>(st, a);
+            case 32: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 32>>(st, a);
+            case 64: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 64>>(st, a);
+            case 128: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 128>>(st, a);
+            case 129: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 129>>(st, a);
+            case 160: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 160>>(st, a);
+            case 192: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 192>>(st, a);
+            case 256: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 256>>(st, a);
+            case 320: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 320>>(st, a);
+            case 512: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 512>>(st, a);
+            case 768: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 768>>(st, a);
+            case 832: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 832>>(st, a);
+            case 72: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 72>>(st, a);
+            case 68: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 68>>(st, a);
+            case 76: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 76>>(st, a);
+            case 96: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 96>>(st, a);
+            case 65: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 65>>(st, a);
+            case 1025: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 1025>>(st, a);
+            case 2049: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 2049>>(st, a);
+            case 257: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 257>>(st, a);
+            case 1281: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 1281>>(st, a);
+            case 2305: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 2305>>(st, a);
+            case 17: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 17>>(st, a);
+            case 4096: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 4096>>(st, a);
+            case 8192: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 8192>>(st, a);
+            case 16384: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 16384>>(st, a);
+            case 100: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 9>>(st, a);
+            case 101: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 9, 1>>(st, a);
+            case 102: return launch_conv_dma<DmaCfg<3, 3, 4, 4, 4>>(st, a);
+            }
+#endif
+            return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6>>(st, a);
+        }
         if (nt == 4 && nchunk == 2) return launch_conv_dma<DmaCfg<3, 3, 2, 4, 6>>(st, a);
         if (nt == 4 && nchunk == 6) return launch_conv_dma<DmaCfg<3, 3, 6, 4, 6>>(st, a);
         if (nt == 4 && nchunk == 8) return launch_conv_dma<DmaCfg<3, 3, 8, 4, 6>>(st, a);
@@ -30,3 +74,14 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
     }
     return VC_EINVAL;
 }
+
+#ifdef VC_DMA_DIAG
+extern "C" int vc_debug_dma_stamps(unsigned long long *out8)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return VC_ELAUNCH;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vc_dma_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return VC_ELAUNCH;
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_vc_dma_stamps), zero, sizeof(zero)) != hipSuccess) return VC_ELAUNCH;
+    return VC_OK;
+}
+#endif

@@ -36,6 +36,51 @@ __global__ void k_nhwc_to_nchw(vc_view s, float *__restrict__ dst)
     }
 }
 
+// ---- frame ingest / output (the data loader's and the CLI's pixel work) ----
+// uint8 RGB [h][w][3] (what a PNG decoder delivers) -> fp32 NCHW [3][hp][wp], /255, reflection-padded on the bottom and
+// right to (hp, wp): normalize + pad of LHBDC/encode_B.py:39-64 and test/utils.py:190-203 in one pass.
+__global__ void k_u8hwc_to_f32nchw_pad(const uint8_t *__restrict__ src, int h, int w, float *__restrict__ dst, int hp, int wp)
+{
+    const long long total = 3ll * hp * wp;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wp);
+        const long long t = i / wp;
+        const int y = (int)(t % hp), c = (int)(t / hp);
+        const int sy = y < h ? y : 2 * (h - 1) - y, sx = x < w ? x : 2 * (w - 1) - x;      // nn.ReflectionPad2d
+        dst[i] = (float)src[((long long)sy * w + sx) * 3 + c] / 255.0f;
+    }
+}
+
+// fp32 NCHW [3][hp][wp] -> uint8 RGB [h][w][3] of the top-left h x w window: clip to [0,1], x255, round half to even
+// (np.round), as float_to_uint8 of LHBDC/decode_B.py:35-38,122-123.
+__global__ void k_f32nchw_to_u8hwc(const float *__restrict__ src, int hp, int wp, uint8_t *__restrict__ dst, int h, int w)
+{
+    const long long total = (long long)h * w * 3;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        const long long t = i / 3;
+        const int x = (int)(t % w), y = (int)(t / w);
+        const float v = fminf(fmaxf(src[((long long)c * hp + y) * wp + x], 0.0f), 1.0f) * 255.0f;
+        dst[i] = (uint8_t)rintf(v);
+    }
+}
+
+extern "C" int vc_u8hwc_to_f32nchw_pad(vc_stream s, const uint8_t *src_hwc, int h, int w, float *dst_nchw, int hp, int wp)
+{
+    if (!src_hwc || !dst_nchw || h < 1 || w < 1 || hp < h || wp < w || hp - h >= h || wp - w >= w) return VC_EINVAL;
+    hipLaunchKernelGGL(k_u8hwc_to_f32nchw_pad, dim3(ew_grid(3ll * hp * wp, 256)), dim3(256), 0, as_stream(s), src_hwc, h, w, dst_nchw, hp, wp);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+extern "C" int vc_f32nchw_to_u8hwc(vc_stream s, const float *src_nchw, int hp, int wp, uint8_t *dst_hwc, int h, int w)
+{
+    if (!src_nchw || !dst_hwc || h < 1 || w < 1 || hp < h || wp < w) return VC_EINVAL;
+    hipLaunchKernelGGL(k_f32nchw_to_u8hwc, dim3(ew_grid((long long)h * w * 3, 256)), dim3(256), 0, as_stream(s), src_nchw, hp, wp, dst_hwc, h, w);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
 extern "C" int vc_nchw_to_nhwc(vc_stream s, const float *src, vc_view dst)
 {
     if (!src || !dst.p) return VC_EINVAL;

@@ -114,6 +114,8 @@ def lib():
     sig("vc_conv2d_nhwc", ci, vp, ctypes.POINTER(ConvDesc))
     sig("vc_nchw_to_nhwc", ci, vp, vp, View)
     sig("vc_nhwc_to_nchw", ci, vp, View, vp)
+    sig("vc_u8hwc_to_f32nchw_pad", ci, vp, vp, ci, ci, vp, ci, ci)
+    sig("vc_f32nchw_to_u8hwc", ci, vp, vp, ci, ci, vp, ci, ci)
     sig("vc_avgpool_reflectpad", ci, vp, View, View, ci, cf)
     sig("vc_maxpool2", ci, vp, View, View)
     sig("vc_upsample_bilinear", ci, vp, View, View, ci, ci, cf)
@@ -155,7 +157,7 @@ EXPORTED_SYMBOLS = [
     "vc_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
     "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
     "vc_conv_pack_weights_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
-    "vc_nhwc_to_nchw", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_channel_scale", "vc_warp",
+    "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
@@ -240,6 +242,32 @@ def nchw_to_nhwc(x):
 def nhwc_to_nchw(t):
     out = torch.empty((t.n, t.c, t.h, t.w), dtype=torch.float32, device=t.buf.device)
     check(lib().vc_nhwc_to_nchw(stream(), t.view(), out.data_ptr()), "vc_nhwc_to_nchw")
+    return out
+
+
+def frame_from_uint8(u8_hwc, hp=None, wp=None, out=None):
+    """uint8 RGB [h,w,3] CUDA tensor -> padded fp32 NCHW [1,3,hp,wp] (x/255, reflection pad to multiples of 64):
+    ``process_frame`` of LHBDC/encode_B.py:58-64 without a torch operator."""
+    h, w, c = u8_hwc.shape
+    if c != 3 or u8_hwc.dtype != torch.uint8 or not u8_hwc.is_cuda or not u8_hwc.is_contiguous():
+        raise VcError("frame_from_uint8 takes a contiguous uint8 [h,w,3] CUDA tensor")
+    hp = hp or h + (64 - h % 64) % 64
+    wp = wp or w + (64 - w % 64) % 64
+    if out is None:
+        out = torch.empty((1, 3, hp, wp), dtype=torch.float32, device=u8_hwc.device)
+    check(lib().vc_u8hwc_to_f32nchw_pad(stream(), u8_hwc.data_ptr(), h, w, out.data_ptr(), hp, wp), "vc_u8hwc_to_f32nchw_pad")
+    return out
+
+
+def frame_to_uint8(x_nchw, h, w):
+    """fp32 NCHW [1,3,hp,wp] CUDA frame -> uint8 RGB [h,w,3] of its top-left window (``float_to_uint8`` + crop of
+    LHBDC/decode_B.py:35-38,122-123)."""
+    _, c, hp, wp = x_nchw.shape
+    if c != 3 or x_nchw.dtype != torch.float32 or not x_nchw.is_cuda:
+        raise VcError("frame_to_uint8 takes an fp32 [1,3,hp,wp] CUDA tensor")
+    x_nchw = x_nchw.contiguous()
+    out = torch.empty((h, w, 3), dtype=torch.uint8, device=x_nchw.device)
+    check(lib().vc_f32nchw_to_u8hwc(stream(), x_nchw.data_ptr(), hp, wp, out.data_ptr(), h, w), "vc_f32nchw_to_u8hwc")
     return out
 
 
