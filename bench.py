@@ -52,9 +52,10 @@ def kernel_source_stamp():
     return h.hexdigest()[:16]
 
 
-def synthetic_gop(seed, gop_index, device, frames_per_gop=9, hw=None):
+def synthetic_gop(seed, gop_index, device, frames_per_gop=9, hw=None, as_uint8=False):
     """Config 2: band-limited noise texture (Gaussian sigma=3 px) + global translation (1.5,0.75) px per
-    frame + 2 % additive noise, quantised to uint8, then /255 and reflection-padded to 1088x1920."""
+    frame + 2 % additive noise, quantised to uint8, then /255 and reflection-padded to 1088x1920.
+    ``as_uint8``: the 8-bit RGB [h,w,3] frames themselves (what --data writes to PNG files)."""
     from scipy import ndimage
     H, W = hw if hw is not None else (1080, 1920)
     rng = np.random.default_rng(seed)
@@ -70,6 +71,9 @@ def synthetic_gop(seed, gop_index, device, frames_per_gop=9, hw=None):
         f = shifted[:, margin:margin + H, margin:margin + W]
         noise = np.random.default_rng(seed + 1 + tt).standard_normal(f.shape).astype(np.float32) * 0.02
         u8 = np.clip(np.round((f + noise) * 255.0), 0, 255).astype(np.uint8)
+        if as_uint8:
+            frames.append(np.ascontiguousarray(u8.transpose(1, 2, 0)))
+            continue
         x = torch.from_numpy(u8.astype(np.float32) / 255.0)[None]
         x = torch.nn.functional.pad(x, (0, (64 - W % 64) % 64, 0, (64 - H % 64) % 64), mode="reflect")
         frames.append(x.to(device))
@@ -174,6 +178,10 @@ def parse_args():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="strong = BASELINE configs[3]: a fixed multi-sequence test set GOP-sharded over the ranks (LHBDC)")
     ap.add_argument("--sequences", type=int, default=7, help="--scaling strong: sequences in the test set (UVG: 7)")
+    ap.add_argument("--seconds-per-step", type=float, default=None,
+                    help="--scaling strong: size the test set (frames per sequence, whole GOP-8s) so that ONE step takes about this "
+                         "long at the given number of GPUs (assuming ~17 frames/s per GPU) instead of using --frames-per-sequence; "
+                         "with the driver's --steps 20 --warmup 5 a value of 10 keeps the run inside a few minutes")
     ap.add_argument("--frames-per-sequence", type=int, default=593,
                     help="--scaling strong: frames per sequence (UVG: 600 -> 74 GOP-8s = 593 frames coded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,6 +189,11 @@ def parse_args():
                     help="LHBDC / Flex-Rate: independent GOPs coded per step and GPU with their hierarchy levels batched together "
                          "(default at 1080p: 4 / 2; 1 at 2160p)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--data", default=None, metavar="DIR",
+                    help="weak scaling, LHBDC: stream the frames of every step from PNG files through vcamd.data.SequenceReader "
+                         "(decode workers -> pinned ring -> async H2D) instead of coding device-resident tensors; the synthetic clip "
+                         "is written to DIR/<rank>/seq00/*.png first when it is not there yet")
+    ap.add_argument("--data-workers", type=int, default=8)
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel event timing table here (json)")
     return ap.parse_args()
 
@@ -248,6 +261,9 @@ def main():
         i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
         i_model.load_state_dict(seeded_state_dict(i_model.state_dict(), seed=4321, conv_gain=0.8))
         i_model = i_model.to(dev).eval()
+        if args.seconds_per_step:
+            per_seq = 17.0 * world * args.seconds_per_step / args.sequences
+            args.frames_per_sequence = 8 * max(1, int(round((per_seq - 1) / 8))) + 1
         plan = vgop.workload_plan([args.frames_per_sequence] * args.sequences)
         lo, hi = vgop.shard_gops(len(plan), world, rank)
         data = SyntheticTestSet(args.sequences, args.frames_per_sequence, (H, W), dev)
@@ -283,11 +299,34 @@ def main():
         else:
             runners = [None if args.no_graph else vgop.GopGraph(model, H, W, gops=G)]
         counter = [0]
+        reader = None
+        if args.data:
+            if is_flex or is_icip:
+                raise SystemExit("--data streams the LHBDC GOP-8 workload")
+            from vcamd import data as vdata
+            root = os.path.join(args.data, f"rank{rank}")
+            seq = os.path.join(root, "seq00")
+            if not (os.path.isdir(seq) and len(os.listdir(seq)) == 9 * G):
+                clip = []
+                for g in range(G):
+                    clip += synthetic_gop(1234, rank * G + g, dev, 9, (H, W), as_uint8=True)
+                vdata.write_synthetic_sequences(root, [clip], ["seq00"])
+            # the G GOPs of a step are 9 consecutive files each; every step asks for all of them again, in order
+            reader = vdata.SequenceReader(root, ["seq00"], gop_size=8, test_size=0, device=dev, workers=args.data_workers,
+                                          depth=2 * 9 * G)
+            keys = [(0, i) for i in range(9 * G)]
+            reader.prefetch(keys)
 
         def step(keep):
             i = counter[0] % len(runners)
             counter[0] += 1
             recs = records if keep else None
+            if reader is not None:
+                # decoded straight into the GOP runner's static input tensors once they exist (no extra device copy)
+                static = runners[i].static_in if (runners[i] is not None and getattr(runners[i], "static_in", None)) else [None] * len(keys)
+                for j, k in enumerate(keys):
+                    frames[j] = reader.load_frame(*k, out=static[j])
+                reader.prefetch(keys)                       # the next step's frames decode while this step's GOPs are coded
             if runners[i] is not None:
                 runners[i].code(frames, gop_index=rank * G, records=recs)
             elif is_icip:
@@ -310,12 +349,24 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i == args.steps - 1)
+        torch.cuda.synchronize()
+        t_coded = time.perf_counter() - t0              # this rank's own work, before it meets the others
         rows = vgop.gather_records(records, dev, width=7 if strong else 6)      # the only exchange: final R-D gather (RCCL)
+        t_gathered = time.perf_counter() - t0
         barrier()
         elapsed = time.perf_counter() - t0
+    rank_stats = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        cdev = dev if backend == "nccl" else "cpu"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # per-rank view of the timed region (after the clock has stopped): a sub-linear point must be explainable from the line
+        mine = torch.tensor([t_coded, t_gathered - t_coded, elapsed, float(len(records))], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().tolist()
+        rank_stats = {"coded_s": [round(r[0], 4) for r in allr], "gather_s": [round(r[1], 4) for r in allr],
+                      "elapsed_s": [round(r[2], 4) for r in allr], "records_last_step": [int(r[3]) for r in allr]}
         elapsed = float(tmax.item())
 
     coded_frames = (frames_total if strong else per_gop * G * world) * args.steps
@@ -360,8 +411,28 @@ def main():
                    "resolution": f"{W}x{H}", "precision": args.precision, "parallelism": f"gop-shard x{world}",
                    "launch": "eager" if args.no_graph else "hip-graph per GOP pass"},
     }
+    if not strong and reader is not None:
+        st = reader.stats
+        n = max(1, st["frames"])
+        result["data"] += f"; frames streamed from PNG files ({args.data}) through vcamd.data.SequenceReader"
+        result["ingest"] = {"source": "png", "frames_loaded": st["frames"], "frames_per_step": len(keys), "workers": args.data_workers,
+                            "decode_ms_per_frame_worker": round(1000.0 * st["decode_s"] / n, 2),
+                            "h2d_ms_per_frame": round(1000.0 * st["h2d_s"] / n, 3),
+                            "consumer_wait_ms_per_step": round(1000.0 * st["wait_s"] / max(1, counter[0] + n_warm), 2),
+                            "what": "every step loads its 9*G frames from disk (decode threads -> pinned ring -> async H2D on a side "
+                                    "stream -> uint8->fp32 pad kernel); the wait is the time load_frame blocked the coding thread, "
+                                    "warm-up steps included"}
+        reader.close()
     if world > 1:
         result["rccl_ranks" if backend == "nccl" else f"{backend}_ranks"] = world
+        per_rank_frames = ([len({(v, i) for v, _, idxs in plan[a:b] for i in idxs}) for a, b in
+                            (vgop.shard_gops(len(plan), world, r) for r in range(world))] if strong else [per_gop * G] * world)
+        result["ranks"] = {"backend": backend, "world": world,
+                           "frames_per_step_per_rank": per_rank_frames,          # (strong: a shard re-codes its first boundary I-frame)
+                           "coded_s_min": min(rank_stats["coded_s"]), "coded_s_max": max(rank_stats["coded_s"]),
+                           "gather_s_max": max(rank_stats["gather_s"]), **rank_stats,
+                           "what": "coded_s = this rank's steps incl. its final device sync; gather_s = R-D record all-gather (waits for the "
+                                   "slowest rank); elapsed_s = up to the closing barrier; value uses the MAX elapsed over ranks"}
     result["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)   # of 288 GB, this rank, graphs included
     if strong:
         table = vgop.RdTable()

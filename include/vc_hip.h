@@ -148,6 +148,8 @@ int vc_maxpool2(vc_stream s, vc_view in, vc_view out);
 int vc_upsample_bilinear(vc_stream s, vc_view in, vc_view out, int factor, int align_corners, float scale);
 /* out = alpha*a + beta*b (b may be NULL-pointer view with p==0) -- m.py:52,56-59,71 */
 int vc_axpby(vc_stream s, vc_view a, vc_view b, vc_view out, float alpha, float beta);
+/* out = clamp(a, 0, 1) on views: a decoded frame before it serves as a reference (ICIP2024/src/test.py:94, src/utils.py:194) */
+int vc_clamp01(vc_stream s, vc_view a, vc_view out);
 /* out[...,c] = gain[c] * a[...,c] -- Flex Gain_Module.forward (Flex.../b_model/layers.py:54-73) */
 int vc_channel_scale(vc_stream s, vc_view a, const float *gain, vc_view out);
 

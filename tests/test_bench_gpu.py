@@ -37,3 +37,42 @@ def test_self_launched_two_rank_strong_run_equals_single_rank():
     assert one["quality"]["frames"] == two["quality"]["frames"] == 34
     assert one["quality"] == two["quality"]                    # bpp, PSNR and the per-frame-type table: identical
     assert two["config"]["parallelism"] == "gop-shard x2"
+    # the multi-rank line explains itself: per-rank work, timings of the coding loop and of the R-D gather
+    r = two["ranks"]
+    assert r["world"] == 2 and r["backend"] == "gloo" and len(r["coded_s"]) == len(r["gather_s"]) == len(r["elapsed_s"]) == 2
+    # 2 sequences x 2 GOPs: each rank codes one sequence (17 frames); a shard that started inside a sequence would add one I-frame
+    assert r["frames_per_step_per_rank"] == [17, 17] and sum(r["records_last_step"]) == 34
+    assert 0 < r["coded_s_min"] <= r["coded_s_max"] <= two["ms_per_step"] / 1000.0 * two["steps"] + 1e-6
+    assert "ranks" not in one
+
+
+def test_strong_run_sized_by_seconds_per_step():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", "strong", "--sequences", "2", "--seconds-per-step", "1.5",
+           "--steps", "1", "--warmup", "0", "--gops-per-step", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    # 17 frames/s x 1.5 s / 2 sequences = 12.75 frames -> whole GOP-8s: 17 frames per sequence
+    assert line["quality"]["frames"] == 34 and line["config"]["frames_per_step"] == 34
+
+
+def test_bench_streams_frames_from_png_files(tmp_path):
+    """--data: the frames of every step come from PNG files through vcamd.data.SequenceReader; same R-D numbers as the
+    device-resident run (the files hold exactly the synthetic clip), ingest statistics in the line."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--gops-per-step", "1", "--no-cpu-baseline"]
+
+    def run(extra):
+        out = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    resident = run([])
+    streamed = run(["--data", str(tmp_path), "--data-workers", "4"])
+    assert streamed["ingest"]["frames_per_step"] == 9 and streamed["ingest"]["frames_loaded"] >= 27
+    assert streamed["quality"]["b_frames"] == resident["quality"]["b_frames"] == 7
+    assert streamed["quality"]["bpp_estimated"] == resident["quality"]["bpp_estimated"]
+    assert streamed["quality"]["psnr_db"] == resident["quality"]["psnr_db"]

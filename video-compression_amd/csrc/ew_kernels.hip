@@ -306,6 +306,30 @@ extern "C" int vc_axpby(vc_stream s, vc_view a, vc_view b, vc_view out, float al
     return VC_OK;
 }
 
+__global__ void k_clamp01(vc_view a, vc_view out)
+{
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        long long t = i / out.c;
+        const int x = (int)(t % out.w); t /= out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        out.p[view_off(out, n, y, x) + c] = fminf(fmaxf(a.p[view_off(a, n, y, x) + c], 0.0f), 1.0f);
+    }
+}
+
+// out = clamp(a, 0, 1): decoded frames before they serve as references (ICIP2024/src/test.py:94 `torch.clamp(x_hat, 0, 1)`)
+extern "C" int vc_clamp01(vc_stream s, vc_view a, vc_view out)
+{
+    if (!a.p || !out.p) return VC_EINVAL;
+    if (a.h < out.h || a.w < out.w || a.c < out.c || a.n != out.n) return VC_EINVAL;
+    const long long total = (long long)out.n * out.h * out.w * out.c;
+    hipLaunchKernelGGL(k_clamp01, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, out);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
 __global__ void k_channel_scale(vc_view a, const float *__restrict__ gain, vc_view out)
 {
     const long long total = (long long)out.n * out.h * out.w * out.c;

@@ -8,6 +8,8 @@ the only exchange is the final gather of per-frame rate-distortion records (SURV
 """
 import math
 
+import numpy as np
+
 import torch
 
 CODING_ORDER = [0, 8, 4, 2, 1, 3, 6, 5, 7]                     # testing.py:70
@@ -177,13 +179,11 @@ def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None
     from .layers import BitCounter
     ratios = (1, 2, 4, 8, 16)
     decoded, picked, feats, stats = {0: dec_first, 16: dec_last}, {}, {}, {}
-    clamped = {0: dec_first, 16: dec_last}
-    nhwc = {}
+    # references live as channels-last windows (clamped to [0,1] once, by vc_clamp01): no torch operator touches a pixel here
+    nhwc = {0: hip.nchw_to_nhwc(dec_first), 16: hip.nchw_to_nhwc(dec_last)}
 
     def features(o):
         if o not in feats:
-            if o not in nhwc:
-                nhwc[o] = hip.nchw_to_nhwc(clamped[o])
             feats[o] = model.feature_extractor.run(nhwc[o])
         return feats[o]
 
@@ -193,23 +193,28 @@ def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None
         orders = [g[0] for g in group]
         s1, s2 = group[0][3], group[0][4]
         n = len(group)
-        cur = gop[orders[0]] if n == 1 else torch.cat([gop[o] for o in orders], 0)
-        ref1 = clamped[group[0][1]] if n == 1 else torch.cat([clamped[g[1]] for g in group], 0)
-        ref2 = clamped[group[0][2]] if n == 1 else torch.cat([clamped[g[2]] for g in group], 0)
-        t1, t2, tc = hip.nchw_to_nhwc(ref1), hip.nchw_to_nhwc(ref2), hip.nchw_to_nhwc(cur)
+        tc = hip.nchw_frames_to_nhwc([gop[o] for o in orders])
+        t1 = hip.stack_images([nhwc[g[1]] for g in group])
+        t2 = hip.stack_images([nhwc[g[2]] for g in group])
         flow, dr = None, down_ratio
         if search == "device":
             flow, choice, _ = model.search_flow_t(tc, t1, t2, s1, s2, ratios)
             for i, o in enumerate(orders):
                 picked[o] = choice[i]
         elif search == "host":
-            mses = []
-            for cand in ratios:
-                pred = hip.nhwc_to_nchw(model.prediction_flowonly_t(tc, t1, t2, s1, s2, cand))
-                mses.append(torch.mean((torch.clamp(pred, 0, 1) - cur) ** 2))
-            psnrs = (10 * torch.log10(1.0 / torch.stack(mses))).cpu()
+            # the reference loop: five candidate predictions, five MSEs compared on the host (one sync per frame)
+            L, slots = hip.lib(), hip.lib().vc_bits_slots()
+            partial = torch.empty(len(ratios) * slots, dtype=torch.float64, device=tc.buf.device)
+            sse = torch.empty(len(ratios), dtype=torch.float64, device=tc.buf.device)
+            for i, cand in enumerate(ratios):
+                pred = model.prediction_flowonly_t(tc, t1, t2, s1, s2, cand)
+                hip.check(L.vc_sse_clamp01(hip.stream(), pred.view(), tc.view(), partial.data_ptr() + 8 * i * slots, slots), "vc_sse_clamp01")
+            hip.check(L.vc_bits_reduce(hip.stream(), partial.data_ptr(), slots, len(ratios), sse.data_ptr()), "vc_bits_reduce")
+            count = float(tc.n * tc.h * tc.w * tc.c)
             best, dr = 0.0, None
-            for cand, p in zip(ratios, psnrs.tolist()):     # strict '>' keeps the first maximum, like the reference
+            for cand, e in zip(ratios, sse.cpu().tolist()):     # strict '>' keeps the first maximum, like the reference
+                # (float32 like the reference's tensor arithmetic: 10 * log10(1 / mean))
+                p = float(np.float32(10.0) * np.log10(np.float32(1.0) / np.float32(e / count))) if e > 0 else math.inf
                 if p > best:
                     best, dr = p, cand
             if dr is None:
@@ -220,18 +225,20 @@ def code_gop_icip2024(model, gop, dec_first, dec_last, h, w, level, records=None
                 picked[o] = dr
         f1 = [features(g[1]) for g in group] if cache_features else None
         f2 = [features(g[2]) for g in group] if cache_features else None
-        bits = BitCounter(cur.device, max_rows=12 * n)
-        x_hat = hip.nhwc_to_nchw(model.forward_device(t1, t2, s1, s2, tc, level, dr, bits, flow=flow, feats1=f1, feats2=f2))
+        bits = BitCounter(tc.buf.device, max_rows=12 * n)
+        y = model.forward_device(t1, t2, s1, s2, tc, level, dr, bits, flow=flow, feats1=f1, feats2=f2)
+        x_hat = hip.nhwc_to_nchw(y)
         sizes = bits.totals().view(12, n).sum(0)
-        cl = torch.clamp(x_hat, 0, 1)
-        is_ref = cache_features and ICIP_LEVELS_16[orders[0]] < 3     # the deepest level is never referenced
+        is_ref = ICIP_LEVELS_16[orders[0]] < 3     # the deepest level is never referenced
         if is_ref:
-            batch_nhwc = hip.nchw_to_nhwc(cl)
-            batch_feats = model.feature_extractor.run(batch_nhwc)
+            cl = hip.clamp01(y)
+            batch_feats = model.feature_extractor.run(cl) if cache_features else None
         for i, o in enumerate(orders):
-            decoded[o], clamped[o], stats[o] = x_hat[i:i + 1], cl[i:i + 1], sizes[i]
+            decoded[o], stats[o] = x_hat[i:i + 1], sizes[i]
             if is_ref:
-                feats[o] = [f.images(i, i + 1) for f in batch_feats]
+                nhwc[o] = cl.images(i, i + 1)
+                if cache_features:
+                    feats[o] = [f.images(i, i + 1) for f in batch_feats]
     if records is not None:
         for o in ICIP_ORDER_16[1:]:
             records.append((video, gop_index * 16 + o, ICIP_LEVELS_16[o], psnr_uint8(decoded[o], gop[o], h, w), stats[o],
@@ -279,7 +286,7 @@ def code_sequence_icip2024(model, i_models, load_frame, n_frames, level, h=1080,
             dec = hip.nhwc_to_nchw(model.forward_device(t1, t2, s1, s2, tc, level, dr, bits, flow=flow, feats1=f1, feats2=f2))
         psnr[order] = psnr_uint8(dec, cur, h, w)
         size[order] = bits.totals().sum() / float(h * w)
-        buffer, buffer_order = icip2024.update_buffer(buffer, buffer_order, torch.clamp(dec, 0, 1), order)
+        buffer, buffer_order = icip2024.update_buffer(buffer, buffer_order, hip.clamp01_nchw(dec), order)
         feats = {o: f for o, f in feats.items() if o in buffer_order}     # frames that left the buffer can go
     return torch.stack(psnr).tolist(), torch.stack(size).tolist()
 

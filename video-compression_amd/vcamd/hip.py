@@ -120,6 +120,7 @@ def lib():
     sig("vc_maxpool2", ci, vp, View, View)
     sig("vc_upsample_bilinear", ci, vp, View, View, ci, ci, cf)
     sig("vc_axpby", ci, vp, View, View, View, cf, cf)
+    sig("vc_clamp01", ci, vp, View, View)
     sig("vc_channel_scale", ci, vp, View, vp, View)
     sig("vc_warp", ci, vp, ci, View, View, View)
     sig("vc_spynet_preprocess", ci, vp, vp, View)
@@ -157,7 +158,7 @@ EXPORTED_SYMBOLS = [
     "vc_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
     "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
     "vc_conv_pack_weights_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
-    "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_channel_scale", "vc_warp",
+    "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
@@ -475,6 +476,39 @@ def axpby(a, b, alpha=1.0, beta=1.0, out=None):
         out = T.empty(a.n, a.h, a.w, a.c, a.buf.device)
     check(lib().vc_axpby(stream(), a.view(), b.view() if b is not None else NULL_VIEW, out.view(), alpha, beta),
           "vc_axpby")
+    return out
+
+
+def clamp01(x, out=None):
+    """clamp(x, 0, 1) of a channels-last window (``torch.clamp(x_hat, 0, 1)`` of ICIP2024/src/test.py:94 on the device path)."""
+    if out is None:
+        out = T.empty(x.n, x.h, x.w, x.c, x.buf.device)
+    check(lib().vc_clamp01(stream(), x.view(), out.view()), "vc_clamp01")
+    return out
+
+
+def clamp01_nchw(x):
+    """The same for a contiguous fp32 CUDA tensor of any shape (a decoded NCHW frame entering the reference buffer)."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    n = x.numel()
+    check(lib().vc_clamp01(stream(), View(x.data_ptr(), 1, 1, n, 1, n, n, 1), View(out.data_ptr(), 1, 1, n, 1, n, n, 1)), "vc_clamp01")
+    return out
+
+
+def stack_images(items, out=None):
+    """Windows of k images each -> ONE batched window, image by image (the batch of a level pass assembled by the
+    layout kernel: no torch.cat of the frames)."""
+    if len(items) == 1 and out is None:
+        return items[0]
+    total = sum(t.n for t in items)
+    t0 = items[0]
+    if out is None:
+        out = T.empty(total, t0.h, t0.w, t0.c, t0.buf.device)
+    i = 0
+    for t in items:
+        check(lib().vc_axpby(stream(), t.view(), NULL_VIEW, out.images(i, i + t.n).view(), 1.0, 0.0), "vc_axpby")
+        i += t.n
     return out
 
 

@@ -903,13 +903,21 @@ def get_best_down_ratio_prediction(model, xref1, xref2, scale1, scale2, xcur, le
     The five candidate predictions are computed on the device; the five MSE scalars are compared on the host."""
     _require_frames(xref1, xref2, xcur)
     c, r1, r2 = hip.nchw_to_nhwc(xcur), hip.nchw_to_nhwc(xref1), hip.nchw_to_nhwc(xref2)
+    L, ratios = hip.lib(), (1, 2, 4, 8, 16)
+    slots = L.vc_bits_slots()
+    partial = torch.empty(len(ratios) * slots, dtype=torch.float64, device=xcur.device)
+    sse = torch.empty(len(ratios), dtype=torch.float64, device=xcur.device)
+    for i, down_ratio in enumerate(ratios):       # squared error of the clamped prediction: vc_sse_clamp01, no torch operator on pixels
+        pred = model.prediction_flowonly_t(c, r1, r2, scale1, scale2, down_ratio)
+        hip.check(L.vc_sse_clamp01(hip.stream(), pred.view(), c.view(), partial.data_ptr() + 8 * i * slots, slots), "vc_sse_clamp01")
+    hip.check(L.vc_bits_reduce(hip.stream(), partial.data_ptr(), slots, len(ratios), sse.data_ptr()), "vc_bits_reduce")
+    count = float(xcur.numel())
     best, best_ratio = 0.0, None
-    for down_ratio in (1, 2, 4, 8, 16):
-        pred = hip.nhwc_to_nchw(model.prediction_flowonly_t(c, r1, r2, scale1, scale2, down_ratio))
-        psnr = 10 * torch.log10(1.0 / torch.mean((torch.clamp(pred, 0, 1) - xcur) ** 2))
+    for down_ratio, e in zip(ratios, sse.cpu().tolist()):
+        psnr = float(np.float32(10.0) * np.log10(np.float32(1.0) / np.float32(e / count))) if e > 0 else float("inf")
         if psnr > best:
             best, best_ratio = psnr, down_ratio
-    return best_ratio, best
+    return best_ratio, torch.tensor(best, dtype=torch.float32)        # (a tensor, as opt_helpers.py:51 returns one)
 
 
 # ------------------------------------------------------------------------------------------------
