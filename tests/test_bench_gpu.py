@@ -55,8 +55,8 @@ def test_strong_run_sized_by_seconds_per_step():
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    # 17 frames/s x 1.5 s / 2 sequences = 12.75 frames -> whole GOP-8s: 17 frames per sequence
-    assert line["quality"]["frames"] == 34 and line["config"]["frames_per_step"] == 34
+    # 17 frames/s x 1.5 s / 2 sequences = 12.75 frames -> the nearest whole number of GOP-8s: 9 frames per sequence
+    assert line["quality"]["frames"] == 18 and line["config"]["frames_per_step"] == 18
 
 
 def test_bench_streams_frames_from_png_files(tmp_path):

@@ -663,7 +663,8 @@ def test_conv2d_random_sweep_every_candidate_configuration(dev):
             try:
                 outs.append((cfg, hip.nhwc_to_nchw(pc(xt, act=code, slope=slope, res=rt))))
             except hip.VcError:
-                assert cfg == 6          # only the streaming 1x1 kernel may decline a call it is not eligible for
+                # only the streaming 1x1 kernel and the LDS-DMA pipeline (half-precision inputs only) may decline a call
+                assert cfg in (6, 8)
         assert outs, f"no configuration ran for case {i}"
         what = f"sweep {i}: {cin}->{cout} k{k} s{stride} @{n}x{h}x{w} {act}{' +res' if with_res else ''}"
         _close(outs[0][1], ref, 2e-5, what)
@@ -696,7 +697,7 @@ def test_conv2d_half_precision_output_equals_rounded_fp32_output(dev):
                     half = hip.T.empty(n, h, w, cout, dev, "f16")
                     pc(x, out=half, act=hip.ACT_LRELU, res=res)
                 except hip.VcError:
-                    assert cfg == 6
+                    assert cfg in (6, 8)     # (the LDS-DMA pipeline takes half-precision inputs only: fp32 here)
                     continue
                 torch.cuda.synchronize()
                 assert torch.equal(full.buf.view(n, h, w, cout).to(torch.float16), half.buf.view(n, h, w, cout)), \

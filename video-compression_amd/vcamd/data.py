@@ -293,7 +293,11 @@ class SequenceReader:
         return self.load_frame(*key)
 
     def close(self):
+        """Stops the workers (queued frames are dropped) and waits for them: no thread of the reader outlives it."""
         self.closed = True
+        for t in self.threads:
+            if t is not threading.current_thread():
+                t.join(timeout=5.0)
 
     def __enter__(self):
         return self
