@@ -486,6 +486,17 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
         product_frame()
         table = hip.timer.table()
         hip.timer = None
+    # memory-bound kernels (warp, resampling, SPyNet level input, Gaussian conditional): achieved GB/s of the algorithmic
+    # traffic against the HBM peak, from the same HIP events (north star: "rocprof HBM GB/s ... against gfx950 peak")
+    hbm = {k[4:]: v for k, v in table.items() if k.startswith("hbm ")}
+    table = {k: v for k, v in table.items() if not k.startswith("hbm ")}
+    result["hbm_kernels"] = {
+        k: {"launches": v["launches"], "avg_us": round(1000.0 * v["ms"] / v["launches"], 2),
+            "algorithmic_mb_per_launch": round(v["bytes"] / v["launches"] / 1e6, 2),
+            "achieved_gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+            "frac_of_hbm_peak": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 3)}
+        for k, v in sorted(hbm.items(), key=lambda kv: -kv[1]["ms"])[:8] if v["ms"] > 0}
+    result["hbm_kernels_ms_per_frame"] = round(sum(v["ms"] for v in hbm.values()), 3)
     total_ms = sum(v["ms"] for v in table.values())
     ranked = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
     key, dom = ranked[0]
@@ -552,7 +563,11 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
         result["conv_engine"]["timed_region_tflops"] = all_flops / 1e12 * result["value"]
     if args.kernel_table:
         with open(args.kernel_table, "w") as f:
-            json.dump({k: v for k, v in ranked}, f, indent=1)
+            rows = {k: dict(v, avg_ms=v["ms"] / v["launches"], tflops=v["flops"] / max(v["ms"], 1e-9) / 1e9,
+                            gbps=v["bytes"] / max(v["ms"], 1e-9) / 1e6, share_of_conv_time=v["ms"] / total_ms) for k, v in ranked}
+            json.dump({"what": "one B-frame launched eagerly with HIP events around every launch (python bench.py --kernel-table ...)",
+                       "model": args.model, "precision": args.precision, "resolution": args.resolution,
+                       "conv_ms_per_frame": total_ms, "convolutions": rows, "hbm_kernels": result["hbm_kernels"]}, f, indent=1)
 
     if not is_flex and not is_icip and args.resolution == "1080p" and args.scaling == "weak":
         # ---- whole GOP as testing.py codes it: 1 I-frame (mbt2018_mean q7 architecture) + 7 B-frames ----

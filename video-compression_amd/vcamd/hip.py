@@ -83,6 +83,15 @@ class KernelTimer:
 timer = None  # set to a KernelTimer() to collect
 
 
+def timed_hbm(key, nbytes, launch):
+    """Run ``launch`` -- bracketed by HIP events under the key "hbm <key>" while a KernelTimer collects (bench.py's
+    ``hbm_kernels`` block: achieved GB/s of the memory-bound kernels against the HBM peak); ``nbytes`` = algorithmic
+    traffic (every operand read once, the result written once)."""
+    if timer is None:
+        return launch()
+    return timer.bracket("hbm " + key, 0.0, launch, nbytes)
+
+
 def lib():
     """Load libvc_hip.so once; raise (never fall back) when it is absent."""
     global _lib
@@ -466,8 +475,9 @@ def maxpool2(x):
 def upsample_bilinear(x, factor, align_corners=False, scale=1.0, out=None):
     if out is None:
         out = T.empty(x.n, x.h * factor, x.w * factor, x.c, x.buf.device)
-    check(lib().vc_upsample_bilinear(stream(), x.view(), out.view(), factor, int(align_corners), scale),
-          "vc_upsample_bilinear")
+    timed_hbm(f"k_upsample_bilinear x{factor} c{x.c} @{x.n}x{x.h}x{x.w}", 4.0 * x.n * x.c * (x.h * x.w + out.h * out.w),
+              lambda: check(lib().vc_upsample_bilinear(stream(), x.view(), out.view(), factor, int(align_corners), scale),
+                            "vc_upsample_bilinear"))
     return out
 
 
@@ -515,7 +525,8 @@ def stack_images(items, out=None):
 def warp(convention, img, flow, out=None):
     if out is None:
         out = T.empty(img.n, flow.h, flow.w, img.c, img.buf.device)
-    check(lib().vc_warp(stream(), convention, img.view(), flow.view(), out.view()), "vc_warp")
+    timed_hbm(f"k_warp W{convention} c{img.c} @{img.n}x{img.h}x{img.w}", 4.0 * img.n * img.h * img.w * (2 * img.c + 2),
+              lambda: check(lib().vc_warp(stream(), convention, img.view(), flow.view(), out.view()), "vc_warp"))
     return out
 
 

@@ -513,11 +513,15 @@ class MeanScaleHyperprior(_Prepared):
             trace.update({"scales": scales, "means": means})
         y_hat = T.empty(y.n, y.h, y.w, y.c, y.buf.device)
         for i in range(y.n):
-            hip.check(L.vc_gc_forward(hip.stream(), y.images(i, i + 1).view(), scales.images(i, i + 1).view(),
-                                      means.images(i, i + 1).view(), None, None if ig is None else ig.data_ptr(),
-                                      y_hat.images(i, i + 1).view(), rows[i][0], bits.slots,
-                                      None, None if sym_y is None else sym_y[i].data_ptr(), None, None, 0,
-                                      None if lik_y is None else lik_y[i].data_ptr()), "vc_gc_forward")
+            # (y, scales, means read + y_hat written; + symbols / likelihoods when requested)
+            hip.timed_hbm(f"k_gc_forward c{y.c} @1x{y.h}x{y.w}",
+                          4.0 * y.h * y.w * y.c * (4 + (sym_y is not None) + (lik_y is not None)),
+                          lambda i=i: hip.check(L.vc_gc_forward(
+                              hip.stream(), y.images(i, i + 1).view(), scales.images(i, i + 1).view(),
+                              means.images(i, i + 1).view(), None, None if ig is None else ig.data_ptr(),
+                              y_hat.images(i, i + 1).view(), rows[i][0], bits.slots,
+                              None, None if sym_y is None else sym_y[i].data_ptr(), None, None, 0,
+                              None if lik_y is None else lik_y[i].data_ptr()), "vc_gc_forward"))
         return run_sequential(self.g_s, y_hat, self._cache["g_s"])
 
     def _scale_table_dev(self):

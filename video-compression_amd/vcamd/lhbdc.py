@@ -108,9 +108,12 @@ class Network(_Prepared):
             dev = f1.buf.device
             feat = T.empty(f1.n, f1.h, f1.w, 8, dev)
             up = T.empty(f1.n, f1.h, f1.w, 2, dev)
-            hip.check(L.vc_spynet_level_input(hip.stream(), f1.view(), f2.view(),
-                                              flow.view() if flow is not None else _zero_flow_view(f1),
-                                              feat.view(), up.view()), "vc_spynet_level_input")
+            fv = flow.view() if flow is not None else _zero_flow_view(f1)
+            # algorithmic traffic: both frames read (3 ch each) + coarse flow read (2 ch at 1/4 of the pixels) + 8-ch level input
+            # and 2-ch upsampled flow written
+            hip.timed_hbm(f"k_spynet_level_input @{f1.n}x{f1.h}x{f1.w}", 4.0 * f1.n * f1.h * f1.w * (3 + 3 + 0.5 + 8 + 2),
+                          lambda: hip.check(L.vc_spynet_level_input(hip.stream(), f1.view(), f2.view(), fv, feat.view(), up.view()),
+                                            "vc_spynet_level_input"))
             c = self._convs(lvl)
             # (each intermediate feeds exactly one convolution: on the fp16 path it is kept as half in HBM)
             x = c[0](feat, act=hip.ACT_RELU, out_f16=c[1].half_ok)
