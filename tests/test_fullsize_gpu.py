@@ -209,3 +209,178 @@ def test_flex_1080p_container_roundtrip_properties(dev):
     assert float(res_only.min()) >= 0.0 and float(res_only.max()) <= 1.0
     assert len(blob) == 24 + sum(len(s[0]) for s in (s_mv + s_res))
     assert torch.isfinite(d1).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ICIP2024 FlowGuidedB (BASELINE configs[4]) at BASELINE size against the oracle
+# reference: ICIP2024/src/model/m.py:181-260 (forward), src/opt_helpers.py:23-51 (flow-resolution search)
+# ---------------------------------------------------------------------------------------------------------------------
+ELIC_GROUPS = (0, 6, 12, 24, 48)          # uneven channel groups of Offset_ELIC / Res_ELIC (compression_bottlenecks.py:229-235) + the remainder
+
+
+def _icip_pair(dev, precision="fp32"):
+    from oracle import icip2024 as oi
+    from vcamd import hip, icip2024
+    from vcamd.seeding import seeded_state_dict
+    hip.set_conv_precision(precision)
+    try:
+        prod = icip2024.FlowGuidedB()
+    finally:
+        hip.set_conv_precision("fp32")
+    sd = seeded_state_dict(prod.state_dict(), seed=1234)
+    prod.load_state_dict(sd)
+    ora = oi.FlowGuidedB().eval()
+    ora.load_state_dict(sd)
+    return ora, prod.to(dev).eval()
+
+
+class _Capture:
+    """Forward hooks on the oracle: inputs of the two ELIC codecs (what the product codecs are teacher-forced with), the
+    gained latents the quantiser rounds (input of h_a / of the factorised prior) and the codecs' outputs."""
+
+    def __init__(self, model):
+        self.model, self.handles, self.data = model, [], {}
+
+    def __enter__(self):
+        for name in ("offset_compressor", "residual_compressor"):
+            codec = getattr(self.model, name)
+            self.handles.append(codec.register_forward_hook(
+                lambda m, args, out, name=name: self.data.setdefault(name, {}).update({"args": args, "out": out})))
+            self.handles.append(codec.h_a.register_forward_pre_hook(
+                lambda m, args, name=name: self.data.setdefault(name, {}).update({"y": args[0]})))
+            self.handles.append(codec.entropy_bottleneck.register_forward_pre_hook(
+                lambda m, args, name=name: self.data.setdefault(name, {}).update({"z": args[0]})))
+        for i, div in enumerate((self.model.offset_diversity_l1, self.model.offset_diversity_l2, self.model.offset_diversity_l3)):
+            self.handles.append(div.register_forward_hook(lambda m, args, out, i=i: self.data.setdefault("aligned", {}).update({i: out})))
+        return self
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+        return False
+
+
+def _group_flips(y_prod, y_ref):
+    """Rounded symbols differing per channel group, and how far from a rounding boundary the oracle's own value is at
+    the flipped positions (a flip must be a boundary case)."""
+    bounds = ELIC_GROUPS + (y_ref.shape[1],)
+    flips, far = [], 0.0
+    for i in range(5):
+        a, b = y_prod[:, bounds[i]:bounds[i + 1]], y_ref[:, bounds[i]:bounds[i + 1]]
+        f = torch.round(a) != torch.round(b)
+        flips.append((int(f.sum()), b.numel()))
+        if f.any():
+            far = max(far, float(((b - torch.floor(b)) - 0.5).abs()[f].max()))
+    return flips, far
+
+
+def _icip_stage_report(dev, ora, prod, frames, level, fp16=False):
+    """One B-frame through both: flow-resolution decision, stage maxima (flow, warped / reference features, aligned features,
+    offset heads) and -- each ELIC codec ALONE on the oracle's inputs -- the symbols per channel group that differ."""
+    from oracle import icip2024 as oi
+    from vcamd import hip, icip2024
+    from vcamd.layers import BitCounter
+    x1, xc, x2 = frames
+    out = {}
+    with torch.no_grad():
+        best_ref, psnr_ref = oi.get_best_down_ratio_prediction(ora, x1, x2, 0.5, 0.5, xc)
+        t1, tc, t2 = (hip.nchw_to_nhwc(x.to(dev)) for x in (x1, xc, x2))
+        flow_t, choice, sse = prod.search_flow_t(tc, t1, t2, 0.5, 0.5)
+        out["down_ratio"] = ((1, 2, 4, 8, 16)[int(choice.item())], best_ref)
+        with _Capture(ora) as cap:
+            ref = ora(x1, x2, 0.5, 0.5, xc, level, best_ref)
+        trace = {}
+        bits = BitCounter(dev, max_rows=12)
+        x_hat = hip.nhwc_to_nchw(prod.forward_device(t1, t2, 0.5, 0.5, tc, level, None, bits, flow=flow_t, trace=trace)).cpu()
+        size = float(bits.totals().sum())
+        out["flow"] = max_abs(nchw(trace["flow"]), ora.estimate_flow(x1, x2, best_ref))
+        off_args, res_args = cap.data["offset_compressor"]["args"], cap.data["residual_compressor"]["args"]
+        # cond = [wref1 | wref2 | fref1 | fref2] per level = arguments 3..5 of the offset codec
+        out["cond"] = [max_abs(nchw(trace["cond"][l]), off_args[3 + l]) for l in range(3)]
+        out["aligned"] = [max_abs(nchw(trace["aligned"][l]), cap.data["aligned"][l]) for l in range(3)]
+        out["offsets"] = [max_abs(nchw(trace["offsets"][l]), cap.data["offset_compressor"]["out"][f"offset{l + 1}"]) for l in range(3)]
+        # end to end symbol statistics
+        for name, key in (("offset_compressor", "offset"), ("residual_compressor", "residual")):
+            out[f"{key}_e2e"] = _group_flips(nchw(trace[key]["y"]), cap.data[name]["y"])[0]
+        # teacher-forced: every product codec alone on the ORACLE's inputs
+        for name, key in (("offset_compressor", "offset"), ("residual_compressor", "residual")):
+            a = cap.data[name]["args"]
+            f = [hip.nchw_to_nhwc(t.to(dev)) for t in a[:6]]
+            temporal = hip.nchw_to_nhwc(a[6].to(dev))
+            codec = getattr(prod, name)
+            tr = {}
+            b2 = BitCounter(dev, max_rows=6)
+            if key == "offset":
+                codec.code([f[0]], [f[1]], [f[2]], f[3], f[4], f[5], lambda dst: hip.axpby(temporal, None, out=dst), a[7], b2, trace=tr)
+            else:   # Res_ELIC: the reference concatenates (feature, aligned feature) at every scale
+                codec.code([f[0], f[3]], [f[1], f[4]], [f[2], f[5]], f[3], f[4], f[5], lambda dst: hip.axpby(temporal, None, out=dst),
+                           a[7], b2, res=(f[3], f[4], f[5]), trace=tr)
+            flips, far = _group_flips(nchw(tr["y"]), cap.data[name]["y"])
+            zf = int((torch.round(nchw(tr["z"])) != torch.round(cap.data[name]["z"])).sum())
+            out[f"{key}_forced"] = {"y_err": max_abs(nchw(tr["y"]), cap.data[name]["y"]), "flips": flips, "z_flips": zf, "far": far}
+        diff = (x_hat - ref["x_hat"]).abs()
+        out["x_hat_max"] = float(diff.max())
+        out["moved"] = float((diff > 1e-3).float().mean())
+        from helpers import psnr
+        out["d_psnr"] = abs(psnr(x_hat.clamp(0, 1), xc) - psnr(ref["x_hat"].clamp(0, 1), xc))
+        out["size_rel"] = abs(size - float(ref["size"])) / float(ref["size"])
+    return out
+
+
+def test_icip2024_1080p_against_oracle(dev):
+    """FlowGuidedB at 1088x1920, fp32: the down-ratio decision equals the oracle's, every stage in front of a quantiser
+    agrees to fp32 noise, each ELIC codec alone on the oracle's input flips at most a handful of symbols per group (every
+    flip a rounding-boundary case), PSNR / size within the north-star tolerances."""
+    ora, prod = _icip_pair(dev)
+    frames = frames_1080p(303)
+    rep = _icip_stage_report(dev, ora, prod, frames, level=2)
+    print(f"ICIP2024 1080p vs oracle: {rep}")
+    assert rep["down_ratio"][0] == rep["down_ratio"][1]
+    assert rep["flow"] < 2e-3 and max(rep["cond"]) < 2e-3
+    for key in ("offset_forced", "residual_forced"):
+        tf = rep[key]
+        total = sum(t for _, t in tf["flips"])
+        assert tf["z_flips"] <= 2, (key, tf)
+        if tf["z_flips"] == 0:
+            assert sum(n for n, _ in tf["flips"]) <= max(2, 5e-4 * total) and tf["far"] < 2e-3, (key, tf)
+    assert rep["d_psnr"] < 1e-3 and rep["size_rel"] < 2e-3, rep
+    # nothing may amplify in front of the first quantiser; behind it a flipped symbol moves the offsets of its neighbourhood
+    if rep["offset_e2e"] == [(0, t) for _, t in rep["offset_e2e"]]:
+        assert max(rep["offsets"]) < 5e-2 and max(rep["aligned"]) < 5e-2, rep
+
+
+def test_icip2024_fp16_2160p_against_fp32_oracle(dev):
+    """BASELINE configs[4]: 2176x3840 on the fp16 MFMA conv path against the fp32 CPU oracle -- same flow resolution,
+    PSNR and estimated size within the fp16 path's stated tolerances (operands rounded to half, fp32 accumulation)."""
+    from oracle import icip2024 as oi
+    from vcamd import hip
+    from vcamd.layers import BitCounter
+    from helpers import psnr
+    ora, prod = _icip_pair(dev, "fp16")
+    g = torch.Generator().manual_seed(404)
+    Hq, Wq = 2176, 3840
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, Hq + 24, Wq + 32, generator=g), 9, 1)
+    frames = []
+    for t in range(3):
+        f = base[..., 2 * t:2 * t + Hq, 3 * t:3 * t + Wq] + 0.01 * torch.randn(1, 3, Hq, Wq, generator=g)
+        frames.append((torch.round(f.clamp(0, 1) * 255.0) / 255.0).contiguous())
+    x1, xc, x2 = frames
+    with torch.no_grad():
+        best_ref, _ = oi.get_best_down_ratio_prediction(ora, x1, x2, 0.5, 0.5, xc)
+        ref = ora(x1, x2, 0.5, 0.5, xc, 2, best_ref)
+        hip.set_conv_precision("fp16")
+        try:
+            t1, tc, t2 = (hip.nchw_to_nhwc(x.to(dev)) for x in (x1, xc, x2))
+            flow_t, choice, _ = prod.search_flow_t(tc, t1, t2, 0.5, 0.5)
+            bits = BitCounter(dev, max_rows=12)
+            x_hat = hip.nhwc_to_nchw(prod.forward_device(t1, t2, 0.5, 0.5, tc, 2, None, bits, flow=flow_t)).cpu()
+        finally:
+            hip.set_conv_precision("fp32")
+        size = float(bits.totals().sum())
+    d_psnr = abs(psnr(x_hat.clamp(0, 1), xc) - psnr(ref["x_hat"].clamp(0, 1), xc))
+    size_rel = abs(size - float(ref["size"])) / float(ref["size"])
+    print(f"ICIP2024 2176x3840 fp16 path vs fp32 oracle: down ratio {(1, 2, 4, 8, 16)[int(choice.item())]} / {best_ref}; "
+          f"dPSNR {d_psnr:.2e} dB; size rel {size_rel:.2e}; max|d| {float((x_hat - ref['x_hat']).abs().max()):.2e}")
+    assert (1, 2, 4, 8, 16)[int(choice.item())] == best_ref
+    assert torch.isfinite(x_hat).all()
+    assert d_psnr < 5e-3 and size_rel < 5e-3

@@ -353,13 +353,14 @@ class _Elic(JointAutoregressiveHierarchicalPriors):
             self._caches[key] = pack_conv(self.context_prediction_models[i])
         return self._caches[key]
 
-    def code(self, enc1, enc2, enc3, f1d, f2d, f3d, temporal_into, s, bits, res=(None, None, None)):
+    def code(self, enc1, enc2, enc3, f1d, f2d, f3d, temporal_into, s, bits, res=(None, None, None), trace=None):
         """Encoder, entropy model and the three decoder heads.
 
         enc1/enc2/enc3: lists of views whose concatenation the reference feeds to g_a1 / (after y) g_a2 / g_a3;
         f*d: decoder-side conditioning views; temporal_into(view): callback that makes the temporal conditioner
         write its output into the given slice of the prior-fusion input; res: optional views added to the three
         heads' outputs (Res_ELIC: x_comp + res fused into the last convolution).  Returns (head1, head2, head3).
+        ``trace``: a dict that receives the gained latents "y" / "z" (what the quantiser rounds) and "heads".
         Appends 6 x n rows to ``bits`` (n = batch size): z of every image, then y_0 .. y_4 of every image."""
         L = hip.lib()
         M = self.M
@@ -381,6 +382,8 @@ class _Elic(JointAutoregressiveHierarchicalPriors):
         hyper = self.seq("prior_fusion", fusion_in, out=params_in.channels(4 * M, 6 * M))
         params_in0 = T.empty(n, h, w, 4 * M, dev)                      # group 0 has no channel context: [ctx | hyper]
         hip.axpby(hyper, None, out=params_in0.channels(2 * M, 4 * M))
+        if trace is not None:
+            trace.update({"y": y, "z": z})
         y_round = hip.quantize_mask(y)                                 # ste_round(y)
         y_half = hip.quantize_mask(y, keep_parity=1)                   # anchors only (non-anchors zeroed)
         bounds = GROUPS + (M,)
@@ -405,6 +408,8 @@ class _Elic(JointAutoregressiveHierarchicalPriors):
         head2 = self._head("g_o2", [xhat2, f2d], res[1])
         xhat1 = self.seq_cat("g_s1", [xhat2, f2d])
         head1 = self._head("g_o1", [xhat1, f1d], res[0])
+        if trace is not None:
+            trace["heads"] = (head1, head2, head3)
         return head1, head2, head3
 
     def _head(self, name, parts, res):
@@ -776,7 +781,8 @@ class FlowGuidedB(nn.Module):
             return flow
         return hip.upsample_bilinear(flow, int(down_ratio), align_corners=False, scale=float(down_ratio))
 
-    def forward_device(self, xref1, xref2, scale1, scale2, xcur, s, down_ratio, bits, flow=None, feats1=None, feats2=None):
+    def forward_device(self, xref1, xref2, scale1, scale2, xcur, s, down_ratio, bits, flow=None, feats1=None, feats2=None,
+                       trace=None):
         """Synchronisation-free body of :meth:`forward` on channels-last views; returns x_hat (T) and appends
         12 x n rows to ``bits`` (offset: z, y_0..y_4; residual: z, y_0..y_4; each for the n images of the batch --
         independent frames of one hierarchy level can share a pass, see gop.code_gop_icip2024).
@@ -785,13 +791,18 @@ class FlowGuidedB(nn.Module):
         reference recomputes estimate_flow(best down_ratio), the same function of the same inputs).
         ``feats1`` / ``feats2`` (optional): per image of the batch the ``feature_extractor`` outputs (l1, l2, l3) of
         its reference computed earlier -- a decoded frame serves several B-frames of a GOP as reference and its
-        features do not change."""
+        features do not change.
+        ``trace``: a dict that receives the stages of the pass ("flow", "cond" = per level [wref1|wref2|fref1|fref2],
+        "fcur", "offsets", "aligned", "offset" / "residual" = the codecs' own traces) for stage-wise parity checks."""
         dev, n = xcur.buf.device, xcur.n
         if xcur.h % 64 or xcur.w % 64:
             raise hip.VcError("frame size must be a multiple of 64 (the reference pads with utils.pad)")
         s1, s2 = self.convert_scales(scale1, scale2)
         if flow is None:
             flow = self.estimate_flow_t(xref1, xref2, down_ratio)
+        if trace is not None:
+            trace["flow"] = flow
+        t_off, t_res = ({}, {}) if trace is not None else (None, None)
         chans = (64, 96, 128)
         # per level one buffer [wref1 | wref2 | fref1 | fref2 | fcur]: f_cond_inp = first four, f_inp = all five
         F_ = [T.empty(n, xcur.h >> (l + 1), xcur.w >> (l + 1), 5 * c, dev) for l, c in enumerate(chans)]
@@ -819,7 +830,8 @@ class FlowGuidedB(nn.Module):
         cond = [F_[l].channels(0, 4 * chans[l]) for l in range(3)]
         oc = self.offset_compressor
         o1, o2, o3 = oc.code([F_[0]], [F_[1]], [F_[2]], cond[0], cond[1], cond[2],
-                             lambda dst: self.offset_temporal_conditioner.run(cond[0], cond[1], cond[2], out=dst), s, bits)
+                             lambda dst: self.offset_temporal_conditioner.run(cond[0], cond[1], cond[2], out=dst), s, bits,
+                             trace=t_off)
         comp = []
         for l, (off, div) in enumerate(((o1, self.offset_diversity_l1), (o2, self.offset_diversity_l2),
                                         (o3, self.offset_diversity_l3))):
@@ -828,7 +840,9 @@ class FlowGuidedB(nn.Module):
         rc = self.residual_compressor
         x1, x2, x3 = rc.code([fcur[0], comp[0]], [fcur[1], comp[1]], [fcur[2], comp[2]], comp[0], comp[1], comp[2],
                              lambda dst: self.residue_temporal_conditioner.run(comp[0], comp[1], comp[2], out=dst), s, bits,
-                             res=(comp[0], comp[1], comp[2]))
+                             res=(comp[0], comp[1], comp[2]), trace=t_res)
+        if trace is not None:
+            trace.update({"cond": cond, "fcur": fcur, "offsets": (o1, o2, o3), "aligned": comp, "offset": t_off, "residual": t_res})
         return self.reconstructor.run(x1, x2, x3)
 
     def forward(self, xref1, xref2, scale1, scale2, xcur, s, down_ratio):
