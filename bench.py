@@ -701,15 +701,14 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                                             "at all physical cores (1 timed call where the warm-up was already 1.5x slower) -- "
                                             "value = the faster setting",
                                   "runs": list(runs.values()), "host_physical_cores": physical_cores()}
-        with torch.no_grad():
-            trace = {} if not is_icip else None
-            gpu_hat, gpu_bits = product_frame(trace)
-        src = frames[mid]
-        d_psnr = abs(float(vgop.psnr_uint8(gpu_hat, src, H, W)) - float(vgop.psnr_uint8(ref_hat.to(dev), src, H, W)))
-        diff = (gpu_hat.cpu() - ref_hat).abs()
-        parity = {"d_psnr_db": d_psnr, "bits_rel": abs(gpu_bits - ref_bits) / abs(ref_bits),
-                  "max_abs": float(diff.max()), "pixels_over_1e-3": float((diff > 1e-3).float().mean())}
-        if traces is not None:
+        def parity_block(gpu_hat, gpu_bits, trace, ref_hat, ref_bits, traces):
+            src = frames[mid]
+            d_psnr = abs(float(vgop.psnr_uint8(gpu_hat, src, H, W)) - float(vgop.psnr_uint8(ref_hat.to(dev), src, H, W)))
+            diff = (gpu_hat.cpu() - ref_hat).abs()
+            parity = {"d_psnr_db": d_psnr, "bits_rel": abs(gpu_bits - ref_bits) / abs(ref_bits),
+                      "max_abs": float(diff.max()), "pixels_over_1e-3": float((diff > 1e-3).float().mean())}
+            if traces is None:
+                return parity
             # the integers of the bitstream: quantised symbols of y and z for the motion and the residual codec
             sym = {}
             for name, key in (("mv", "flow" if is_flex else "mv"), ("res", "res")):
@@ -737,7 +736,37 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                 "residual_codec_input": float((hip.nhwc_to_nchw(trace["resid"]).cpu() - traces["res"]["x"]).abs().max()),
                 "res_y": float((hip.nhwc_to_nchw(trace["res"]["y"]).cpu() - traces["res"]["y"]).abs().max()),
                 "res_scales": float((hip.nhwc_to_nchw(trace["res"]["scales"]).cpu() - traces["res"]["scales"]).abs().max())}
-        result["parity_vs_cpu"] = parity
+            return parity
+
+        with torch.no_grad():
+            trace = {} if not is_icip else None
+            gpu_hat, gpu_bits = product_frame(trace)
+        result["parity_vs_cpu"] = parity_block(gpu_hat, gpu_bits, trace, ref_hat, ref_bits, traces)
+        result["parity_vs_cpu"]["checkpoint"] = "seeded (vcamd.seeding.seeded_state_dict, seed 1234)"
+        if not is_flex and not is_icip:
+            # ---- the same frame on the checkpoint with TRAINED-LIKE statistics (vcamd.seeding.calibrated_state_dict):
+            # sub-pixel flows, |y - mu| ~ 1, scales spread over the table, a decoded residual that is a small correction
+            from vcamd import lhbdc as vlhbdc
+            from vcamd.seeding import calibrated_state_dict
+            cal_sd = calibrated_state_dict(model.state_dict(), seed=1234)
+            ora_c = oracle_lhbdc.LhbdcModel().eval()
+            ora_c.load_state_dict(cal_sd)
+            prod_c = vlhbdc.Model()
+            prod_c.load_state_dict(cal_sd)
+            prod_c = prod_c.to(dev).eval()
+            with torch.no_grad():
+                with CodecTrace(ora_c.mv_compressor) as t_mv, CodecTrace(ora_c.residual_compressor) as t_res, CallLog(ora_c.masknet) as t_mask:
+                    ref_hat_c, _, ref_bits_c = ora_c(xb, xc, xa, False)
+                    traces_c = {"mv": t_mv.latents(get_scale_table()), "res": t_res.latents(get_scale_table()), "mask": t_mask.outputs[-1]}
+                trace_c = {}
+                gpu_hat_c, tot_c = prod_c.forward_device(frames[0], frames[mid], frames[2 * mid], trace=trace_c)
+            pc = parity_block(gpu_hat_c, float(tot_c.sum().item()), trace_c, ref_hat_c, float(ref_bits_c), traces_c)
+            pc["checkpoint"] = "calibrated (vcamd.seeding.calibrated_state_dict, seed 1234)"
+            pc["quality_of_this_frame"] = {"psnr_db": float(vgop.psnr_uint8(ref_hat_c.to(dev), frames[mid], H, W)),
+                                           "bpp_estimated": float(ref_bits_c) / (H * W),
+                                           "residual_symbols_nonzero": float((traces_c["res"]["y_sym"] != 0).float().mean()),
+                                           "what": "middle frame of the GOP (references 4 frames away: the hardest level)"}
+            result["parity_vs_cpu_calibrated"] = pc
 
 
 if __name__ == "__main__":

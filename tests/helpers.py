@@ -21,13 +21,14 @@ def psnr(a, b):
     return 10.0 * np.log10(1.0 / mse) if mse > 0 else float("inf")
 
 
-def lhbdc_pair(seed, device=None):
-    """(oracle model, product model) carrying the same seeded checkpoint."""
+def lhbdc_pair(seed, device=None, calibrated=False):
+    """(oracle model, product model) carrying the same seeded checkpoint (``calibrated``: the trained-like variant of
+    vcamd.seeding.calibrated_state_dict -- ~0.1-0.5 bpp, prediction-limited PSNR)."""
     from oracle import lhbdc as ol
     from vcamd import lhbdc
-    from vcamd.seeding import seeded_state_dict
+    from vcamd.seeding import calibrated_state_dict, seeded_state_dict
     prod = lhbdc.Model()
-    sd = seeded_state_dict(prod.state_dict(), seed=seed)
+    sd = (calibrated_state_dict if calibrated else seeded_state_dict)(prod.state_dict(), seed=seed)
     prod.load_state_dict(sd)
     ora = ol.LhbdcModel().eval()
     ora.load_state_dict(sd)

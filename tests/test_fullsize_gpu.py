@@ -91,11 +91,15 @@ def check_teacher_forced(tag, tf):
         assert far < 2e-3, (tag, which, far)
 
 
-def test_lhbdc_1080p_against_oracle(dev):
+@pytest.mark.parametrize("calibrated", [False, True], ids=["seeded", "calibrated"])
+def test_lhbdc_1080p_against_oracle(dev, calibrated):
+    """``calibrated``: the checkpoint with trained-like statistics (vcamd.seeding.calibrated_state_dict: ~0.1-0.5 bpp,
+    |y - mu| ~ 1, scales spread over the table, 31 dB on this triple) next to the plain seeded one (latents in the
+    hundreds, 6 dB): the integer counts and the PSNR tolerance are checked on both."""
     from helpers import lhbdc_pair, psnr
     from oracle.cai.entropy_models import get_scale_table
     from oracle.trace import CallLog, CodecTrace
-    ora, prod = lhbdc_pair(1234, dev)
+    ora, prod = lhbdc_pair(1234, dev, calibrated=calibrated)
     xb, xc, xa = frames_1080p(101)
     table = get_scale_table()
     with torch.no_grad():
@@ -118,18 +122,30 @@ def test_lhbdc_1080p_against_oracle(dev):
     diff = (x_hat.cpu() - ref_hat).abs()
     moved = float((diff > 1e-3).float().mean())
     d_psnr = abs(psnr(x_hat.cpu(), xc) - psnr(ref_hat, xc))
+    q_psnr, q_bpp = psnr(ref_hat.clamp(0, 1), xc), ref_bits / (H * W)
+    nz = float((ref["res"]["y_sym"] != 0).float().mean())
+    print(f"LHBDC 1080p ({'calibrated' if calibrated else 'seeded'} checkpoint: {q_psnr:.2f} dB, {q_bpp:.3f} bpp, {100 * nz:.1f} % of the residual "
+          f"symbols non-zero, |y| max {float(ref['res']['y'].abs().max()):.1f})")
+    if calibrated:
+        assert q_psnr > 25.0 and 0.05 < q_bpp < 0.6, (q_psnr, q_bpp)
     print(f"LHBDC 1080p vs oracle: stage max|d| {stage}; symbols differing {rep} = {frac:.2e}; pixels moved > 1e-3: {moved:.2e}; "
           f"max|d| {float(diff.max()):.3e}; dPSNR {d_psnr:.2e} dB; bits rel {abs(bits - ref_bits) / ref_bits:.2e}")
     assert stage["flows"] < 2e-3 and stage["mv_codec_input"] < 2e-3
     with torch.no_grad():
         check_teacher_forced("LHBDC mv_compressor", teacher_forced(prod.mv_compressor, ref["mv"], dev))
         check_teacher_forced("LHBDC residual_compressor", teacher_forced(prod.residual_compressor, ref["res"], dev))
-    assert frac < 2e-3, rep          # end to end: a flip in the motion codec moves the residual codec's whole input
-    assert d_psnr < 1e-3 and abs(bits - ref_bits) / ref_bits < 2e-3
+    # Bounds = 10x what MI355X measures on this triple (round 3: 1.7e-6 / 8.4e-7 of the symbols differ end to end, stage maxima
+    # 2e-5 / 5e-6, dPSNR 2e-7 / 2e-6 dB, bits 9e-6 / 9e-7 for the seeded / calibrated checkpoint).
+    assert frac < 2e-5, rep          # end to end: a flip in the motion codec moves the residual codec's whole input
+    assert d_psnr < 1e-4 and abs(bits - ref_bits) / ref_bits < 1e-4
     # up to the first quantiser nothing may amplify: the flow codec's reconstruction feeds mask / prediction / residual
     if rep["mv_y_sym"][0] == 0 and rep["mv_z_sym"][0] == 0:
-        assert stage["mask"] < 2e-3 and stage["prediction"] < 2e-3 and stage["res_y"] < 0.05
-        assert rep["res_y_sym"][0] <= 5e-4 * rep["res_y_sym"][1]
+        assert stage["mask"] < 2e-4 and stage["prediction"] < 2e-4 and stage["res_y"] < 3e-4
+        assert rep["res_y_sym"][0] <= 2e-5 * rep["res_y_sym"][1]
+    if calibrated:
+        # trained-like statistics: a flipped symbol is a local +-1 behind a synthesis transform of small gain -- no pixel
+        # may move visibly (measured: none above 1e-3, max 5.5e-4)
+        assert moved < 1e-4 and float(diff.max()) < 5e-3, (moved, float(diff.max()))
 
 
 def test_flex_1080p_against_oracle(dev):
