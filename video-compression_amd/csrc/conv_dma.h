@@ -229,6 +229,15 @@ __device__ __forceinline__ void dma_epilogue_mode(const ConvArgs &p, f32x16 (&ac
     });
 }
 
+// v_max_f32 as ONE instruction: fmaxf() on an MFMA result makes hipcc put a canonicalising v_max(v, v) in front of it
+// (cdna guide, attention notes) -- a third of the fast epilogue's vector instructions
+__device__ __forceinline__ float vc_max_f32(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Fast epilogue for the common case inside a chain of fp16-path layers: half-precision output, plain / ReLU / LeakyReLU
 // (slope in [0, 1]), no residual / gain / pixel shuffle, tile entirely inside the output.  Per M-tile the wave's
 // 32 px x (32 WN) channels are activated and rounded in the accumulator layout, pass through a private 32 x (64 WN)-byte
@@ -260,7 +269,7 @@ __device__ __forceinline__ void dma_epilogue_fast(const ConvArgs &p, f32x16 (&ac
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float v = acc[t][n][4 * g + e];
-                    h[e] = (_Float16)fmaxf(v, v * neg);
+                    h[e] = (_Float16)vc_max_f32(v, v * neg);
                 }
                 const int c = 4 * n + g;
                 *reinterpret_cast<f16x4 *>(scratch + wpx * ROWB + ((c ^ (wpx & (CH16 - 1))) << 4) + 8 * wh) = h;
@@ -346,9 +355,13 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         return in_b + 2 * ((long long)t.img * p.in_sn + (long long)(t.oy0 - C::KH / 2) * p.in_sh + (long long)(t.ox0 - KW / 2) * p.in_sw);
     };
     auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {
-        const unsigned iy = (unsigned)(t.oy0 - C::KH / 2 + (a_rc[k] & 0xff)), ix = (unsigned)(t.ox0 - KW / 2 + (a_rc[k] >> 8));
+        // (the two per-lane constants pass through an empty asm: the address is then computed HERE, not hoisted to the top
+        //  of the tile loop for all pieces of both tiles at once -- 20 registers the accumulators need)
+        int rc = a_rc[k], off = a_off[k];
+        asm volatile("" : "+v"(rc), "+v"(off));
+        const unsigned iy = (unsigned)(t.oy0 - C::KH / 2 + (rc & 0xff)), ix = (unsigned)(t.ox0 - KW / 2 + (rc >> 8));
         const bool ok = t.valid && iy < (unsigned)p.H && ix < (unsigned)p.W;
-        const unsigned char *sp = ok ? tbase + (a_off[k] + c * 64) : zero_lane;
+        const unsigned char *sp = ok ? tbase + (off + c * 64) : zero_lane;
         if constexpr (!(C::KO & (16 | 1024))) vc_glds16<!(C::KO & 512)>(sp, (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
     };
     // Weights of tile-phase pb (>= PT: of the next tile, same layer): wave w fetches fragment w of the phase =
@@ -397,6 +410,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
 #endif
     VC_DMA_STAMP(t_begin);
     f32x16 acc[WM][WN];
+    f32x4 af[UPP][2][WM], bf[UPP][2][WN];             // the fragments of one phase (waves 4-7 carry them across a barrier)
     int gchunk = 0;                                  // chunks contracted so far: parity = buffer of the current chunk
     for (int it = 0;; ++it) {
         // ---- accumulators start at the bias ----
@@ -410,29 +424,24 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[t][n][4 * g + e] = b[e];
             }
-        if (grp == 1 && !(C::KO & 32)) VC_DMA_BARRIER();              // waves 4-7 run half a phase behind waves 0-3
-
-        static_for<0, PT>([&](auto pc) {
+        // ---- the three parts of a phase ----
+        auto issue_loads = [&](auto pc) {            // DMA of later phases: pieces of the next chunk image, then this phase's weight slot
             constexpr int ph = decltype(pc)::value;
-            VC_DMA_STAMP(t0);
-            // -- R: loads of later phases, and this phase's fragments --
-            auto issue_loads = [&]() {
             static_for<0, NCHUNK>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    static_for<0, NA>([&](auto kc) {
-                        constexpr int k = decltype(kc)::value;
-                        if constexpr (C::piece_phase(c, k) == ph) {
-                            // chunk c+1 of this tile, or chunk 0 of the next one, into the buffer chunk c does not use
-                            if constexpr (c + 1 < NCHUNK) issue_a(cur, cur_base, c + 1, k, (gchunk + c + 1) & 1);
-                            else issue_a(nxt, nxt_base, 0, k, (gchunk + c + 1) & 1);
-                        }
-                    });
+                constexpr int c = decltype(cc)::value;
+                static_for<0, NA>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (C::piece_phase(c, k) == ph) {
+                        // chunk c+1 of this tile, or chunk 0 of the next one, into the buffer chunk c does not use
+                        if constexpr (c + 1 < NCHUNK) issue_a(cur, cur_base, c + 1, k, (gchunk + c + 1) & 1);
+                        else issue_a(nxt, nxt_base, 0, k, (gchunk + c + 1) & 1);
+                    }
                 });
-                issue_b(ph + RING - 2, cur.nblk, nxt.nblk);
-            };
-            if constexpr (C::KO & 256) issue_loads();
-            VC_DMA_STAMP(t1);
-            f32x4 af[UPP][2][WM], bf[UPP][2][WN];
+            });
+            issue_b(ph + RING - 2, cur.nblk, nxt.nblk);
+        };
+        auto read_frags = [&](auto pc) {             // this phase's fragments: LDS -> registers
+            constexpr int ph = decltype(pc)::value;
             static_for<0, UPP>([&](auto uc) {
                 constexpr int uu = decltype(uc)::value;
                 constexpr int u = ph * UPP + uu;
@@ -458,14 +467,9 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
                     }
                 }
             });
-            VC_DMA_STAMP(t1b);
-            if constexpr (!(C::KO & 256)) issue_loads();
-            VC_DMA_STAMP(t2);                        // (a stamp waits for the fragment reads: t2 - t1 = LDS reads issued and returned)
-            if constexpr (!(C::KO & 2)) vc_wait_vmcnt<C::nwait(ph)>();           // this wave's part of the next phase's weights (and everything older) has landed
-            VC_DMA_STAMP(t3);
-            VC_DMA_BARRIER();
-            VC_DMA_STAMP(t4);
-            // -- M: 16 MFMAs per wave while the other group reads --
+        };
+        auto contract = [&](auto pc) {               // 16 MFMAs per wave on the fragments read_frags left in registers
+            constexpr int ph = decltype(pc)::value;
             if constexpr (!(C::KO & 128)) __builtin_amdgcn_s_setprio(1);
             static_for<0, UPP>([&](auto uc) {
                 constexpr int uu = decltype(uc)::value;
@@ -489,6 +493,23 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
                 }
             });
             if constexpr (!(C::KO & 128)) __builtin_amdgcn_s_setprio(0);
+        };
+
+        if (grp == 1 && !(C::KO & 32)) VC_DMA_BARRIER();              // waves 4-7 run half a phase behind waves 0-3
+        static_for<0, PT>([&](auto pc) {
+            constexpr int ph = decltype(pc)::value;
+            VC_DMA_STAMP(t0);
+            if constexpr (C::KO & 256) issue_loads(pc);
+            VC_DMA_STAMP(t1);
+            read_frags(pc);
+            VC_DMA_STAMP(t1b);
+            if constexpr (!(C::KO & 256)) issue_loads(pc);
+            VC_DMA_STAMP(t2);                        // (a stamp waits for the fragment reads: t2 - t1 = LDS reads issued and returned)
+            if constexpr (!(C::KO & 2)) vc_wait_vmcnt<C::nwait(ph)>();           // this wave's part of the next phase's weights (and everything older) has landed
+            VC_DMA_STAMP(t3);
+            VC_DMA_BARRIER();
+            VC_DMA_STAMP(t4);
+            contract(pc);                            // -- M: 16 MFMAs per wave while the other group reads --
             VC_DMA_STAMP(t5);
             VC_DMA_BARRIER();
             VC_DMA_STAMP(t6);
