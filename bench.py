@@ -38,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # BF16/FP16 matrix peak, dense
 PEAK_HBM_GBPS = 8000.0           # HBM3E peak (same guide)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02", "traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03", "traffic.json")
 
 
 def kernel_source_stamp():
@@ -748,7 +748,7 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
             # sub-pixel flows, |y - mu| ~ 1, scales spread over the table, a decoded residual that is a small correction
             from vcamd import lhbdc as vlhbdc
             from vcamd.seeding import calibrated_state_dict
-            cal_sd = calibrated_state_dict(model.state_dict(), seed=1234)
+            cal_sd = calibrated_state_dict(vlhbdc.Model().state_dict(), seed=1234)     # (a fresh module: empty CDF buffers)
             ora_c = oracle_lhbdc.LhbdcModel().eval()
             ora_c.load_state_dict(cal_sd)
             prod_c = vlhbdc.Model()
