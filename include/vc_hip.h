@@ -72,7 +72,13 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
                         or a multiple of 128, plain / ReLU / LeakyReLU / sigmoid / clamp epilogue (+ gain, residual, pixel
                         shuffle): one persistent 512-thread workgroup per CU, both operands streamed into LDS by
                         global_load_lds with counted vmcnt across raw barriers (csrc/conv_dma.h); reads the packed weights
-                        of the 32-wide configurations and gives bit-identical results */ };
+                        of the 32-wide configurations and gives bit-identical results */,
+       VC_CFG_PWS = 9 /* streaming 1x1 stride-1 kernel, second generation (csrc/conv_pws.hip): one persistent 512-thread
+                        workgroup per CU, weights resident in LDS, activations streamed into per-wave LDS rings by
+                        global_load_lds in whole 128-byte lines with counted vmcnt waits (no barriers), the residual
+                        requested a tile ahead; cin 32/64/96/128, cout <= 128, plain/ReLU/LeakyReLU epilogue (+ gain,
+                        residual), fp32 and both fp16-path input types; reads the packed weights of N128/N64/N32 and
+                        gives bit-identical results */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
  * same packed weights and produces bit-identical results); without it the library narrows the block for
  * small feature maps by itself. */

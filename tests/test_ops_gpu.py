@@ -477,13 +477,16 @@ def test_entropy_kernels_exact_inputs(dev):
 
 
 PW_CASES = [(128, 128, 37, 75, 2), (64, 64, 33, 64, 1), (96, 96, 20, 50, 1), (32, 32, 16, 96, 3), (128, 64, 18, 40, 1),
-            (96, 64, 9, 31, 1), (128, 96, 12, 33, 1), (64, 32, 8, 129, 1)]
+            (96, 64, 9, 31, 1), (128, 96, 12, 33, 1), (64, 32, 8, 129, 1),
+            # VC_CFG_PWS: a row shorter than one tile; more tiles than the 2048 persistent waves (ring wrap-around, tile hand-over)
+            (64, 64, 5, 17, 1), (32, 32, 200, 330, 2), (128, 128, 300, 250, 1)]
 
 
 @pytest.mark.parametrize("cin,cout,h,w,n", PW_CASES)
 @pytest.mark.parametrize("precision", ["fp32", "fp16"])
 def test_pointwise_streaming_kernel_is_bit_identical(dev, cin, cout, h, w, n, precision):
-    """VC_CFG_PW (streaming 1x1 kernel, csrc/conv_pw.hip) against the general kernel on the same packed weights:
+    """VC_CFG_PW (streaming 1x1 kernel, csrc/conv_pw.hip) and VC_CFG_PWS (its LDS-DMA successor, csrc/conv_pws.hip) against the
+    general kernel on the same packed weights:
     plain and ReLU epilogues, channel gain + residual, inputs/outputs that are channel slices of wider buffers,
     widths that are not a multiple of the 32-pixel tile, batches; on the fp16 path also half-precision in/out."""
     from vcamd import hip
@@ -521,6 +524,11 @@ def test_pointwise_streaming_kernel_is_bit_identical(dev, cin, cout, h, w, n, pr
     pw = run(6)
     for a, b in zip(base, pw):
         assert torch.equal(a, b)
+    if cin % 32 == 0 and cout % 32 == 0:                      # VC_CFG_PWS (csrc/conv_pws.hip): LDS-DMA rings, counted waits
+        assert 9 in pc.candidates
+        for rep in range(3):                                  # (a wrong wait count shows as run-to-run differences)
+            for a, b in zip(base, run(9)):
+                assert torch.equal(a, b)
     # and against torch on the exact path
     ref = F.relu(F.conv2d(hip.nhwc_to_nchw(x).cpu(), _rand((cout, cin, 1, 1), 51, 1.0 / np.sqrt(cin)), _rand((cout,), 52, 0.1)))
     _close(pw[0], ref, 2e-5 if precision == "fp32" else 5e-3, "pointwise kernel vs torch")
@@ -664,7 +672,7 @@ def test_conv2d_random_sweep_every_candidate_configuration(dev):
                 outs.append((cfg, hip.nhwc_to_nchw(pc(xt, act=code, slope=slope, res=rt))))
             except hip.VcError:
                 # only the streaming 1x1 kernel and the LDS-DMA pipeline (half-precision inputs only) may decline a call
-                assert cfg in (6, 8)
+                assert cfg in (6, 8, 9)
         assert outs, f"no configuration ran for case {i}"
         what = f"sweep {i}: {cin}->{cout} k{k} s{stride} @{n}x{h}x{w} {act}{' +res' if with_res else ''}"
         _close(outs[0][1], ref, 2e-5, what)
@@ -697,7 +705,7 @@ def test_conv2d_half_precision_output_equals_rounded_fp32_output(dev):
                     half = hip.T.empty(n, h, w, cout, dev, "f16")
                     pc(x, out=half, act=hip.ACT_LRELU, res=res)
                 except hip.VcError:
-                    assert cfg in (6, 8)     # (the LDS-DMA pipeline takes half-precision inputs only: fp32 here)
+                    assert cfg in (6, 8, 9)     # (the LDS-DMA pipeline takes half-precision inputs only: fp32 here)
                     continue
                 torch.cuda.synchronize()
                 assert torch.equal(full.buf.view(n, h, w, cout).to(torch.float16), half.buf.view(n, h, w, cout)), \

@@ -107,7 +107,7 @@ extern "C" int vc_conv_pack_weights(const float *w, const float *bias, int cout,
 static inline bool cfg_f16_ok(int cfg, int cin)
 {
     return (cfg == VC_CFG_N128 || cfg == VC_CFG_N64 || cfg == VC_CFG_N32 || cfg == VC_CFG_N128B || cfg == VC_CFG_N16 ||
-            cfg == VC_CFG_PW || cfg == VC_CFG_N32T16 || cfg == VC_CFG_DMA) && (cin % 8) == 0;
+            cfg == VC_CFG_PW || cfg == VC_CFG_PWS || cfg == VC_CFG_N32T16 || cfg == VC_CFG_DMA) && (cin % 8) == 0;
 }
 
 extern "C" size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride)
@@ -236,6 +236,10 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     if (cfg == VC_CFG_PW) {                 // streaming 1x1 kernel: only ever chosen explicitly (autotuner)
         if (!conv_pw_eligible(a, k, st, f16)) return VC_EINVAL;
         return conv_dispatch_pw(stream, a, f16);
+    }
+    if (cfg == VC_CFG_PWS) {                // LDS-DMA streaming 1x1 kernel: only ever chosen explicitly (autotuner)
+        if (!conv_pws_eligible(a, k, st, f16)) return VC_EINVAL;
+        return conv_dispatch_pws(stream, a, f16);
     }
     if (cfg == VC_CFG_DMA)                  // fp16-path LDS-DMA pipeline: only ever chosen explicitly (autotuner)
         return f16 ? conv_dispatch_dma(stream, a, k, st) : VC_EINVAL;

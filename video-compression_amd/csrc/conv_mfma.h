@@ -851,6 +851,8 @@ template <int KH, int KW, int S, int CK> int launch_conv_n4(hipStream_t st, cons
     int conv_dispatch_##k##_f16(hipStream_t st, const ConvArgs &a, int stride, int cfg, int ck);
 // streaming 1x1 kernel (conv_pw.hip): same packed weights as the 32-wide configurations
 bool conv_pw_eligible(const ConvArgs &a, int k, int stride, bool f16);
+bool conv_pws_eligible(const ConvArgs &a, int k, int stride, bool f16);
+int conv_dispatch_pws(hipStream_t st, const ConvArgs &a, bool f16);
 int conv_dispatch_pw(hipStream_t st, const ConvArgs &a, bool f16);
 // fp16-path LDS-DMA pipeline (conv_dma.hip): same packed weights again; sets the tile geometry of `a` itself
 int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride);

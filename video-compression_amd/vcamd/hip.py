@@ -290,6 +290,7 @@ CFG_IN_F16 = 0x400
 CFG_OUT_F16 = 0x800
 CFG_RES_FIRST = 0x1000
 CFG_DMA = 8               # fp16 path: LDS-DMA pipeline, one persistent workgroup per CU (csrc/conv_dma.h); half-precision input only
+CFG_PWS = 9               # streaming 1x1 kernel with LDS-DMA activation rings (csrc/conv_pws.hip)
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
 # "fp32" (default, exact fp32 FMA chains like the reference) or "fp16" (BASELINE.json configs[4]: half-precision MFMA
 # with fp32 accumulate for every eligible layer; judged on PSNR/bpp tolerance, never the headline number).
@@ -357,6 +358,8 @@ class PackedConv:
             self.candidates.append(5)          # VC_CFG_N128B: 128-channel block with the waves arranged 2x2
         if self.candidates and kh == 1 and stride == 1 and not self.ps and 32 <= cin <= 128 and cout <= 128 and cin % 8 == 0:
             self.candidates.append(6)          # VC_CFG_PW: streaming 1x1 kernel (skipped by the tuner when the call is not eligible)
+            if cin % 32 == 0 and cout % 32 == 0 and os.environ.get("VC_PWS_KERNELS", "1") != "0":
+                self.candidates.append(CFG_PWS)  # VC_CFG_PWS: the same through per-wave LDS-DMA rings
         if self.candidates and kh == 7 and stride == 1:
             self.candidates.append(7)          # VC_CFG_N32T16: 16-row tiles (less halo per output)
         if (self.candidates and kh in (3, 7) and stride == 1 and cin % 32 == 0 and (cout in (32, 64) or cout % 128 == 0)
