@@ -404,7 +404,8 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f16 operands / f32 accumulate (eligible convolutions), f32 elsewhere" if f16 else "f32",
+        "dtype": ("f16 operands / f32 accumulate (eligible convolutions; activations between them and, VC_HALF_RESIDUAL=1, the identity "
+                  "path of bottleneck chains stored as half), f32 elsewhere") if f16 else "f32",
         "data": f"synthetic (band-limited texture + global translation + 2% noise, {H}x{W} reflection-padded to x64); seeded random weights",
         "config": {"workload": workload,
                    "frames_per_step": (frames_total if strong else per_gop * G * world), "gop": 16 if (is_flex or is_icip) else 8,

@@ -98,6 +98,11 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
 /* OR into vc_conv_desc.cfg: add `res` BEFORE the (plain / ReLU / LeakyReLU) activation instead of after it --
  * out = relu(conv(x) + res), the ResidualUnit of compressai.layers.AttentionBlock (ICIP2024/src/model/elic.py:97-121). */
 #define VC_CFG_RES_FIRST 0x1000
+/* With VC_CFG_F16, VC_CFG_PWS only: `res` is a HALF-precision tensor (pointer to _Float16, strides in elements) -- the
+ * identity path of a chain of bottleneck blocks kept as half on the fp16 path (ICIP2024/src/model/elic.py:69-83: out =
+ * x + f(x) per block).  Unlike VC_CFG_IN_F16 / OUT_F16 this CHANGES results (one more rounding of the identity per block):
+ * part of the fp16 mode's stated tolerance, never of the fp32 path.  Every other configuration returns VC_EINVAL. */
+#define VC_CFG_RES_F16 0x2000
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */
     vc_view out;           /* [n,ho,wo,cout]  (PIXELSHUFFLE2: [n,2ho,2wo,cout/4]) */

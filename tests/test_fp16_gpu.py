@@ -81,6 +81,7 @@ def test_half_precision_activations_do_not_change_a_bit(dev):
         "icip2024": (icip2024.FlowGuidedB, lambda m: m(xb, xa, 0.5, 0.5, xc, 2, 1)["x_hat"]),
     }
     hip.set_conv_precision("fp16")
+    hip.HALF_RESIDUAL = False          # (the half-precision identity path is NOT bit-neutral: its own test below)
     try:
         for name, (build, run) in builders.items():
             m = build()
@@ -107,7 +108,57 @@ def test_half_precision_activations_do_not_change_a_bit(dev):
             assert torch.equal(outs[0], outs[1])
     finally:
         hip.HALF_ACTIVATIONS = True
+        hip.HALF_RESIDUAL = True
         hip.set_conv_precision("fp32")
+
+
+def test_half_precision_identity_path_of_bottleneck_chains(dev):
+    """VC_CFG_RES_F16 (hip.HALF_RESIDUAL): ICIP2024's chains of bottleneck blocks (elic.py:69-83, out = x + f(x)) keep x as half
+    between the blocks on the fp16 path.  Not bit-neutral -- one more rounding of the identity per block -- so: it must be
+    IN USE (half residuals reach the streaming kernel), and what it changes must stay inside the fp16 mode's own distance
+    from the fp32 path (measured on this frame, seeded weights: max |d| of the reconstruction 0.47 against 0.45 for fp16 vs
+    fp32 -- both are single flipped symbols of the quantiser, not drift; estimated size 827 067 vs 827 094 vs 827 137 bits)."""
+    from vcamd import hip, icip2024
+    from vcamd.seeding import seeded_state_dict
+    fx = load_fixture("lhbdc_forward_a.npz")
+    xb, xc, xa = (frame_tensor(fx[k]).to(dev) for k in ("ref_1", "current", "ref_2"))
+    outs = {}
+    seen = []
+    orig = hip.PackedConv.__call__
+
+    def spy(self, x, *a, **k):
+        if k.get("res") is not None:
+            seen.append(k["res"].dtype)
+        return orig(self, x, *a, **k)
+    try:
+        for mode, prec, hr in (("fp32", "fp32", False), ("fp16 fp32-identity", "fp16", False), ("fp16 half-identity", "fp16", True)):
+            hip.set_conv_precision(prec)
+            hip.HALF_RESIDUAL = hr
+            m = icip2024.FlowGuidedB()
+            m.load_state_dict(seeded_state_dict(m.state_dict(), seed=1234))
+            m = m.to(dev).eval()
+            del seen[:]
+            hip.PackedConv.__call__ = spy
+            try:
+                with torch.no_grad():
+                    r = m(xb, xa, 0.5, 0.5, xc, 2, 1)
+            finally:
+                hip.PackedConv.__call__ = orig
+            outs[mode] = (r["x_hat"].float().cpu(), float(r["size"]), seen.count("f16"))
+    finally:
+        hip.HALF_RESIDUAL = True
+        hip.set_conv_precision("fp32")
+    x32, b32, _ = outs["fp32"]
+    xf, bf, nf = outs["fp16 fp32-identity"]
+    xh, bh, nh = outs["fp16 half-identity"]
+    d_mode = (xf - x32).abs().max().item()
+    d_half = (xh - xf).abs().max().item()
+    print(f"half residuals per frame {nh} (fp32-identity run: {nf}); max|fp16 - fp32| = {d_mode:.2e}, max|half identity - fp32 identity| = {d_half:.2e}, "
+          f"bits {b32:.1f} / {bf:.1f} / {bh:.1f}")
+    assert nf == 0 and nh >= 20
+    assert d_half <= max(3.4e-2, 2.0 * d_mode)
+    if b32:
+        assert abs(bh - bf) / b32 < 5e-3
 
 
 def test_half_activation_never_reaches_other_kernels(dev):

@@ -4,6 +4,8 @@ The CPU side here is plain torch (fp32) on the same seeded inputs -- the operato
 from.  Tolerances: convolutions 2e-5 * (1 + |ref|) (fp32 FMA chains in a different order), resampling /
 warping 1e-5, entropy bit counts 1e-5 relative, integer outputs exact.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -532,6 +534,50 @@ def test_pointwise_streaming_kernel_is_bit_identical(dev, cin, cout, h, w, n, pr
     # and against torch on the exact path
     ref = F.relu(F.conv2d(hip.nhwc_to_nchw(x).cpu(), _rand((cout, cin, 1, 1), 51, 1.0 / np.sqrt(cin)), _rand((cout,), 52, 0.1)))
     _close(pw[0], ref, 2e-5 if precision == "fp32" else 5e-3, "pointwise kernel vs torch")
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(128, 128, 37, 75, 2), (64, 64, 20, 33, 1), (96, 96, 9, 50, 1), (32, 32, 200, 330, 1), (128, 64, 18, 40, 1)])
+def test_streaming_kernel_half_precision_residual(dev, cin, cout, h, w, n):
+    """VC_CFG_RES_F16 (fp16 path, VC_CFG_PWS only): a half-precision residual gives exactly what the fp32 residual holding the
+    same (half-representable) values gives -- fp32 and half output, residual before and after the activation, half and fp32
+    input; any other configuration declines it."""
+    from vcamd import hip
+    hip.set_conv_precision("fp16")
+    try:
+        pc = hip.PackedConv(_rand((cout, cin, 1, 1), 61, 1.0 / np.sqrt(cin)), _rand((cout,), 62, 0.1), device=dev)
+    finally:
+        hip.set_conv_precision("fp32")
+    assert pc.half_res_ok
+    x32 = hip.nchw_to_nhwc(_rand((n, cin, h, w), 63).to(dev))
+    x16 = hip.T.empty(n, h, w, cin, dev, "f16")
+    x16.buf.copy_(x32.buf.half())
+    r16 = hip.T.empty(n, h, w, cout, dev, "f16")
+    r16.buf.copy_(hip.nchw_to_nhwc(_rand((n, cout, h, w), 64).to(dev)).buf.half())
+    r32 = hip.T.empty(n, h, w, cout, dev)
+    r32.buf.copy_(r16.buf.float())
+    for x in (x32, x16):
+        for out_f16 in (False, True):
+            for res_first in (False, True):
+                outs = []
+                for res in (r32, r16):
+                    for rep in range(2 if res is r16 else 1):
+                        pc.tuned = {}
+                        fl = hip.CFG_F16 | (hip.CFG_IN_F16 if x is x16 else 0) | (hip.CFG_OUT_F16 if out_f16 else 0)
+                        pc.tuned[(n, h, w, fl)] = 9 | hip.CFG_EXACT | fl               # the fp32-residual twin on the same kernel
+                        o = pc(x, act=hip.ACT_LRELU, slope=0.2, res=res, res_first=res_first, out_f16=out_f16)
+                        assert o.dtype == ("f16" if out_f16 else "f32")
+                        outs.append(o.buf.clone())
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    d = hip.ConvDesc()        # and the C ABI refuses the flag on any other configuration
+    o = hip.T.empty(n, h, w, cout, dev)
+    d.inp, d.out = x32.view(True), o.view(True)
+    d.wpk, d.bias = pc.wpk16.data_ptr(), pc.bias.data_ptr()
+    d.res, d.res_sn, d.res_sh, d.res_sw = r16.ptr, r16.sn, r16.sh, r16.sw
+    d.kh = d.kw = 1
+    d.stride = 1
+    for cfg in (pc.cfg, 6):
+        d.cfg = cfg | hip.CFG_EXACT | hip.CFG_F16 | hip.CFG_RES_F16
+        assert hip.lib().vc_conv2d_nhwc(hip.stream(), ctypes.byref(d)) == -1     # VC_EINVAL
 
 
 @pytest.mark.parametrize("convention", [1, 2, 3])

@@ -41,7 +41,7 @@ def check_kernel(name, lines):
         if not t or t.startswith(";") or t.startswith("."):
             continue
         code = t.split(";")[0]
-        if in_asm and code.startswith("global_load_dwordx4"):
+        if in_asm and (code.startswith("global_load_dwordx4") or code.startswith("global_load_dwordx2")):
             dst = code.split()[1].rstrip(",")
             if not pending:
                 nload = 0

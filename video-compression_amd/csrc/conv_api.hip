@@ -191,6 +191,8 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.in_f16 = (d->cfg & VC_CFG_IN_F16) ? 1 : 0;
     a.out_f16 = (d->cfg & VC_CFG_OUT_F16) ? 1 : 0;
     if ((a.in_f16 || a.out_f16) && !f16) return VC_EINVAL;   // half-precision tensors exist on the fp16 path only
+    a.res_f16 = (d->cfg & VC_CFG_RES_F16) ? 1 : 0;
+    if (a.res_f16 && (!f16 || !d->res || (d->cfg & 0xff) != VC_CFG_PWS)) return VC_EINVAL;   // the streaming 1x1 kernel only
     a.res_first = (d->cfg & VC_CFG_RES_FIRST) ? 1 : 0;
     if (a.res_first && (!d->res || d->epi != VC_EPI_NONE || d->act == VC_ACT_SIGMOID || d->act == VC_ACT_CLAMP01)) return VC_EINVAL;
     a.cin_pad = round_up(a.Cin, f16 ? 2 * ck : ck);

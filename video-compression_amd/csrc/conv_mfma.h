@@ -84,6 +84,7 @@ struct ConvArgs {
     int in_f16, out_f16;   // fp16 path only: `in` / `out` point at half-precision tensors (strides in elements)
     int res_first;         // add the residual BEFORE the activation (plain/ReLU/LeakyReLU epilogues only)
     int tile_band;         // tile rows per band of the 2-D tile order (vc_tile_xy)
+    int res_f16;           // VC_CFG_PWS on the fp16 path only: `res` points at a half-precision tensor
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

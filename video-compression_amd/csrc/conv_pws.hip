@@ -58,6 +58,13 @@ template <int KQ_, int NT_, int PREC_> struct PwsCfg {      // PREC: 0 fp32, 1 f
     static constexpr int WAIT_RES = clamp63(2 * (NG32 - 1));
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pws_load8(const void *uniform_base, unsigned lane_off)
+{
+    f32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(v) : "v"(lane_off), "s"(uniform_base) : "memory");
+    return v;
+}
 __device__ __forceinline__ f32x4 pws_load16(const void *uniform_base, unsigned lane_off)
 {
     f32x4 v;
@@ -65,7 +72,7 @@ __device__ __forceinline__ f32x4 pws_load16(const void *uniform_base, unsigned l
     return v;
 }
 
-template <class C, bool RES> __global__ void __launch_bounds__(512, 2) conv_pws_kernel(const ConvArgs p)
+template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_kernel(const ConvArgs p)      // RES: 0 none, 1 fp32, 2 half
 {
     constexpr int KQ = C::KQ, NT = C::NT, NSUB = C::NSUB, D = C::D, NI = C::NI, QPS = C::QPS, RPQ = C::RPQ, S = C::S;
     constexpr bool F16 = C::F16;
@@ -170,7 +177,8 @@ template <class C, bool RES> __global__ void __launch_bounds__(512, 2) conv_pws_
     int slot = 0;                                     // ring slot of the sub-row being contracted
     int steps = 0;                                    // steps this wave has taken (saturates at D)
 
-    constexpr bool has_res = RES;                     // a template parameter: the residual registers must not pass through a phi
+    constexpr bool has_res = RES != 0;                // a template parameter: the residual registers must not pass through a phi
+    constexpr bool res_half = RES == 2;
     const int osz = (F16 && p.out_f16) ? 2 : 4;
     const bool half_plain = osz == 2 && !has_res && !p.chscale && (p.out_sw % 8) == 0 && (p.out_sh % 8) == 0 && (p.out_sn % 8) == 0;
     const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
@@ -179,7 +187,7 @@ template <class C, bool RES> __global__ void __launch_bounds__(512, 2) conv_pws_
     const int lane16 = lane * 16;
     const unsigned char *const res_b = reinterpret_cast<const unsigned char *>(p.res);
     unsigned char *const out_b = reinterpret_cast<unsigned char *>(p.out);
-    const int out_pix_bytes = (int)p.out_sw * osz, res_pix_bytes = (int)p.res_sw * 4;
+    const int out_pix_bytes = (int)p.out_sw * osz, res_pix_bytes = (int)p.res_sw * (res_half ? 2 : 4);
 
     for (unsigned tile = gw; tile < ntiles; tile += gstride) {
         const Loc tl = locate(tile);
@@ -193,6 +201,7 @@ template <class C, bool RES> __global__ void __launch_bounds__(512, 2) conv_pws_
 #pragma unroll
             for (int j = 0; j < 2; ++j) pxc[part][j] = min(part * 16 + 8 * j + rpx, wlim);
         f32x4 rv[C::NG32][2];
+        f32x2 rvh[C::NG32][2];                    // a half-precision residual: 4 halves per lane and load
         // ---- accumulators start at the bias ----
         f32x16 acc[NT];
 #pragma unroll
@@ -227,12 +236,16 @@ template <class C, bool RES> __global__ void __launch_bounds__(512, 2) conv_pws_
             issue_dma();
             if constexpr (s == NSUB - 1 && has_res) {
                 // residual of this tile: requested behind the tile's last refill, used in the epilogue (see PwsCfg)
-                const unsigned char *rbase = res_b + ((long long)tl.img * p.res_sn + (long long)tl.y * p.res_sh + (long long)tl.x0 * p.res_sw) * 4;
+                const unsigned char *rbase =
+                    res_b + ((long long)tl.img * p.res_sn + (long long)tl.y * p.res_sh + (long long)tl.x0 * p.res_sw) * (res_half ? 2 : 4);
 #pragma unroll
                 for (int g = 0; g < C::NG32; ++g)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        rv[g][j] = pws_load16(rbase, (unsigned)(pxc[g & 1][j] * res_pix_bytes + ((g >> 1) * 32 + 4 * rq) * 4));
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned off = (unsigned)(pxc[g & 1][j] * res_pix_bytes + ((g >> 1) * 32 + 4 * rq) * (res_half ? 2 : 4));
+                        if constexpr (res_half) rvh[g][j] = pws_load8(rbase, off);
+                        else rv[g][j] = pws_load16(rbase, off);
+                    }
             }
             if constexpr (!F16) {
                 // fp32: a weight fragment feeds four 64-cycle MFMAs; fetch fragment f+1 while fragment f is consumed (left to
@@ -314,9 +327,14 @@ template <class C, bool RES> __global__ void __launch_bounds__(512, 2) conv_pws_
         } else {
             static_for<0, C::NG32>([&](auto gc) {
                 constexpr int g = decltype(gc)::value, t = g >> 1, part = g & 1;
-                // (no register operand on this wait: a tied operand invites a copy of the in-flight registers in FRONT of it;
-                //  every use below also needs a value read from LDS behind the wait, so none can move above it)
-                if constexpr (has_res) vc_wait_vmcnt<C::WAIT_RES>();
+                // (no register operand on the wait itself: a tied operand invites a copy of the in-flight registers in FRONT of
+                //  it.  The empty statement BEHIND it takes them instead: asm volatile statements keep their order, a copy made
+                //  for its operands sits between the two, and every use below depends on its result.)
+                if constexpr (has_res) {
+                    vc_wait_vmcnt<C::WAIT_RES>();
+                    if constexpr (res_half) asm volatile("" : "+v"(rvh[g][0]), "+v"(rvh[g][1]));
+                    else asm volatile("" : "+v"(rv[g][0]), "+v"(rv[g][1]));
+                }
                 const int row = ((n >> 4) == part) ? (n & 15) : 16;
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
@@ -326,11 +344,18 @@ template <class C, bool RES> __global__ void __launch_bounds__(512, 2) conv_pws_
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x4 v = *reinterpret_cast<const f32x4 *>(scr + (8 * j + rpx) * (VC_EPI_ROWF * 4) + rq * 16);
-                    if constexpr (has_res) { if (p.res_first) v += rv[g][j]; }
+                    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (res_half) {
+                        const f16x4 rh = __builtin_bit_cast(f16x4, rvh[g][j]);
+                        r = f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                    } else if constexpr (has_res) {
+                        r = rv[g][j];
+                    }
+                    if constexpr (has_res) { if (p.res_first) v += r; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
                     if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(lds8 + C::GAIN_OFF + (t * 32 + 4 * rq) * 4);
-                    if constexpr (has_res) { if (!p.res_first) v += rv[g][j]; }
+                    if constexpr (has_res) { if (!p.res_first) v += r; }
                     unsigned char *dst = obase + (pxc[part][j] * out_pix_bytes + (t * 32 + 4 * rq) * osz);
                     if (osz == 2) {
                         const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -345,7 +370,7 @@ template <class C, bool RES> __global__ void __launch_bounds__(512, 2) conv_pws_
     vc_wait_vmcnt<0>();
 }
 
-template <class C, bool RES> int launch_pws_res(hipStream_t st, const ConvArgs &a)
+template <class C, int RES> int launch_pws_res(hipStream_t st, const ConvArgs &a)
 {
     auto kern = conv_pws_kernel<C, RES>;
     static vc_lds_raised raised;
@@ -358,7 +383,11 @@ template <class C, bool RES> int launch_pws_res(hipStream_t st, const ConvArgs &
 
 template <class C> int launch_pws(hipStream_t st, const ConvArgs &a)
 {
-    return a.res ? launch_pws_res<C, true>(st, a) : launch_pws_res<C, false>(st, a);
+    if (!a.res) return launch_pws_res<C, 0>(st, a);
+    if constexpr (C::F16) {
+        if (a.res_f16) return launch_pws_res<C, 2>(st, a);
+    }
+    return a.res_f16 ? VC_EINVAL : launch_pws_res<C, 1>(st, a);
 }
 
 template <int KQ, int PREC> int by_nt(hipStream_t st, const ConvArgs &a)

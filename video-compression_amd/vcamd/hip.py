@@ -289,6 +289,7 @@ CFG_F16 = 0x200
 CFG_IN_F16 = 0x400
 CFG_OUT_F16 = 0x800
 CFG_RES_FIRST = 0x1000
+CFG_RES_F16 = 0x2000        # fp16 path, VC_CFG_PWS only: `res` is a half-precision tensor (the identity path of a bottleneck chain)
 CFG_DMA = 8               # fp16 path: LDS-DMA pipeline, one persistent workgroup per CU (csrc/conv_dma.h); half-precision input only
 CFG_PWS = 9               # streaming 1x1 kernel with LDS-DMA activation rings (csrc/conv_pws.hip)
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
@@ -300,6 +301,10 @@ _PRECISION = os.environ.get("VC_CONV_PRECISION", "fp32")
 # fp16 path only: keep activations whose sole consumers are fp16-path convolutions as half in HBM (bit-identical
 # results, see VC_CFG_OUT_F16); VC_HALF_ACTIVATIONS=0 stores them as fp32 like every other tensor (A/B, tests).
 HALF_ACTIVATIONS = bool(int(os.environ.get("VC_HALF_ACTIVATIONS", "1")))
+# fp16 path only: keep the identity path of a chain of bottleneck blocks (x + f(x) per block, ICIP2024/src/model/elic.py:69-83)
+# as half in HBM too.  NOT bit-neutral (one more rounding of the identity per block; VC_CFG_RES_F16): part of the fp16 mode's
+# stated tolerance.  VC_HALF_RESIDUAL=0 keeps the identity fp32 (A/B, tests).
+HALF_RESIDUAL = bool(int(os.environ.get("VC_HALF_RESIDUAL", "1")))
 
 
 def set_conv_precision(mode):
@@ -371,6 +376,8 @@ class PackedConv:
     def _pick_cfg(self, d, key, flags=0):
         if key in self.tuned:
             return self.tuned[key]
+        if flags & CFG_RES_F16:                       # only the streaming 1x1 kernel reads a half-precision residual
+            return CFG_PWS | CFG_EXACT | flags
         cands = self.candidates
         if flags & CFG_F16 and 5 in cands:
             cands = [c for c in cands if c != 0]     # the 4x1 128-channel fp16 instance spills registers
@@ -405,6 +412,12 @@ class PackedConv:
         """True when this layer runs on the fp16 path and can therefore read a half-precision activation."""
         return self.wpk16 is not None
 
+    @property
+    def half_res_ok(self):
+        """True when this layer can add a HALF-precision residual (fp16 path, streaming 1x1 kernel): the last layer of a
+        bottleneck block whose identity path is kept as half (see VC_CFG_RES_F16 in include/vc_hip.h)."""
+        return self.wpk16 is not None and CFG_PWS in self.candidates
+
     def __call__(self, x, out=None, act=ACT_NONE, slope=0.01, res=None, epi=EPI_NONE, mul=None,
                  in_xform=IN_NONE, chscale=None, out_f16=False, res_first=False):
         """``out_f16``: a hint that every consumer of the result is an fp16-path convolution (``half_ok``), so the
@@ -425,6 +438,9 @@ class PackedConv:
         d = ConvDesc()
         d.inp, d.out = x.view(True), out.view(True)
         d.wpk, d.bias = self.wpk.data_ptr(), self.bias.data_ptr()
+        res_half = res is not None and res.dtype == "f16"
+        if res_half and not (use16 and self.half_res_ok and epi == EPI_NONE and act < ACT_SIGMOID):
+            raise VcError("a half-precision residual needs the fp16 path's streaming 1x1 kernel (PackedConv.half_res_ok)")
         if res is not None:
             d.res, d.res_sn, d.res_sh, d.res_sw = res.ptr, res.sn, res.sh, res.sw
         if mul is not None:
@@ -440,7 +456,7 @@ class PackedConv:
         flags = CFG_RES_FIRST if res_first else 0        # out = act(conv + res) instead of act(conv) + res
         if use16:
             d.wpk = self.wpk16.data_ptr()
-            flags |= CFG_F16 | (CFG_IN_F16 if half_in else 0) | (CFG_OUT_F16 if half_out else 0)
+            flags |= CFG_F16 | (CFG_IN_F16 if half_in else 0) | (CFG_OUT_F16 if half_out else 0) | (CFG_RES_F16 if res_half else 0)
         # (the tuned choice is per shape AND per epilogue class: the streaming 1x1 kernel, for one, takes plain / ReLU /
         #  GDN epilogues but not sigmoid or clamp, so a layer called both ways must not share one entry)
         key = (x.n, x.h, x.w, flags) if (act < ACT_SIGMOID and epi == EPI_NONE) else (x.n, x.h, x.w, flags, act, epi)
@@ -454,7 +470,7 @@ class PackedConv:
             key = f"conv k{self.k} s{self.stride} {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
             nbytes = (x.n * x.h * x.w * self.cin * (2 if half_in else 4) + x.n * ho * wo * co * (2 if half_out else 4)
                       + self.cout * self.cin * self.k * self.k * (2 if use16 else 4)
-                      + (x.n * ho * wo * co * 4 if res is not None else 0) + (x.n * ho * wo * co * 4 if mul is not None else 0))
+                      + (x.n * ho * wo * co * (2 if res_half else 4) if res is not None else 0) + (x.n * ho * wo * co * 4 if mul is not None else 0))
             timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
         return out
 

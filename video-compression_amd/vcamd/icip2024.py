@@ -50,14 +50,25 @@ class ResidualBottleneckBlock(_Prepared):
         self.BottleneckBlock = nn.Sequential(conv1x1(in_ch, out_ch), nn.ReLU(inplace=True), conv3x3(out_ch, out_ch),
                                              nn.ReLU(inplace=True), conv1x1(out_ch, out_ch))
 
-    def run(self, x, out=None):
+    def _pack(self):
         if self._packed is None:
             b = self.BottleneckBlock
             self._packed = (pack_conv(b[0]), pack_conv(b[2]), pack_conv(b[4]))
-        c1, c2, c3 = self._packed
+        return self._packed
+
+    def half_stream_ok(self):
+        """fp16 path: the block can take its input -- first layer's operand AND the identity -- as a half-precision tensor
+        and hand its result on as one (hip.HALF_RESIDUAL; the streaming 1x1 kernel adds the half identity)."""
+        c1, c2, c3 = self._pack()
+        return hip.HALF_RESIDUAL and hip.HALF_ACTIVATIONS and c1.half_ok and c2.half_ok and c3.half_res_ok and c3.cout % 8 == 0
+
+    def run(self, x, out=None, out_f16=False):
+        c1, c2, c3 = self._pack()
+        if x.dtype == "f16" and not self.half_stream_ok():
+            raise hip.VcError("a half-precision tensor reached a bottleneck block that keeps its identity path in fp32")
         t = c1(x, act=hip.ACT_RELU, out_f16=c2.half_ok)        # both intermediates feed one convolution each:
         t = c2(t, act=hip.ACT_RELU, out_f16=c3.half_ok)        # half-precision storage on the fp16 path
-        return c3(t, res=x, out=out)
+        return c3(t, res=x, out=out, out_f16=bool(out_f16 and out is None and self.half_stream_ok()))
 
 
 def _rbb(c, n=3):

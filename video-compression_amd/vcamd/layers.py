@@ -215,6 +215,15 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
                 return None
         return packed[key]
 
+    def takes_half(m):
+        """May the member's input live in HBM as half (fp16 path)?"""
+        if hasattr(m, "half_stream_ok"):
+            return m.half_stream_ok()
+        if isinstance(m, (ResidualBlock, ResidualBlockWithStride, ResidualBlockUpsample, GDN)) or getattr(m, "vc_block", False):
+            return False
+        pk = pack_of(m)
+        return pk is not None and pk.half_ok
+
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -222,7 +231,12 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
         if isinstance(m, (ResidualBlock, ResidualBlockWithStride, ResidualBlockUpsample, GDN)) or getattr(m, "vc_block", False):
             if last and (final_chscale is not None or final_act is not None):
                 raise hip.VcError("a block cannot take the sequence's final gain/activation")
-            x = m.run(x, out=out) if (last and out is not None) else m.run(x)
+            if last and out is not None:
+                x = m.run(x, out=out)
+            elif hasattr(m, "half_stream_ok") and not last and takes_half(mods[i + 1]):
+                x = m.run(x, out_f16=True)                # the next member reads (and, a block, adds) it as half
+            else:
+                x = m.run(x)
             i += 1
             continue
         pk = pack_of(m)
@@ -236,13 +250,10 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
             last = i == len(mods) - 1
         if last and final_act is not None:
             act = final_act
-        # a result consumed by the next convolution alone may be kept as half on the fp16 path
-        nxt_pk = None
-        if not last and not isinstance(mods[i + 1], (ResidualBlock, ResidualBlockWithStride, ResidualBlockUpsample, GDN)) \
-                and not getattr(mods[i + 1], "vc_block", False):
-            nxt_pk = pack_of(mods[i + 1])
+        # a result consumed by the next convolution alone (or by a bottleneck block that keeps its identity as half) may be
+        # kept as half on the fp16 path
         x = pk(x, act=act, slope=slope, chscale=final_chscale if last else None, out=out if last else None,
-               out_f16=bool(nxt_pk is not None and nxt_pk.half_ok))
+               out_f16=bool(not last and takes_half(mods[i + 1])))
         i += 1
     return x
 
