@@ -117,7 +117,7 @@ def test_half_precision_identity_path_of_bottleneck_chains(dev):
     between the blocks on the fp16 path.  Not bit-neutral -- one more rounding of the identity per block -- so: it must be
     IN USE (half residuals reach the streaming kernel), and what it changes must stay inside the fp16 mode's own distance
     from the fp32 path (measured on this frame, seeded weights: max |d| of the reconstruction 0.47 against 0.45 for fp16 vs
-    fp32 -- both are single flipped symbols of the quantiser, not drift; estimated size 827 067 vs 827 094 vs 827 137 bits)."""
+    fp32 -- both are single flipped symbols of the quantiser, not drift; estimated size 827 046 vs 827 094 vs 827 137 bits)."""
     from vcamd import hip, icip2024
     from vcamd.seeding import seeded_state_dict
     fx = load_fixture("lhbdc_forward_a.npz")

@@ -130,9 +130,11 @@ class _Seq(_Prepared):
                                             stride=first.stride[0], device=first.weight.device))
                 c0 += c
             cache[key] = packs
+        # (fp16 path: when a bottleneck chain follows, the LAST partial sum is the chain's input and leaves as half)
+        half_tail = len(mods) > 1 and hasattr(mods[1], "half_stream_ok") and mods[1].half_stream_ok()
         acc = None
-        for pk, part in zip(cache[key], parts):
-            acc = pk(part, res=acc)
+        for i, (pk, part) in enumerate(zip(cache[key], parts)):
+            acc = pk(part, res=acc, out_f16=bool(half_tail and i == len(parts) - 1))
         return run_sequential(nn.Sequential(*mods[1:]), acc, self._caches.setdefault(name + ":tail", {}), **kw)
 
 
