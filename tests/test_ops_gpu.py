@@ -158,6 +158,8 @@ DMA_CASES = [  # cin, cout, k, n, h, w, classic tile configs to compare with
     (128, 128, 3, 1, 40, 72, (5, 1)), (128, 128, 3, 3, 17, 33, (5,)), (64, 32, 7, 2, 50, 70, (7, 2)), (32, 64, 7, 1, 34, 60, (1, 2)),
     (64, 128, 3, 1, 33, 31, (5,)), (256, 128, 3, 1, 16, 40, (1, 5)), (128, 512, 3, 1, 17, 30, (5,)), (192, 128, 3, 2, 20, 36, (5,)),
     (128, 128, 3, 2, 160, 288, (5,)),
+    # more than 128 output channels that are not a multiple of 128: the last block of 128 is partly padding
+    (128, 432, 3, 1, 20, 40, (5, 0)), (64, 208, 3, 2, 17, 33, (5, 0)),
 ]
 
 

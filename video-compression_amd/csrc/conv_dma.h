@@ -535,7 +535,8 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         } else {
             const bool fast = !(C::KO & 16384) && p.out_f16 && !p.res && !p.chscale && p.out_mode == VC_OUT_PLAIN &&
                               (p.act == VC_ACT_NONE || p.act == VC_ACT_RELU || (p.act == VC_ACT_LRELU && p.slope >= 0.0f && p.slope <= 1.0f)) &&
-                              cur.oy0 + C::TH <= p.Ho && cur.ox0 + C::TW <= p.Wo && (p.out_sw & 7) == 0 && (p.out_sh & 7) == 0 &&
+                              cur.oy0 + C::TH <= p.Ho && cur.ox0 + C::TW <= p.Wo && (cur.nblk + 1) * C::BN <= p.Cout &&
+                              (p.out_sw & 7) == 0 && (p.out_sh & 7) == 0 &&
                               (p.out_sn & 7) == 0;
             if (fast)
                 dma_epilogue_fast<C>(p, acc, cur.nblk, wm, wn, lane, cur.oy0, cur.ox0, cur.img,

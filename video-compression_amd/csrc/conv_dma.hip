@@ -14,11 +14,14 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
 {
     if (stride != 1 || !dma_views_ok(a) || (a.Cin & 31)) return VC_EINVAL;
     const int nchunk = a.Cin / 32;
-    const int nt = (a.Cout % 128 == 0) ? 4 : (a.Cout == 64 ? 2 : (a.Cout == 32 ? 1 : 0));
-    if (!nt) return VC_EINVAL;
+    // more than 128 output channels: blocks of 128, the last one partly padding (the packing of VC_CFG_N128 / N128B pads the
+    // weights and the bias to a multiple of 128 with zeros; the caller names this configuration only on such a packing)
+    const int nt = (a.Cout >= 128) ? 4 : (a.Cout == 64 ? 2 : (a.Cout == 32 ? 1 : 0));
+    if (!nt || (a.Cout % 4)) return VC_EINVAL;
     a.tiles_x = (a.Wo + 31) / 32;
     a.tiles_y = (a.Ho + 15) / 16;
-    a.nblks = a.Cout / (32 * nt);
+    a.nblks = (a.Cout + 32 * nt - 1) / (32 * nt);
+    if (a.nblks * 32 * nt != a.Cout && a.out_mode != VC_OUT_PLAIN) return VC_EINVAL;
     a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
     if (k == 3) {
         if (nt == 4 && nchunk == 4) {
