@@ -582,6 +582,27 @@ def test_streaming_kernel_half_precision_residual(dev, cin, cout, h, w, n):
         assert hip.lib().vc_conv2d_nhwc(hip.stream(), ctypes.byref(d)) == -1     # VC_EINVAL
 
 
+def test_pointwise_chain_padding_does_not_change_a_bit(dev):
+    """run_sequential pads the odd intermediate channel counts of a chain of 1x1 convolutions (ICIP2024's entropy-parameter
+    networks, 768 -> 426 -> 341 -> 2c) to multiples of 16 with zero weights: aligned rows for the consumer, and -- adding
+    zeros -- the very same fp32 results as the unpadded chain."""
+    import torch.nn as nn
+    from vcamd import hip
+    from vcamd.layers import run_sequential
+    torch.manual_seed(5)
+    seq = nn.Sequential(nn.Conv2d(96, 42, 1), nn.LeakyReLU(inplace=True), nn.Conv2d(42, 37, 1), nn.LeakyReLU(inplace=True),
+                        nn.Conv2d(37, 12, 1)).to(dev)
+    x = hip.nchw_to_nhwc(_rand((2, 96, 19, 45), 71).to(dev))
+    padded_cache, plain_cache = {}, {"pads": {}}
+    a = run_sequential(seq, x, padded_cache)
+    b = run_sequential(seq, x, plain_cache)
+    assert sorted(padded_cache["pads"].values()) == [(0, 6), (6, 11), (11, 0)]
+    assert [p.cout for p in padded_cache["seq"].values()] == [48, 48, 12] and [p.cout for p in plain_cache["seq"].values()] == [42, 37, 12]
+    assert a.c == 12 and torch.equal(hip.nhwc_to_nchw(a), hip.nhwc_to_nchw(b))
+    ref = seq(hip.nhwc_to_nchw(x))
+    _close(hip.nhwc_to_nchw(a).cpu(), ref.cpu(), 2e-5, "padded 1x1 chain vs torch")
+
+
 @pytest.mark.parametrize("convention", [1, 2, 3])
 def test_warp_feature_maps_vectorised(dev, convention):
     """multi-channel feature maps (ICIP2024 warps 64/96/128-channel pyramids) take the 16-byte path; it must give

@@ -200,6 +200,28 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
         cache["seq"] = {}
     packed = cache["seq"]
 
+    # Chains of 1x1 convolutions with only (Leaky)ReLU between them (the entropy-parameter networks of ICIP2024:
+    # 768 -> 426 -> 341 -> 2c, compression_bottlenecks.py:72-551): an intermediate channel count like 426 makes every pixel row
+    # of the tensor between two layers unaligned (1704 bytes) and keeps the consumer off the 16-byte staging path and the
+    # fp16 path.  The intermediate is padded to a multiple of 16 channels with zero weights / zero bias on the producer
+    # and zero weights on the consumer: (Leaky)ReLU(0) = 0 and x + 0 * w = x, so no result bit changes.
+    if "pads" not in cache:
+        def pointwise(m):
+            return (isinstance(m, nn.Conv2d) and tuple(m.kernel_size) == (1, 1) and tuple(m.stride) == (1, 1) and m.groups == 1
+                    and getattr(m, "mask", None) is None)
+        pads, prev = {}, None
+        for idx, m in enumerate(mods):
+            if pointwise(m):
+                if prev is not None and (-mods[prev].out_channels) % 16:
+                    pad = (-mods[prev].out_channels) % 16
+                    pads[id(mods[prev])] = (pads.get(id(mods[prev]), (0, 0))[0], pad)
+                    pads[id(m)] = (pad, 0)
+                prev = idx
+            elif not isinstance(m, (nn.ReLU, nn.LeakyReLU)):
+                prev = None
+        cache["pads"] = pads
+    pads = cache["pads"]
+
     def pack_of(m):
         """PackedConv of a Conv2d / ConvTranspose2d / subpel Sequential member (None for anything else)."""
         is_subpel = isinstance(m, nn.Sequential)
@@ -209,6 +231,14 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
             if isinstance(conv, nn.ConvTranspose2d):
                 w3, b3 = deconv_as_subpel_weights(conv)
                 packed[key] = hip.PackedConv(w3, b3, stride=1, pixelshuffle=True, device=conv.weight.device)
+            elif isinstance(conv, nn.Conv2d) and key in pads:
+                pi, po = pads[key]
+                w = torch.zeros(conv.out_channels + po, conv.in_channels + pi, 1, 1)
+                w[:conv.out_channels, :conv.in_channels] = conv.weight.detach().to("cpu", torch.float32)
+                b = torch.zeros(conv.out_channels + po)
+                if conv.bias is not None:
+                    b[:conv.out_channels] = conv.bias.detach().to("cpu", torch.float32)
+                packed[key] = hip.PackedConv(w, b, stride=1, device=conv.weight.device)
             elif isinstance(conv, nn.Conv2d):
                 packed[key] = pack_conv(conv, pixelshuffle=is_subpel)
             else:
