@@ -215,6 +215,13 @@ int vc_deform_conv2d(vc_stream s, vc_view in, vc_view offset, vc_view mask, cons
  * the rest x2.  raw_r [n,h,w,27*G/2], flow_r [n,h,w,2] = (u,v), x_r [n,h,w,(G/2)*cg], out [n,h,w,G*og]. */
 int vc_offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2,
                         float magnitude, const float *wpk, const float *bias, int groups, vc_view out);
+/* fp16 path: the same with HALF-precision features -- x1.p / x2.p point at _Float16 tensors (strides in elements), as
+ * vc_to_half writes them.  The deformable fusion (helpers.py:35-58) is bound by its gathers; half features halve them.
+ * 8 or 16 channels per group; offsets, modulation, bilinear weights and accumulation stay fp32. */
+int vc_offset_diversity_hx(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2,
+                        float magnitude, const float *wpk, const float *bias, int groups, vc_view out);
+/* Dense half-precision copy [n,h,w,c] of a channels-last window (c % 4 == 0), round to nearest even. */
+int vc_to_half(vc_stream s, vc_view a, void *out_half);
 
 /* Gate of compressai.layers.AttentionBlock (ELIC intra codec of ICIP2024, src/model/elic.py:97-121):
  * out = a * sigmoid(b) + identity. */

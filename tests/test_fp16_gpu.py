@@ -82,6 +82,7 @@ def test_half_precision_activations_do_not_change_a_bit(dev):
     }
     hip.set_conv_precision("fp16")
     hip.HALF_RESIDUAL = False          # (the half-precision identity path is NOT bit-neutral: its own test below)
+    hip.HALF_DEFORM = False            # (nor are half-precision features under the deformable gather: test_icip2024_gpu.py)
     try:
         for name, (build, run) in builders.items():
             m = build()
@@ -109,6 +110,7 @@ def test_half_precision_activations_do_not_change_a_bit(dev):
     finally:
         hip.HALF_ACTIVATIONS = True
         hip.HALF_RESIDUAL = True
+        hip.HALF_DEFORM = True
         hip.set_conv_precision("fp32")
 
 

@@ -81,6 +81,41 @@ def test_offset_diversity_matches_oracle(dev, c, mag):
     assert ((out - ref).abs() / (1 + ref.abs()))[ok].max().item() < 5e-5
 
 
+@pytest.mark.parametrize("c,mag", [(64, 40), (96, 20), (128, 10)])
+def test_offset_diversity_half_precision_features(dev, c, mag):
+    """fp16 path (hip.HALF_DEFORM, vc_offset_diversity_hx): the fusion gathers from half-precision copies of its feature maps
+    -- the fp32 kernel's result on features that were rounded to half beforehand (offsets, modulation, bilinear weights and
+    accumulation stay fp32), up to the compiler's choice of fused multiply-adds in the two instances: 1e-6 relative, 500x
+    below one half-precision rounding; 8, 12 and 16 channels per group (12: a 16-byte and an 8-byte gather per corner)."""
+    from vcamd import hip, icip2024
+    g = torch.Generator().manual_seed(c + 1)
+    h, w, n = 27, 44, 2
+    prod = icip2024.OffsetDiversity(c, mag)
+    with torch.no_grad():
+        prod.fusion.weight.copy_(torch.randn(prod.fusion.weight.shape, generator=g) * 0.2)
+        prod.fusion.bias.copy_(torch.randn(c, generator=g))
+    prod = prod.to(dev)
+    x1, x2 = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+    o1, o2 = torch.randn(n, 216, h, w, generator=g), torch.randn(n, 216, h, w, generator=g)
+    f1, f2 = torch.randn(n, 2, h, w, generator=g) * 3, torch.randn(n, 2, h, w, generator=g) * 3
+    rest = [_nhwc(t, dev) for t in (o1, f1, o2, f2)]
+    calls = []
+    orig = hip.to_half
+    hip.to_half = lambda t: (calls.append(t.c), orig(t))[1]
+    try:
+        ref = hip.nhwc_to_nchw(prod.run(_nhwc(x1.half().float(), dev), rest[0], rest[1], _nhwc(x2.half().float(), dev), rest[2], rest[3]))
+        assert not calls                                        # fp32 precision: fp32 features
+        hip.set_conv_precision("fp16")
+        out = hip.nhwc_to_nchw(prod.run(_nhwc(x1, dev), rest[0], rest[1], _nhwc(x2, dev), rest[2], rest[3]))
+        assert calls == [c, c]
+    finally:
+        hip.to_half = orig
+        hip.set_conv_precision("fp32")
+    d = ((out - ref).abs() / (1 + ref.abs())).max().item()
+    print(f"c={c}: max relative difference {d:.2e}")
+    assert d < 1e-6
+
+
 def test_quantize_mask(dev):
     from vcamd import hip
     g = torch.Generator().manual_seed(1)

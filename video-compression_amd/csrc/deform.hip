@@ -17,6 +17,7 @@ struct DeformArgs {
     const float *wpk, *bias;
     float magnitude;
     int groups;
+    int x_half;            // fp16 path: x1 / x2 point at half-precision features (strides in elements)
 };
 
 // One workgroup = one 8x8 pixel tile x all G/2 groups of ONE reference (wave w <-> group w of that half): the
@@ -25,7 +26,7 @@ struct DeformArgs {
 // by the workgroup.  Lanes of a wave are the 64 pixels of the tile, so the group (and its weights) is wave-uniform.
 // MAXT: 512 when the half has at most 8 groups (the ICIP2024 model: 16 groups) -- leaves the register file for the batched
 // gathers; 1024 (up to 16 groups per half) keeps 128 registers and gathers one tap at a time.
-template <int CG, int OG, bool FUSED, bool VEC, int RV = 1, int MAXT = 1024>
+template <int CG, int OG, bool FUSED, bool VEC, int RV = 1, int MAXT = 1024, bool XH = false>
 __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
 {
     extern __shared__ float wsm_all[];
@@ -101,14 +102,17 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
         fu = fp[0];
         fv = fp[1];
     }
-    const float *xbase = X.p + (long long)n * X.sn + gl * CG;
+    // (XH: half-precision features -- a group's CG channels of a pixel are CG / 8 gathers of 16 bytes instead of CG / 4; the
+    //  kernel is bound by the gathers, every lane of an instruction in a different 128-byte line, so that halves it)
+    constexpr int ESZ = XH ? 2 : 4;
+    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(X.p) + ((long long)n * X.sn + gl * CG) * ESZ;
 
     // One tap's sampling geometry.  Nothing below sits under a branch: a corner (or a whole tap) outside the image gets
     // its address clamped into the image and its VALUE replaced by zero after the load, so the 4 * CG / 4 gathers of all
     // taps of a batch are issued back to back and their L2 round trips overlap.  (With the loads under `if`s the compiler
     // waited for each of them in turn: ~45 dependent round trips per wave, 53 us per workgroup at 1088x1920.)
     struct Tap {
-        const float *p1, *p2, *p3, *p4;
+        const unsigned char *p1, *p2, *p3, *p4;
         float w1, w2, w3, w4, m;
         bool ok, tl, tr, bl, br;
     };
@@ -132,14 +136,16 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
         q.w1 = hh * hw, q.w2 = hh * lw, q.w3 = lh * hw, q.w4 = lh * lw;
         const bool t = y0 >= 0, b = y1 <= H - 1, l = x0 >= 0, r = x1 <= W - 1;
         q.tl = q.ok && t && l, q.tr = q.ok && t && r, q.bl = q.ok && b && l, q.br = q.ok && b && r;
-        const long long r0 = (long long)max(y0, 0) * X.sh, r1 = (long long)min(y1, H - 1) * X.sh;
-        const long long c0 = (long long)max(x0, 0) * X.sw, c1 = (long long)min(x1, W - 1) * X.sw;
+        const long long r0 = (long long)max(y0, 0) * X.sh * ESZ, r1 = (long long)min(y1, H - 1) * X.sh * ESZ;
+        const long long c0 = (long long)max(x0, 0) * X.sw * ESZ, c1 = (long long)min(x1, W - 1) * X.sw * ESZ;
         q.p1 = xbase + r0 + c0, q.p2 = xbase + r0 + c1, q.p3 = xbase + r1 + c0, q.p4 = xbase + r1 + c1;
         return q;
     };
     if constexpr (VEC) {
         constexpr int TB = (MAXT > 512 || CG > 8) ? 1 : 3;       // taps per batch (divides 9): 12-24 16-byte gathers in flight per lane
-        constexpr int V = CG / 4;
+        constexpr int V = XH ? (CG + 7) / 8 : CG / 4;            // gathers per corner: 16 bytes each; XH with CG % 8 == 4: the last one 8 bytes
+        constexpr int EPV = XH ? 8 : 4;                          // channels per gather
+        constexpr bool TAIL8 = XH && (CG % 8) == 4;
 #pragma unroll 1
         for (int k0 = 0; k0 < 9; k0 += TB) {     // (rolled: unrolled, the compiler hoists all 9 * CG * OG weight reads and spills)
             Tap q[TB];
@@ -149,10 +155,17 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
                 q[j] = tap(k0 + j);
 #pragma unroll
                 for (int c = 0; c < V; ++c) {
-                    v[j][0][c] = *reinterpret_cast<const f32x4 *>(q[j].p1 + 4 * c);
-                    v[j][1][c] = *reinterpret_cast<const f32x4 *>(q[j].p2 + 4 * c);
-                    v[j][2][c] = *reinterpret_cast<const f32x4 *>(q[j].p3 + 4 * c);
-                    v[j][3][c] = *reinterpret_cast<const f32x4 *>(q[j].p4 + 4 * c);
+                    if (TAIL8 && c == V - 1) {
+                        const float2 t1 = *reinterpret_cast<const float2 *>(q[j].p1 + 16 * c), t2 = *reinterpret_cast<const float2 *>(q[j].p2 + 16 * c);
+                        const float2 t3 = *reinterpret_cast<const float2 *>(q[j].p3 + 16 * c), t4 = *reinterpret_cast<const float2 *>(q[j].p4 + 16 * c);
+                        v[j][0][c] = f32x4{t1.x, t1.y, 0.f, 0.f}, v[j][1][c] = f32x4{t2.x, t2.y, 0.f, 0.f};
+                        v[j][2][c] = f32x4{t3.x, t3.y, 0.f, 0.f}, v[j][3][c] = f32x4{t4.x, t4.y, 0.f, 0.f};
+                    } else {
+                        v[j][0][c] = *reinterpret_cast<const f32x4 *>(q[j].p1 + 16 * c);
+                        v[j][1][c] = *reinterpret_cast<const f32x4 *>(q[j].p2 + 16 * c);
+                        v[j][2][c] = *reinterpret_cast<const f32x4 *>(q[j].p3 + 16 * c);
+                        v[j][3][c] = *reinterpret_cast<const f32x4 *>(q[j].p4 + 16 * c);
+                    }
                 }
             }
 #pragma unroll
@@ -161,14 +174,22 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
 #pragma unroll
                 for (int c = 0; c < V; ++c) {
                     const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                    const f32x4 v1 = q[j].tl ? v[j][0][c] : z, v2 = q[j].tr ? v[j][1][c] : z;
+                    const f32x4 v1 = q[j].tl ? v[j][0][c] : z, v2 = q[j].tr ? v[j][1][c] : z;      // (half +0.0 == fp32 +0.0 bit pattern 0)
                     const f32x4 v3 = q[j].bl ? v[j][2][c] : z, v4 = q[j].br ? v[j][3][c] : z;
+                    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < ((TAIL8 && c == V - 1) ? 4 : EPV); ++e) {
+                        float e1, e2, e3, e4;
+                        if constexpr (XH) {
+                            e1 = (float)__builtin_bit_cast(h8, v1)[e], e2 = (float)__builtin_bit_cast(h8, v2)[e];
+                            e3 = (float)__builtin_bit_cast(h8, v3)[e], e4 = (float)__builtin_bit_cast(h8, v4)[e];
+                        } else {
+                            e1 = v1[e < 4 ? e : 0], e2 = v2[e < 4 ? e : 0], e3 = v3[e < 4 ? e : 0], e4 = v4[e < 4 ? e : 0];
+                        }
                         // (a tap outside the image contributes nothing, whatever its modulation value)
-                        const float val = q[j].ok ? (q[j].w1 * v1[e] + q[j].w2 * v2[e] + q[j].w3 * v3[e] + q[j].w4 * v4[e]) * q[j].m : 0.0f;
+                        const float val = q[j].ok ? (q[j].w1 * e1 + q[j].w2 * e2 + q[j].w3 * e3 + q[j].w4 * e4) * q[j].m : 0.0f;
 #pragma unroll
-                        for (int o = 0; o < OG; ++o) acc[o] = fmaf(wk[(4 * c + e) * OG + o], val, acc[o]);
+                        for (int o = 0; o < OG; ++o) acc[o] = fmaf(wk[(EPV * c + e) * OG + o], val, acc[o]);
                     }
                 }
             }
@@ -181,8 +202,10 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
             const float *wk = wsm + k * CG * OG;
 #pragma unroll
             for (int c = 0; c < CG; ++c) {
-                const float v1 = q.tl ? q.p1[c] : 0.0f, v2 = q.tr ? q.p2[c] : 0.0f;
-                const float v3 = q.bl ? q.p3[c] : 0.0f, v4 = q.br ? q.p4[c] : 0.0f;
+                const float *f1 = reinterpret_cast<const float *>(q.p1), *f2 = reinterpret_cast<const float *>(q.p2);
+                const float *f3 = reinterpret_cast<const float *>(q.p3), *f4 = reinterpret_cast<const float *>(q.p4);
+                const float v1 = q.tl ? f1[c] : 0.0f, v2 = q.tr ? f2[c] : 0.0f;
+                const float v3 = q.bl ? f3[c] : 0.0f, v4 = q.br ? f4[c] : 0.0f;
                 const float val = (q.w1 * v1 + q.w2 * v2 + q.w3 * v3 + q.w4 * v4) * q.m;
 #pragma unroll
                 for (int o = 0; o < OG; ++o) acc[o] = fmaf(wk[c * OG + o], val, acc[o]);
@@ -220,6 +243,12 @@ template <int CG, int OG, bool FUSED> int launch(hipStream_t st, const DeformArg
             return (27 * half) % w == 0 && reinterpret_cast<uintptr_t>(v.p) % (4 * w) == 0 && v.sn % w == 0 && v.sh % w == 0 && v.sw % w == 0;
         };
         const int rv = (ok(a.off1, 4) && ok(a.off2, 4)) ? 4 : ((ok(a.off1, 2) && ok(a.off2, 2)) ? 2 : 1);
+        if (a.x_half) {             // half-precision features: the fast fused instance or nothing
+            if constexpr (CG % 4 == 0) {
+                if (vec && small && rv == 4) return launch_one(k_deform<CG, OG, true, true, 4, 512, true>);
+            }
+            return VC_EINVAL;
+        }
         if (vec && small && rv == 4) return launch_one(k_deform<CG, OG, true, true, 4, 512>);
         if (rv == 4) return vec ? launch_one(k_deform<CG, OG, true, true, 4>) : launch_one(k_deform<CG, OG, true, false, 4>);
         if (rv == 2) return vec ? launch_one(k_deform<CG, OG, true, true, 2>) : launch_one(k_deform<CG, OG, true, false, 2>);
@@ -230,7 +259,10 @@ template <int CG, int OG, bool FUSED> int launch(hipStream_t st, const DeformArg
 
 template <bool FUSED> int dispatch(hipStream_t st, const DeformArgs &a, int cg, int og)
 {
-    const bool vec = cg % 4 == 0 && aligned16(a.x1) && aligned16(a.x2);
+    // (half features: a group's 2 * cg bytes start 8-byte aligned; a 16-byte gather that is only 8-byte aligned is legal)
+    auto aligned8h = [](const vc_view &v) { return (reinterpret_cast<uintptr_t>(v.p) % 16 == 0) && v.sn % 4 == 0 && v.sh % 4 == 0 && v.sw % 4 == 0; };
+    const bool vec = a.x_half ? (cg % 4 == 0 && aligned8h(a.x1) && aligned8h(a.x2)) : (cg % 4 == 0 && aligned16(a.x1) && aligned16(a.x2));
+    if (a.x_half && !FUSED) return VC_EINVAL;
     switch (cg * 16 + og) {
     case 4 * 16 + 2: return launch<4, 2, FUSED>(st, a, vec);
     case 4 * 16 + 4: return launch<4, 4, FUSED>(st, a, vec);
@@ -283,9 +315,28 @@ extern "C" int vc_deform_conv2d(vc_stream s, vc_view in, vc_view offset, vc_view
     return dispatch<false>(as_stream(s), a, cg, og);
 }
 
+static int offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2, float magnitude,
+                            const float *wpk, const float *bias, int groups, vc_view out, int x_half);
+
 extern "C" int vc_offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2,
                                    vc_view flow2, float magnitude, const float *wpk, const float *bias, int groups,
                                    vc_view out)
+{
+    return offset_diversity(s, x1, raw1, flow1, x2, raw2, flow2, magnitude, wpk, bias, groups, out, 0);
+}
+
+// The same with HALF-precision features: x1.p / x2.p point at _Float16 tensors (strides in elements; vc_to_half makes one).
+// fp16 path only -- the gathered values are the features rounded to half, everything else (offsets, modulation, bilinear
+// weights, accumulation) stays fp32; 8 or 16 channels per group, offsets / output as in vc_offset_diversity.
+extern "C" int vc_offset_diversity_hx(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2,
+                                      vc_view flow2, float magnitude, const float *wpk, const float *bias, int groups,
+                                      vc_view out)
+{
+    return offset_diversity(s, x1, raw1, flow1, x2, raw2, flow2, magnitude, wpk, bias, groups, out, 1);
+}
+
+static int offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2, float magnitude,
+                            const float *wpk, const float *bias, int groups, vc_view out, int x_half)
 {
     if (!x1.p || !x2.p || !raw1.p || !raw2.p || !flow1.p || !flow2.p || !wpk || !out.p) return VC_EINVAL;
     if (groups < 2 || groups % 2) return VC_EINVAL;
@@ -307,5 +358,6 @@ extern "C" int vc_offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_vie
     a.bias = bias;
     a.magnitude = magnitude;
     a.groups = groups;
+    a.x_half = x_half;
     return dispatch<true>(as_stream(s), a, x1.c / half, out.c / groups);
 }

@@ -330,6 +330,35 @@ extern "C" int vc_clamp01(vc_stream s, vc_view a, vc_view out)
     return VC_OK;
 }
 
+// 4 consecutive channels per thread: 16 bytes in, 8 bytes out
+__global__ void k_to_half(vc_view a, _Float16 *__restrict__ out)
+{
+    const int c4 = a.c >> 2;
+    const long long total = (long long)a.n * a.h * a.w * c4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4) * 4;
+        long long t = i / c4;
+        const int x = (int)(t % a.w); t /= a.w;
+        const int y = (int)(t % a.h);
+        const int n = (int)(t / a.h);
+        const float4 v = *reinterpret_cast<const float4 *>(a.p + view_off(a, n, y, x) + c);
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<h4 *>(out + 4 * i) = hv;
+    }
+}
+
+// dense half-precision copy of a channels-last window (round to nearest even, what an fp16-path layer does to its input
+// while staging): the features the fp16-path deformable fusion gathers from (vc_offset_diversity_hx)
+extern "C" int vc_to_half(vc_stream s, vc_view a, void *out_half)
+{
+    if (!a.p || !out_half || (a.c % 4) || (a.sw % 4) || (a.sh % 4) || (a.sn % 4) || ((uintptr_t)a.p % 16) || ((uintptr_t)out_half % 8)) return VC_EINVAL;
+    const long long total = (long long)a.n * a.h * a.w * (a.c / 4);
+    hipLaunchKernelGGL(k_to_half, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, static_cast<_Float16 *>(out_half));
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
 __global__ void k_channel_scale(vc_view a, const float *__restrict__ gain, vc_view out)
 {
     const long long total = (long long)out.n * out.h * out.w * out.c;

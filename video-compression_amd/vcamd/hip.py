@@ -141,6 +141,8 @@ def lib():
     sig("vc_deform_pack_weights", ci, vp, ci, ci, ci, vp)
     sig("vc_deform_conv2d", ci, vp, View, View, View, vp, vp, ci, View)
     sig("vc_offset_diversity", ci, vp, View, View, View, View, View, View, cf, vp, vp, ci, View)
+    sig("vc_offset_diversity_hx", ci, vp, View, View, View, View, View, View, cf, vp, vp, ci, View)
+    sig("vc_to_half", ci, vp, View, vp)
     sig("vc_attention_gate", ci, vp, View, View, View, View)
     sig("vc_sse_clamp01", ci, vp, View, View, vp, ci)
     sig("vc_select_flow", ci, vp, vp, ci, ctypes.c_double, ctypes.POINTER(View), View, vp)
@@ -169,7 +171,7 @@ EXPORTED_SYMBOLS = [
     "vc_conv_pack_weights_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
-    "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity",
+    "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
     "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_psnr_uint8", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes", "vc_rans_decode_stream",
@@ -305,6 +307,10 @@ HALF_ACTIVATIONS = bool(int(os.environ.get("VC_HALF_ACTIVATIONS", "1")))
 # as half in HBM too.  NOT bit-neutral (one more rounding of the identity per block; VC_CFG_RES_F16): part of the fp16 mode's
 # stated tolerance.  VC_HALF_RESIDUAL=0 keeps the identity fp32 (A/B, tests).
 HALF_RESIDUAL = bool(int(os.environ.get("VC_HALF_RESIDUAL", "1")))
+# fp16 path only: the deformable fusion of ICIP2024 gathers from HALF-precision copies of its feature maps (8 / 16 channels per
+# group: one 16-byte gather per corner instead of two; the kernel is bound by its gathers).  Offsets, modulation, bilinear
+# weights and accumulation stay fp32.  VC_HALF_DEFORM=0 gathers fp32 features (A/B, tests).
+HALF_DEFORM = bool(int(os.environ.get("VC_HALF_DEFORM", "1")))
 
 
 def set_conv_precision(mode):
@@ -511,6 +517,14 @@ def axpby(a, b, alpha=1.0, beta=1.0, out=None):
     return out
 
 
+def to_half(x):
+    """Dense half-precision copy of a channels-last fp32 window (round to nearest even): the features the fp16-path
+    deformable fusion gathers from."""
+    out = T.empty(x.n, x.h, x.w, x.c, x.buf.device, "f16")
+    check(lib().vc_to_half(stream(), x.view(), out.ptr), "vc_to_half")
+    return out
+
+
 def clamp01(x, out=None):
     """clamp(x, 0, 1) of a channels-last window (``torch.clamp(x_hat, 0, 1)`` of ICIP2024/src/test.py:94 on the device path)."""
     if out is None:
@@ -640,16 +654,23 @@ class PackedDeform:
     def offset_diversity(self, x1, raw1, flow1, x2, raw2, flow2, magnitude, out=None):
         if out is None:
             out = T.empty(x1.n, x1.h, x1.w, self.cout, x1.buf.device)
+        cg = self.cin // self.groups
+        half_x = (_PRECISION == "fp16" and HALF_DEFORM and cg % 4 == 0 and cg >= 8 and self.groups <= 16 and raw1.c % 4 == 0
+                  and x1.dtype == "f32" and x2.dtype == "f32"
+                  and all(t.ptr % 16 == 0 and t.sw % 4 == 0 and t.sh % 4 == 0 and t.sn % 4 == 0 and t.c % 4 == 0 for t in (x1, x2)))
+        if half_x:
+            x1, x2 = to_half(x1), to_half(x2)
+        fn = lib().vc_offset_diversity_hx if half_x else lib().vc_offset_diversity
 
         def launch():
-            check(lib().vc_offset_diversity(stream(), x1.view(), raw1.view(), flow1.view(), x2.view(), raw2.view(),
-                                            flow2.view(), float(magnitude), self.wpk.data_ptr(), self._bias_ptr(),
-                                            self.groups, out.view()), "vc_offset_diversity")
+            check(fn(stream(), x1.view(True), raw1.view(), flow1.view(), x2.view(True), raw2.view(),
+                     flow2.view(), float(magnitude), self.wpk.data_ptr(), self._bias_ptr(),
+                     self.groups, out.view()), "vc_offset_diversity_hx" if half_x else "vc_offset_diversity")
         if timer is None:
             launch()
         else:
             flops = 2.0 * x1.n * x1.h * x1.w * self.cout * (self.cin // self.groups) * 9
-            nbytes = 4.0 * x1.n * x1.h * x1.w * (self.cin + raw1.c + raw2.c + 4 + self.cout)
+            nbytes = x1.n * x1.h * x1.w * ((2.0 if half_x else 4.0) * self.cin + 4.0 * (raw1.c + raw2.c + 4 + self.cout))
             timer.bracket(f"deform k3 {self.cin}->{self.cout} g{self.groups} @{x1.n}x{x1.h}x{x1.w}", flops, launch, nbytes)
         return out
 
