@@ -160,6 +160,8 @@ DMA_CASES = [  # cin, cout, k, n, h, w, classic tile configs to compare with
     (128, 128, 3, 2, 160, 288, (5,)),
     # more than 128 output channels that are not a multiple of 128: the last block of 128 is partly padding
     (128, 432, 3, 1, 20, 40, (5, 0)), (64, 208, 3, 2, 17, 33, (5, 0)),
+    # 64 -> 64 (two N-tiles): 9 phases per tile, weight ring of 3
+    (64, 64, 3, 2, 33, 50, (1, 2)), (64, 64, 3, 1, 100, 170, (1,)),
 ]
 
 

@@ -71,6 +71,7 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
         if (nt == 4 && nchunk == 2) return launch_conv_dma<DmaCfg<3, 3, 2, 4, 6>>(st, a);
         if (nt == 4 && nchunk == 6) return launch_conv_dma<DmaCfg<3, 3, 6, 4, 6>>(st, a);
         if (nt == 4 && nchunk == 8) return launch_conv_dma<DmaCfg<3, 3, 8, 4, 6>>(st, a);
+        if (nt == 2 && nchunk == 2) return launch_conv_dma<DmaCfg<3, 3, 2, 2, 3>>(st, a);      // 64 -> 64: 9 phases per tile, ring of 3
     } else if (k == 7) {
         if (nt == 1 && nchunk == 2) return launch_conv_dma<DmaCfg<7, 7, 2, 1, 5>>(st, a);
         if (nt == 2 && nchunk == 1) return launch_conv_dma<DmaCfg<7, 7, 1, 2, 5>>(st, a);
