@@ -373,12 +373,12 @@ class PackedConv:
                 self.candidates.append(CFG_PWS)  # VC_CFG_PWS: the same through per-wave LDS-DMA rings
         if self.candidates and kh == 7 and stride == 1:
             self.candidates.append(7)          # VC_CFG_N32T16: 16-row tiles (less halo per output)
-        if (self.candidates and kh in (3, 7) and stride == 1 and cin % 32 == 0 and not self.ps
-                and (cout in (32, 64) or cout % 128 == 0 or (cout > 128 and cout % 4 == 0 and self.cfg == 0))    # (N128 packing pads to 128s)
-                and os.environ.get("VC_DMA_KERNELS", "1") != "0") or \
-           (self.candidates and self.ps and kh in (3, 7) and stride == 1 and cin % 32 == 0 and cout % 128 == 0
+        # VC_CFG_DMA (fp16 path, half-precision input; the library refuses shapes it has no instance for): 32 / 64 output channels,
+        # blocks of 128, or -- plain output on the N128 packing, which pads weights and bias to 128s -- a partly padded last block
+        dma_cout = cout in (32, 64) or cout % 128 == 0 or (cout > 128 and cout % 4 == 0 and self.cfg == 0 and not self.ps)
+        if (self.candidates and kh in (3, 7) and stride == 1 and cin % 32 == 0 and dma_cout
                 and os.environ.get("VC_DMA_KERNELS", "1") != "0"):
-            self.candidates.append(CFG_DMA)    # fp16 path, half-precision input (the library refuses shapes it has no instance for)
+            self.candidates.append(CFG_DMA)
         # every alternative must read THIS packing: same channel chunk (the zero padding of cin depends on it)
         self.candidates = [c for c in self.candidates if L.vc_conv_chunk(c, kh, stride, cin) == ck]
 
