@@ -162,6 +162,8 @@ DMA_CASES = [  # cin, cout, k, n, h, w, classic tile configs to compare with
     (128, 432, 3, 1, 20, 40, (5, 0)), (64, 208, 3, 2, 17, 33, (5, 0)),
     # 64 -> 64 (two N-tiles): 9 phases per tile, weight ring of 3
     (64, 64, 3, 2, 33, 50, (1, 2)), (64, 64, 3, 1, 100, 170, (1,)),
+    # 96 input channels (27 phases, ring of 9); 96 output channels = one block of 128, a quarter of it padding
+    (96, 384, 3, 1, 20, 40, (5, 0)), (96, 96, 3, 2, 33, 50, (5, 1, 2)), (96, 96, 3, 1, 100, 170, (5,)),
 ]
 
 

@@ -14,9 +14,9 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
 {
     if (stride != 1 || !dma_views_ok(a) || (a.Cin & 31)) return VC_EINVAL;
     const int nchunk = a.Cin / 32;
-    // more than 128 output channels: blocks of 128, the last one partly padding (the packing of VC_CFG_N128 / N128B pads the
+    // 96 output channels and more: blocks of 128, the last one partly padding (the packing of VC_CFG_N128 / N128B pads the
     // weights and the bias to a multiple of 128 with zeros; the caller names this configuration only on such a packing)
-    const int nt = (a.Cout >= 128) ? 4 : (a.Cout == 64 ? 2 : (a.Cout == 32 ? 1 : 0));
+    const int nt = (a.Cout >= 96) ? 4 : (a.Cout == 64 ? 2 : (a.Cout == 32 ? 1 : 0));
     if (!nt || (a.Cout % 4)) return VC_EINVAL;
     a.tiles_x = (a.Wo + 31) / 32;
     a.tiles_y = (a.Ho + 15) / 16;
@@ -69,6 +69,7 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
             return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6>>(st, a);
         }
         if (nt == 4 && nchunk == 2) return launch_conv_dma<DmaCfg<3, 3, 2, 4, 6>>(st, a);
+        if (nt == 4 && nchunk == 3) return launch_conv_dma<DmaCfg<3, 3, 3, 4, 9>>(st, a);      // 96 input channels: 27 phases, ring of 9
         if (nt == 4 && nchunk == 6) return launch_conv_dma<DmaCfg<3, 3, 6, 4, 6>>(st, a);
         if (nt == 4 && nchunk == 8) return launch_conv_dma<DmaCfg<3, 3, 8, 4, 6>>(st, a);
         if (nt == 2 && nchunk == 2) return launch_conv_dma<DmaCfg<3, 3, 2, 2, 3>>(st, a);      // 64 -> 64: 9 phases per tile, ring of 3

@@ -375,7 +375,7 @@ class PackedConv:
             self.candidates.append(7)          # VC_CFG_N32T16: 16-row tiles (less halo per output)
         # VC_CFG_DMA (fp16 path, half-precision input; the library refuses shapes it has no instance for): 32 / 64 output channels,
         # blocks of 128, or -- plain output on the N128 packing, which pads weights and bias to 128s -- a partly padded last block
-        dma_cout = cout in (32, 64) or cout % 128 == 0 or (cout > 128 and cout % 4 == 0 and self.cfg == 0 and not self.ps)
+        dma_cout = cout in (32, 64) or cout % 128 == 0 or (cout >= 96 and cout % 4 == 0 and self.cfg == 0 and not self.ps)
         if (self.candidates and kh in (3, 7) and stride == 1 and cin % 32 == 0 and dma_cout
                 and os.environ.get("VC_DMA_KERNELS", "1") != "0"):
             self.candidates.append(CFG_DMA)
