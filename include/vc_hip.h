@@ -69,7 +69,8 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
        VC_CFG_N32T16 = 7 /* 7x7 stride 1: 16-row tiles of 32 channels (22 x 38 input footprint per 16 x 32 outputs
                         instead of 14 x 38 per 8 x 32); same packed weights as N32, bit-identical results */,
        VC_CFG_DMA = 8 /* fp16 path only (VC_CFG_F16 | VC_CFG_IN_F16), 3x3 / 7x7 stride 1, cin a multiple of 32, cout 32, 64
-                        or a multiple of 128, plain / ReLU / LeakyReLU / sigmoid / clamp epilogue (+ gain, residual, pixel
+                        or a multiple of 128 -- with VC_CFG_PACK128 also any multiple of 4 from 96 up (plain output only:
+                        blocks of 128 whose last one is partly padding) --, plain / ReLU / LeakyReLU / sigmoid / clamp epilogue (+ gain, residual, pixel
                         shuffle): one persistent 512-thread workgroup per CU, both operands streamed into LDS by
                         global_load_lds with counted vmcnt across raw barriers (csrc/conv_dma.h); reads the packed weights
                         of the 32-wide configurations and gives bit-identical results */,
@@ -103,6 +104,11 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
  * x + f(x) per block).  Unlike VC_CFG_IN_F16 / OUT_F16 this CHANGES results (one more rounding of the identity per block):
  * part of the fp16 mode's stated tolerance, never of the fp32 path.  Every other configuration returns VC_EINVAL. */
 #define VC_CFG_RES_F16 0x2000
+/* With VC_CFG_DMA only: the caller states that `wpk` and `bias` were packed by vc_conv_pack_weights[_f16] with
+ * cfg = VC_CFG_N128 (or N128B), i.e. zero-padded to whole blocks of 128 output channels.  Required for output-channel counts
+ * above 64 that are no multiple of 128 (the kernel reads whole blocks); without it such a call returns VC_EINVAL instead of
+ * reading past a narrower packing. */
+#define VC_CFG_PACK128 0x4000
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */
     vc_view out;           /* [n,ho,wo,cout]  (PIXELSHUFFLE2: [n,2ho,2wo,cout/4]) */

@@ -34,7 +34,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 
 from oracle import cai, deform as odeform, flex as oflex, icip2024 as oicip, lhbdc as olhbdc  # noqa: E402
-from oracle.trace import CodecTrace  # noqa: E402
+from oracle.trace import CallLog, CodecTrace  # noqa: E402
 
 # The seeded-checkpoint generator is loaded by file: video-compression_amd/ must NOT be on sys.path here, it holds
 # packages named like the reference's (model/, b_model/, src/) that would shadow the modules this script pins against.
@@ -43,6 +43,21 @@ _spec = importlib.util.spec_from_file_location("vc_seeding", os.path.join(REPO, 
 _seeding = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_seeding)
 seeded_state_dict = _seeding.seeded_state_dict
+calibrated_state_dict = _seeding.calibrated_state_dict
+calibrated_intra_state_dict = _seeding.calibrated_intra_state_dict
+
+
+def intra_state_dict(kind, template, seed):
+    """I-frame model of the test() loops (compressai.zoo.mbt2018_mean stand-in; the zoo weights are unavailable offline):
+    "seeded" = plain seeded weights with conv_gain 0.8 (decodes to noise), "calibrated" = the linear transform codec of
+    vcamd.seeding.calibrated_intra_state_dict (decodes to ~30 dB)."""
+    if kind == "calibrated":
+        return calibrated_intra_state_dict(template, seed=seed)
+    return seeded_state_dict(template, seed=seed, conv_gain=0.8)
+
+
+def checkpoint_fn(kind):
+    return {"seeded": seeded_state_dict, "calibrated": calibrated_state_dict}[kind]
 
 
 def from_reference(*modules):
@@ -241,6 +256,118 @@ def gen_lhbdc(outdir, frames, seed):
             decoded=dec_r.numpy(),
             decoded_u8=enc["float_to_uint8"](dec_r[0].numpy())[:h, :w])
     return sd
+
+
+def fragile_mask(value, width):
+    """packbits mask of the entries whose value lies within ``width`` of a rounding boundary (a half-integer): the only
+    places where fp32 summation-order noise may legitimately flip a symbol."""
+    frac = value - torch.floor(value)
+    return np.packbits(((frac - 0.5).abs() < width).reshape(-1).numpy())
+
+
+def gen_lhbdc_fullsize(outdir, frames, seed):
+    """BASELINE configs[0] at its real size: the reference's Model.forward (LHBDC/model/m.py:32-98, with the six-level
+    pyramid of flow.py:83-101 and the 272x480 -> 320x512 reflection pad of m.py:38-47 at their real shapes) and the CLI
+    pair encode_B / decode_B on the FULL bundled frames (1080x1920 -> 1088x1920), calibrated checkpoint.  The oracle must
+    be tensor-equal / byte-equal; the fixture keeps what a GPU test needs to meet the REFERENCE's integers: symbols and
+    scale indexes (int8 / int16), the four strings, bit totals, the uint8 decoded frame and sub-sampled float tensors
+    (floats are stored, not hashed: another host's oneDNN may sum in a different order)."""
+    import shutil
+    ref_m = import_reference_lhbdc()
+    torch.manual_seed(0)
+    ref = ref_m.Model().eval()
+    sd = calibrated_state_dict(ref.state_dict(), seed=seed)
+    ref.load_state_dict(sd)
+    ora = olhbdc.LhbdcModel().eval()
+    ora.load_state_dict(sd)
+    enc = cli_functions(os.path.join(REF, "LHBDC/encode_B.py"),
+                        {"normalize", "float_to_uint8", "pad", "process_frame", "ups", "encode_B"})
+    dec = cli_functions(os.path.join(REF, "LHBDC/decode_B.py"),
+                        {"normalize", "float_to_uint8", "pad", "process_frame", "ups", "decode_B"})
+    table = cai.entropy_models.get_scale_table()
+    fdir = os.path.join(outdir, "frames")
+    os.makedirs(fdir, exist_ok=True)
+    for name in ("ref_1", "current", "ref_2"):             # the reference's bundled test data (inputs of configs[0])
+        shutil.copyfile(os.path.join(REF, "LHBDC/frames", name + ".png"), os.path.join(fdir, name + ".png"))
+    store = dict(seed=np.int64(seed), checkpoint="calibrated",
+                 frames_sha256=np.array([hashlib.sha256(frames[k].tobytes()).hexdigest() for k in ("ref_1", "current", "ref_2")]))
+    sub = (slice(None), slice(None), slice(0, None, 8), slice(0, None, 8))
+
+    def minus_current(u8):
+        """a decoded uint8 frame as its int8 difference to the bundled current frame (36 dB: a few grey levels; packs 5x
+        better than the frame).  The test adds tests/golden/frames/current.png back."""
+        d = u8.astype(np.int16) - frames["current"].astype(np.int16)
+        if np.abs(d).max() > 127:
+            raise SystemExit("decoded frame is more than 127 grey levels from the current frame")
+        return d.astype(np.int8)
+
+    def integers(prefix, lat):
+        out = {}
+        for k, dt in (("y_sym", np.int16), ("z_sym", np.int16), ("y_idx", np.int8)):
+            v = lat[k].numpy()
+            if np.abs(v).max() > np.iinfo(dt).max:
+                raise SystemExit(f"{prefix}_{k} does not fit {dt}")
+            out[f"{prefix}_{k}"] = v.astype(dt)
+        out[f"{prefix}_y_fragile"] = fragile_mask(lat["y"] - lat["means"], 2e-3)
+        return out
+
+    with torch.no_grad():
+        xb, xc, xa = (enc["process_frame"](frames[k].astype(float)) for k in ("ref_1", "current", "ref_2"))
+        print(f"  LHBDC full-size fixture: frames {tuple(xc.shape)}")
+        with CallLog(ref.FlowNet) as flows_r, CallLog(ref.masknet) as mask_r, CodecTrace(ref.mv_compressor) as t_mv, \
+                CodecTrace(ref.residual_compressor) as t_res:
+            x_hat_r, rate_r, bits_r = ref(xb, xc, xa, False)
+            lat_mv, lat_res = t_mv.latents(table), t_res.latents(table)
+        with CallLog(ora.FlowNet) as flows_o, CallLog(ora.masknet) as mask_o:
+            x_hat_o, rate_o, bits_o = ora(xb, xc, xa, False)
+        for j, nm in enumerate(("ba", "ab", "cb", "ca")):
+            check(f"FlowNet[{nm}] 1088x1920 (6 levels)", flows_o.outputs[j], flows_r.outputs[j])
+        check("masknet 1088x1920", mask_o.outputs[-1], mask_r.outputs[-1])
+        check("Model.forward x_hat 1088x1920", x_hat_o, x_hat_r)
+        check("Model.forward rate", rate_o, rate_r)
+        check("Model.forward bits", bits_o, bits_r)
+        h, w = frames["current"].shape[:2]
+        u8_r = enc["float_to_uint8"](x_hat_r[0].numpy())[:h, :w]
+        mse = np.mean((u8_r.astype(np.float64) - frames["current"].astype(np.float64)) ** 2)
+        store.update(fwd_flows_sub8=torch.cat(flows_r.outputs, 0)[sub].numpy(), fwd_mask_sub8=mask_r.outputs[-1][sub].numpy(),
+                     fwd_x_hat_sub8=x_hat_r[sub].numpy(), fwd_rate=np.float64(rate_r.item()),
+                     fwd_bits=np.float64(bits_r), fwd_psnr_u8=np.float64(10.0 * np.log10(255.0 ** 2 / mse)),
+                     fwd_res_input_sub8=lat_res["x"][sub].numpy(), fwd_mv_input_sub2=lat_mv["x"][:, :, ::2, ::2].numpy())
+        store.update({f"fwd_{k}": v for k, v in integers("mv", lat_mv).items()})
+        store.update({f"fwd_{k}": v for k, v in integers("res", lat_res).items()})
+        print(f"    forward: {store['fwd_psnr_u8']:.3f} dB (uint8), {bits_r / (h * w):.4f} bpp over {h}x{w}; "
+              f"{100 * float((lat_res['y_sym'] != 0).float().mean()):.1f} % of the residual symbols non-zero")
+
+        for m_ in (ref, ora):
+            m_.mv_compressor.update(force=True)
+            m_.residual_compressor.update(force=True)
+        with CodecTrace(ref.mv_compressor) as tr_mv, CodecTrace(ref.residual_compressor) as tr_res:
+            mv_r, res_r = enc["encode_B"](ref, xa, xc, xb)
+            lat_mv = tr_mv.latents(table)
+            lat_res = tr_res.latents(table)
+            latent_arrays("mv", tr_mv, ref.mv_compressor, mv_r["strings"])          # (asserts: symbols re-encode to the strings)
+            latent_arrays("res", tr_res, ref.residual_compressor, res_r["strings"])
+        mv_o, res_o = olhbdc.encode_B(ora, xa, xc, xb)
+        for nm, r, o in (("mv", mv_r, mv_o), ("res", res_r, res_o)):
+            for j, part in enumerate("yz"):
+                if r["strings"][j][0] != o["strings"][j][0]:
+                    raise SystemExit(f"oracle bitstream differs from the reference at full size: {nm}.{part}")
+                print(f"    oracle-vs-reference {nm}.{part} string {len(r['strings'][j][0])} bytes: identical")
+        dec_r = dec["decode_B"](xb, xa, ref, mv_r["strings"], res_r["strings"], mv_r["shape"], res_r["shape"])
+        dec_o = olhbdc.decode_B(xb, xa, ora, mv_o["strings"], res_o["strings"], mv_o["shape"], res_o["shape"])
+        check("decode_B 1088x1920", dec_o, dec_r)
+        dec_u8 = enc["float_to_uint8"](dec_r[0].numpy())[:h, :w]
+        mse = np.mean((dec_u8.astype(np.float64) - frames["current"].astype(np.float64)) ** 2)
+        store.update({f"enc_{k}": v for k, v in integers("mv", lat_mv).items()})
+        store.update({f"enc_{k}": v for k, v in integers("res", lat_res).items()})
+        store.update(mv_y=np.frombuffer(mv_r["strings"][0][0], dtype=np.uint8), mv_z=np.frombuffer(mv_r["strings"][1][0], dtype=np.uint8),
+                     res_y=np.frombuffer(res_r["strings"][0][0], dtype=np.uint8), res_z=np.frombuffer(res_r["strings"][1][0], dtype=np.uint8),
+                     mv_shape=np.array(tuple(mv_r["shape"]), dtype=np.int64), res_shape=np.array(tuple(res_r["shape"]), dtype=np.int64),
+                     container=np.frombuffer(olhbdc.write_container(1626, mv_r, res_r), dtype=np.uint8),
+                     dec_u8_minus_current=minus_current(dec_u8), dec_sub8=dec_r[sub].numpy(), dec_psnr_u8=np.float64(10.0 * np.log10(255.0 ** 2 / mse)))
+        print(f"    encode_B / decode_B: container {store['container'].size} bytes, decoded {store['dec_psnr_u8']:.3f} dB (uint8)")
+    np.savez_compressed(os.path.join(outdir, "lhbdc_fullsize_1080p.npz"), **store)
+    print(f"  wrote lhbdc_fullsize_1080p.npz ({os.path.getsize(os.path.join(outdir, 'lhbdc_fullsize_1080p.npz')) / 1e6:.1f} MB)")
 
 
 def gen_flex(outdir, frames, seed):
@@ -456,7 +583,7 @@ def gen_icip2024(outdir, frames, seed):
     print("  ICIP2024 bookkeeping fixture:", {k: len(v) for k, v in book["refs"].items()})
 
 
-def gen_lhbdc_test_loop(outdir, seed):
+def gen_lhbdc_test_loop(outdir, seed, checkpoint="calibrated"):
     """The reference's own evaluation function ``test()`` (LHBDC/test/testing.py:88-196) run on seven tiny synthetic
     "videos" (the seven folder names are hard-coded there): UVGTestDataset reads PNGs this function writes to a temp
     directory, TestInfographic collects the per-frame rows.  Stubs: imageio (PIL), natsort, matplotlib; pandas >= 2
@@ -498,12 +625,12 @@ def gen_lhbdc_test_loop(outdir, seed):
 
     torch.manual_seed(0)
     ref_b = ref_m.Model().eval()
-    sd_b = seeded_state_dict(ref_b.state_dict(), seed=seed)
+    sd_b = checkpoint_fn(checkpoint)(ref_b.state_dict(), seed=seed)
     ref_b.load_state_dict(sd_b)
     ora_b = olhbdc.LhbdcModel().eval()
     ora_b.load_state_dict(sd_b)
     ref_i = cai.models.mbt2018_mean(7).eval()          # compressai.zoo stand-in (weights unavailable offline): seeded
-    sd_i = seeded_state_dict(ref_i.state_dict(), seed=seed + 7, conv_gain=0.8)
+    sd_i = intra_state_dict(checkpoint, ref_i.state_dict(), seed + 7)
     ref_i.load_state_dict(sd_i)
     folders = ["beauty", "bosphorus", "honeybee", "jockey", "ready", "shake", "yatch"]
     with tempfile.TemporaryDirectory() as tmp:
@@ -531,12 +658,13 @@ def gen_lhbdc_test_loop(outdir, seed):
     info.print_per_level()
     agg = {"per_level": {str(k_): float(v) for k_, v in info.average_bpp_psnr_dict.items()}}
     with open(os.path.join(outdir, "lhbdc_test_loop.json"), "w") as f:
-        json.dump({"seed": seed, "intra_seed": seed + 7, "intra_conv_gain": 0.8, "folders": folders, "frames_per_video": 9,
+        json.dump({"seed": seed, "checkpoint": checkpoint, "intra_seed": seed + 7, "intra_checkpoint": checkpoint, "intra_conv_gain": 0.8,
+                   "folders": folders, "frames_per_video": 9,
                    "frame_hw": [180, 180], "rows": rows, "aggregate_bpp_to_psnr": agg}, f)
     print(f"  LHBDC test() fixture: {len(rows)} frame rows over {len(folders)} videos; bpp->PSNR {agg['per_level']}")
 
 
-def gen_flex_test_loop(outdir, seed):
+def gen_flex_test_loop(outdir, seed, checkpoint="calibrated"):
     """Flex-Rate's own ``test()`` (test/testing.py:124-224) on seven synthetic clips of 17 frames, for all eight of its
     operating points (the module-level ``qualities`` list).  Same scaffolding as gen_lhbdc_test_loop."""
     import argparse as _argparse
@@ -578,14 +706,14 @@ def gen_flex_test_loop(outdir, seed):
 
     torch.manual_seed(0)
     ref_b = ref_b_mod.BidirFlowRef(n=4).eval()
-    sd_b = seeded_state_dict(ref_b.state_dict(), seed=seed)
+    sd_b = checkpoint_fn(checkpoint)(ref_b.state_dict(), seed=seed)
     ref_b.load_state_dict(sd_b)
     ora_b = oflex.FlexModel(n=4).eval()
     ora_b.load_state_dict(sd_b)
     i_models = {}
     for q in sorted({q_[0] for q_ in all_q}):
         m = cai.models.mbt2018_mean(q).eval()
-        m.load_state_dict(seeded_state_dict(m.state_dict(), seed=seed + q, conv_gain=0.8))
+        m.load_state_dict(intra_state_dict(checkpoint, m.state_dict(), seed + q))
         i_models[q] = m
     folders = ["beauty", "bosphorus", "honeybee", "jockey", "ready", "shake", "yatch"]
     with tempfile.TemporaryDirectory() as tmp:
@@ -611,7 +739,7 @@ def gen_flex_test_loop(outdir, seed):
             check(f"flex test() size {name} q{qi}", np.array([m_[3] for m_ in mine], dtype=np.float64),
                   np.array([t_[6] for t_ in theirs], dtype=np.float64))
     with open(os.path.join(outdir, "flex_test_loop.json"), "w") as f:
-        json.dump({"seed": seed, "intra_seed_offset_is_quality": True, "intra_conv_gain": 0.8, "folders": folders,
+        json.dump({"seed": seed, "checkpoint": checkpoint, "intra_seed_offset_is_quality": True, "intra_checkpoint": checkpoint, "intra_conv_gain": 0.8, "folders": folders,
                    "frames_per_video": 17, "frame_hw": [120, 180],
                    "qualities": [[q[0], {str(k_): list(v) for k_, v in q[1].items()}] for q in ns["qualities"]], "rows": rows}, f)
     print(f"  Flex test() fixture: {len(rows)} frame rows, {len(ns['qualities'])} operating points x {len(folders)} videos")
@@ -655,7 +783,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--only", choices=["lhbdc", "flex", "harness", "icip2024", "testloop", "flextestloop"], default=None)
+    ap.add_argument("--only", choices=["lhbdc", "fullsize", "flex", "harness", "icip2024", "testloop", "flextestloop"], default=None)
+    ap.add_argument("--loop-checkpoint", choices=["seeded", "calibrated"], default="calibrated",
+                    help="checkpoint of the B-frame model in the test() loop fixtures (calibrated: trained-like statistics)")
     args = ap.parse_args()
     if not os.path.isdir(REF):
         raise SystemExit("/root/reference is not present: fixtures can only be generated in the build container")
@@ -667,14 +797,16 @@ def main():
         print(f"frame {k}: {v.shape} sha256(raw RGB)={hashlib.sha256(v.tobytes()).hexdigest()[:16]}")
     if args.only in (None, "lhbdc"):
         gen_lhbdc(args.out, frames, args.seed)
+    if args.only in (None, "fullsize"):
+        gen_lhbdc_fullsize(args.out, frames, args.seed)
     if args.only in (None, "flex"):
         gen_flex(args.out, frames, args.seed)
     if args.only in (None, "icip2024"):
         gen_icip2024(args.out, frames, args.seed)
     if args.only in (None, "testloop"):
-        gen_lhbdc_test_loop(args.out, args.seed)
+        gen_lhbdc_test_loop(args.out, args.seed, args.loop_checkpoint)
     if args.only in (None, "flextestloop"):
-        gen_flex_test_loop(args.out, args.seed)
+        gen_flex_test_loop(args.out, args.seed, args.loop_checkpoint)
     if args.only in (None, "harness"):
         gen_harness(args.out)
     print("fixtures written to", args.out)

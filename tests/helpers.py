@@ -35,3 +35,20 @@ def lhbdc_pair(seed, device=None, calibrated=False):
     if device is not None:
         prod = prod.to(device)
     return ora, prod.eval()
+
+
+def fixture_state_dict(fx, template, seed=None):
+    """The B-frame checkpoint a test() loop fixture was generated on: ``fx["checkpoint"]`` = "calibrated" (trained-like
+    statistics, vcamd.seeding.calibrated_state_dict) or absent / "seeded"."""
+    from vcamd.seeding import calibrated_state_dict, seeded_state_dict
+    fn = calibrated_state_dict if fx.get("checkpoint", "seeded") == "calibrated" else seeded_state_dict
+    return fn(template, seed=fx["seed"] if seed is None else seed)
+
+
+def fixture_intra_state_dict(fx, template, seed):
+    """The I-frame checkpoint of a test() loop fixture (``fx["intra_checkpoint"]``: "calibrated" = the reconstructing
+    linear transform codec of vcamd.seeding.calibrated_intra_state_dict; else seeded with the fixture's conv gain)."""
+    from vcamd.seeding import calibrated_intra_state_dict, seeded_state_dict
+    if fx.get("intra_checkpoint", "seeded") == "calibrated":
+        return calibrated_intra_state_dict(template, seed=seed)
+    return seeded_state_dict(template, seed=seed, conv_gain=fx["intra_conv_gain"])

@@ -46,6 +46,34 @@ def test_self_launched_two_rank_strong_run_equals_single_rank():
     assert "ranks" not in one
 
 
+def test_default_line_carries_the_strong_block_and_its_checksum_is_the_single_rank_one():
+    """The DEFAULT (weak) line of `bench.py --gpus N` also holds BASELINE configs[3] as a `strong` block: one pass over a test
+    set sized by --strong-seconds at N GPUs, GOP-sharded, R-D records gathered, per-rank coding times, and a checksum over the
+    records of the frames every world size codes -- which must equal the single-rank run's, bit pattern for bit pattern."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    args = ["--sequences", "2", "--strong-seconds", "1", "--steps", "1", "--warmup", "0", "--gops-per-step", "1", "--no-cpu-baseline"]
+
+    def run(extra, env_extra=None):
+        env = dict(os.environ)
+        env.update(env_extra or {})
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + extra, env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    one = run([])
+    two = run(["--gpus", "2"], {"VC_BENCH_SHARE_GPU": "1", "VC_BENCH_BACKEND": "gloo"})
+    assert one["scaling"] == two["scaling"] == "weak" and two["n_gpus"] == 2
+    s1, s2 = one["strong"], two["strong"]
+    # 17 frames/s x 1 s / 2 sequences -> 9 frames per sequence on one GPU, 17 on two
+    assert s1["frames"] == 18 and s2["frames"] == 34 and s2["gloo_ranks"] == 2 and s2["frames_per_rank"] == [17, 17]
+    assert len(s2["coded_s"]) == len(s2["gather_s"]) == 2 and all(t > 0 for t in s2["coded_s"])
+    assert s1["rd_checksum_common"]["records"] == s2["rd_checksum_common"]["records"] == 18
+    assert s1["rd_checksum_common"]["sha256"] == s2["rd_checksum_common"]["sha256"] == s1["rd_checksum"]["sha256"]
+    assert s2["rd_checksum"]["records"] == 34 and s2["rd_checksum"]["sha256"] != s1["rd_checksum"]["sha256"]
+    assert s1["value"] > 0 and s2["quality"]["frames"] == 34
+
+
 def test_strong_run_sized_by_seconds_per_step():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -64,7 +92,8 @@ def test_bench_streams_frames_from_png_files(tmp_path):
     device-resident run (the files hold exactly the synthetic clip), ingest statistics in the line."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--gops-per-step", "1", "--no-cpu-baseline"]
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--gops-per-step", "1", "--no-cpu-baseline",
+            "--no-strong-block"]
 
     def run(extra):
         out = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)

@@ -52,3 +52,17 @@ def test_use_behind_the_wait_passes_and_later_units_stay_guarded(tmp_path):
 
 def test_a_file_without_the_kernels_is_an_error(tmp_path):
     assert run("nothing here\n", tmp_path).returncode == 1
+
+
+def test_control_flow_a_linear_scan_cannot_follow_is_rejected(tmp_path):
+    """The scan follows file order (documented in the tool): a backward branch while loads are in flight, and a wait that a
+    forward branch could bypass, are refused; a forward branch that lands in front of the wait is fine."""
+    loop = HEAD + ".LBB0_1:\n" + LOADS + "\ts_cbranch_scc1 .LBB0_1\n" + WAIT + WAIT + TAIL
+    r = run(loop, tmp_path)
+    assert r.returncode == 1 and "BACKWARD" in r.stdout
+    bypass = HEAD + LOADS + "\ts_cbranch_vccnz .LBB0_9\n" + WAIT + ".LBB0_9:\n\tv_pk_add_f32 v[94:95], v[56:57], v[88:89]\n" + WAIT + TAIL
+    r = run(bypass, tmp_path)
+    assert r.returncode == 1 and "bypass" in r.stdout
+    fine = HEAD + LOADS + "\ts_cbranch_vccnz .LBB0_9\n\tv_mov_b32 v1, v2\n.LBB0_9:\n" + WAIT + \
+        "\tv_pk_add_f32 v[94:95], v[56:57], v[88:89]\n" + WAIT + TAIL
+    assert run(fine, tmp_path).returncode == 0

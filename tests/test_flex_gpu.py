@@ -150,8 +150,8 @@ def test_gops_batched_together_equal_gops_coded_alone(dev, models):
 
 def test_sequence_loop_against_the_reference_test_function(dev):
     """vcamd.gop.code_sequence_flex against the rows of the reference's own ``test()`` (fixture flex_test_loop.json: seven
-    clips x all eight operating points of testing.py:86-89; three clips per point are run here).  Tolerances graded by hierarchy level as in the LHBDC twin of this test (unclamped
-    decoded references + untrained weights amplify reference differences level by level)."""
+    clips x all eight operating points of testing.py:86-89; three clips per point are run here).  Calibrated checkpoint
+    (trained-like statistics), every hierarchy level held at 1e-3 dB / 1e-3 in size, like the LHBDC twin of this test."""
     import json
     import os
     from helpers import GOLDEN
@@ -159,12 +159,13 @@ def test_sequence_loop_against_the_reference_test_function(dev):
     from vcamd import flex, gop as vgop, iframe
     from vcamd.seeding import seeded_state_dict
     fx = json.load(open(os.path.join(GOLDEN, "flex_test_loop.json")))
+    from helpers import fixture_intra_state_dict, fixture_state_dict
     b_model = flex.BidirFlowRef(n=4)
-    b_model.load_state_dict(seeded_state_dict(b_model.state_dict(), seed=fx["seed"]))
+    b_model.load_state_dict(fixture_state_dict(fx, b_model.state_dict()))
     b_model = b_model.to(dev).eval()
     h, w = fx["frame_hw"]
-    # (measured on MI355X over all eight operating points: I 3.6e-6 dB, level 0 1.3e-3, 1 7e-4, 2 4.8e-3, 3 2.4e-3)
-    tol = {"I": (1e-3, 1e-4), 0: (2.5e-3, 1e-3), 1: (5e-3, 5e-3), 2: (2e-2, 1e-2), 3: (2e-2, 2e-2)}
+    assert fx.get("checkpoint") == "calibrated"
+    tol = {"I": (1e-3, 1e-4), 0: (1e-3, 1e-3), 1: (1e-3, 1e-3), 2: (1e-3, 1e-3), 3: (1e-3, 1e-3)}
     worst = {k: [0.0, 0.0] for k in tol}
     i_models = {}
     with torch.no_grad():
@@ -172,7 +173,7 @@ def test_sequence_loop_against_the_reference_test_function(dev):
             quality = (i_qual, {int(k): tuple(v) for k, v in table.items()})
             if i_qual not in i_models:
                 m = iframe.mbt2018_mean(i_qual, "mse", pretrained=False)
-                m.load_state_dict(seeded_state_dict(m.state_dict(), seed=fx["seed"] + i_qual, conv_gain=fx["intra_conv_gain"]))
+                m.load_state_dict(fixture_intra_state_dict(fx, m.state_dict(), fx["seed"] + i_qual))
                 i_models[i_qual] = m.to(dev).eval()
             lvl, itv = quality[1][3]
             for k, name in enumerate(fx["folders"][:3]):            # three clips per operating point keep the test short

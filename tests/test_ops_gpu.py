@@ -225,6 +225,17 @@ def test_lds_dma_fp16_kernel_is_bit_identical(dev, cin, cout, k, n, h, w, cfgs):
     pc.tuned = {(n, h, w, fl): hip.CFG_DMA | hip.CFG_EXACT | fl}
     with pytest.raises(hip.VcError):
         pc(xt, act=hip.ACT_NONE)
+    if cout > 64 and cout % 128:
+        # a partly padded last block reads weights / bias padded to 128s: a caller that does not state that packing
+        # (VC_CFG_PACK128) is refused instead of reading past a narrower one
+        fi = fl | hip.CFG_IN_F16
+        pc.tuned = {(n, h, w, fi): hip.CFG_DMA | hip.CFG_EXACT | fi}
+        keep, pc.cfg = pc.cfg, 1
+        try:
+            with pytest.raises(hip.VcError):
+                pc(xh, act=hip.ACT_NONE)
+        finally:
+            pc.cfg = keep
 
 
 def test_conv_residual_and_channel_slices(dev):

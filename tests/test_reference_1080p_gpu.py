@@ -1,0 +1,200 @@
+"""-m gpu: the HIP path against THE REFERENCE ITSELF at BASELINE size (configs[0]: the bundled 1080x1920 frames, padded to
+1088x1920), calibrated checkpoint.
+
+tests/golden/lhbdc_fullsize_1080p.npz was written by oracle/gen_golden.py --only fullsize while the reference's own
+``Model.forward`` (LHBDC/model/m.py:32-98: six-level SPyNet pyramid of flow.py:83-101, the 272x480 -> 320x512 reflection
+pad of m.py:38-47) and its CLI functions ``encode_B`` / ``decode_B`` (LHBDC/encode_B.py:71-105, decode_B.py:63-86) ran
+on tests/golden/frames/*.png (the reference's bundled test data).  No oracle in between: what is compared here are the
+reference's integers (quantised symbols, scale-table indexes), its four strings, its bit totals, its uint8 decoded frame
+and sub-sampled float tensors.
+
+Bars (BASELINE.json north_star): range-coder input identical up to <= 2 boundary-case symbols per tensor (a symbol may only
+differ where the reference's own value sits within 2e-3 of a rounding boundary -- ``*_fragile`` masks of the fixture),
+strings byte-equal when no symbol differs, PSNR within 1e-3 dB, size within 1e-3.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+H, W, HP, WP = 1080, 1920, 1088, 1920
+MAX_FLIPS = 2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return load_fixture("lhbdc_fullsize_1080p.npz")
+
+
+@pytest.fixture(scope="module")
+def bundled(fx):
+    """The three bundled frames as HWC uint8 (sha256 of the raw RGB bytes pinned by the fixture)."""
+    from PIL import Image
+    out = {}
+    for name, digest in zip(("ref_1", "current", "ref_2"), fx["frames_sha256"]):
+        u8 = np.asarray(Image.open(os.path.join(GOLDEN, "frames", name + ".png")).convert("RGB"))
+        assert u8.shape == (H, W, 3) and hashlib.sha256(u8.tobytes()).hexdigest() == str(digest), name
+        out[name] = u8
+    return out
+
+
+@pytest.fixture(scope="module")
+def model(dev, fx):
+    from vcamd import lhbdc
+    from vcamd.seeding import calibrated_state_dict
+    assert str(fx["checkpoint"]) == "calibrated"
+    prod = lhbdc.Model()
+    prod.load_state_dict(calibrated_state_dict(prod.state_dict(), seed=int(fx["seed"])))
+    prod = prod.to(dev).eval()
+    prod.mv_compressor.update(force=True)
+    prod.residual_compressor.update(force=True)
+    return prod
+
+
+@pytest.fixture(scope="module")
+def frames(dev, bundled):
+    from vcamd import lhbdc
+    xb, xc, xa = (lhbdc.process_frame(bundled[k].astype(float), dev) for k in ("ref_1", "current", "ref_2"))
+    assert tuple(xc.shape) == (1, 3, HP, WP)
+    return xb, xc, xa
+
+
+def nchw(t):
+    from vcamd import hip
+    return hip.nhwc_to_nchw(t).cpu()
+
+
+def psnr_u8(u8, ref_u8):
+    mse = np.mean((u8.astype(np.float64) - ref_u8.astype(np.float64)) ** 2)
+    return 10.0 * np.log10(255.0 ** 2 / mse)
+
+
+def to_u8(x_hat):
+    from vcamd import lhbdc
+    return lhbdc.float_to_uint8(x_hat[0].cpu().numpy())[:H, :W]
+
+
+def flips(tag, mine, theirs, fragile=None):
+    """Entries differing from the reference's; every differing y symbol must sit where the reference's own value is within
+    2e-3 of a rounding boundary."""
+    mine = np.asarray(mine.cpu() if torch.is_tensor(mine) else mine).reshape(-1).astype(np.int64)
+    theirs = np.asarray(theirs).reshape(-1).astype(np.int64)
+    assert mine.size == theirs.size, (tag, mine.size, theirs.size)
+    bad = np.nonzero(mine != theirs)[0]
+    if fragile is not None and bad.size:
+        mask = np.unpackbits(fragile)[: theirs.size].astype(bool)
+        assert mask[bad].all(), f"{tag}: a symbol differs from the reference's away from any rounding boundary"
+        assert np.abs(mine[bad] - theirs[bad]).max() == 1, tag
+    return int(bad.size)
+
+
+def test_forward_meets_the_reference_at_1088x1920(dev, fx, bundled, model, frames):
+    """Model.forward on the full bundled frames: SPyNet levels 0-5, the reflection-padded flow codec input, mask, residual
+    input against the reference's sub-sampled tensors; the entropy models' integers against the reference's."""
+    xb, xc, xa = frames
+    trace = {}
+    with torch.no_grad():
+        x_hat, tot = model.forward_device(xb, xc, xa, trace=trace)
+        bits = float(tot.sum())
+    stage = {
+        "flows": float((nchw(trace["flows"])[:, :, ::8, ::8] - torch.from_numpy(fx["fwd_flows_sub8"])).abs().max()),
+        "mv_input": float((nchw(trace["diff"])[:, :, ::2, ::2] - torch.from_numpy(fx["fwd_mv_input_sub2"])).abs().max()),
+        "mask": float((nchw(trace["mask"])[:, :, ::8, ::8] - torch.from_numpy(fx["fwd_mask_sub8"])).abs().max()),
+        "res_input": float((nchw(trace["resid"])[:, :, ::8, ::8] - torch.from_numpy(fx["fwd_res_input_sub8"])).abs().max()),
+    }
+    n = {"mv_z": flips("mv z", trace["mv"]["z_sym"], fx["fwd_mv_z_sym"]), "res_z": flips("res z", trace["res"]["z_sym"], fx["fwd_res_z_sym"])}
+    n["mv_y"] = flips("mv y", trace["mv"]["y_sym"], fx["fwd_mv_y_sym"], fx["fwd_mv_y_fragile"] if not n["mv_z"] else None)
+    upstream = n["mv_z"] or n["mv_y"]
+    n["res_y"] = flips("res y", trace["res"]["y_sym"], fx["fwd_res_y_sym"],
+                       fx["fwd_res_y_fragile"] if not (upstream or n["res_z"]) else None)
+    u8 = to_u8(x_hat)
+    d_psnr = abs(psnr_u8(u8, bundled["current"]) - float(fx["fwd_psnr_u8"]))
+    d_bits = abs(bits - float(fx["fwd_bits"])) / float(fx["fwd_bits"])
+    d_hat = float((x_hat.cpu()[:, :, ::8, ::8] - torch.from_numpy(fx["fwd_x_hat_sub8"])).abs().max())
+    print(f"LHBDC forward vs THE REFERENCE at 1088x1920 (bundled frames, calibrated checkpoint, {float(fx['fwd_psnr_u8']):.3f} dB, "
+          f"{float(fx['fwd_bits']) / (H * W):.4f} bpp): stage max|d| {stage}; symbols differing {n} of "
+          f"{fx['fwd_mv_y_sym'].size} / {fx['fwd_mv_z_sym'].size} / {fx['fwd_res_y_sym'].size} / {fx['fwd_res_z_sym'].size}; "
+          f"x_hat max|d| (1/8 grid) {d_hat:.2e}; dPSNR(uint8) {d_psnr:.2e} dB; bits rel {d_bits:.2e}")
+    assert stage["flows"] < 1e-4 and stage["mv_input"] < 1e-4, stage       # SPyNet incl. levels 4 and 5, pool + reflect pad
+    assert all(v <= MAX_FLIPS for v in n.values()), n
+    if not upstream:
+        assert stage["mask"] < 1e-4 and stage["res_input"] < 1e-4, stage
+    assert d_psnr < 1e-3 and d_bits < 1e-3
+    assert d_hat < 2e-3                                                     # (a flipped latent moves a pixel by < 1e-3 here)
+    if not any(n.values()):
+        assert d_hat < 1e-4 and d_bits < 1e-5
+
+
+def test_encode_B_gives_the_reference_container_at_1088x1920(dev, fx, model, frames):
+    """encode_B on the full frames: the integers handed to the range coder against the reference's; with no symbol
+    differing the four strings and the whole bits_B container are the reference's, byte for byte."""
+    from vcamd import lhbdc
+    xb, xc, xa = frames
+    trace = {}
+    with torch.no_grad():
+        mv_bits, res_bits = lhbdc.encode_B(model, xa, xc, xb, trace=trace)
+    n = {"mv_z": flips("mv z", trace["mv"]["z_sym"], fx["enc_mv_z_sym"]), "res_z": flips("res z", trace["res"]["z_sym"], fx["enc_res_z_sym"])}
+    n["mv_y"] = flips("mv y", trace["mv"]["y_sym"], fx["enc_mv_y_sym"], fx["enc_mv_y_fragile"] if not n["mv_z"] else None)
+    upstream = n["mv_z"] or n["mv_y"]
+    n["res_y"] = flips("res y", trace["res"]["y_sym"], fx["enc_res_y_sym"],
+                       fx["enc_res_y_fragile"] if not (upstream or n["res_z"]) else None)
+    n["mv_idx"] = flips("mv idx", trace["mv"]["y_idx"], fx["enc_mv_y_idx"])
+    n["res_idx"] = flips("res idx", trace["res"]["y_idx"], fx["enc_res_y_idx"])
+    strings = {"mv_y": mv_bits["strings"][0][0], "mv_z": mv_bits["strings"][1][0],
+               "res_y": res_bits["strings"][0][0], "res_z": res_bits["strings"][1][0]}
+    same = {k: v == fx[k].tobytes() for k, v in strings.items()}
+    blob = lhbdc.write_container(None, 1626, mv_bits, res_bits)
+    print(f"LHBDC encode_B vs THE REFERENCE at 1088x1920: integers differing {n}; strings byte-identical {same}; "
+          f"container {len(blob)} bytes vs {fx['container'].size}")
+    assert all(v <= MAX_FLIPS for v in n.values()), n
+    assert tuple(mv_bits["shape"]) == tuple(fx["mv_shape"]) and tuple(res_bits["shape"]) == tuple(fx["res_shape"])
+    for k, deps in (("mv_z", ("mv_z",)), ("mv_y", ("mv_z", "mv_y", "mv_idx")),
+                    ("res_z", ("mv_z", "mv_y", "res_z")), ("res_y", ("mv_z", "mv_y", "res_z", "res_y", "res_idx"))):
+        if not any(n[d] for d in deps):
+            assert same[k], k
+    if not any(n.values()):
+        assert blob == fx["container"].tobytes()
+    assert abs(len(blob) - fx["container"].size) <= 64
+
+
+def test_decode_B_reads_the_reference_container_at_1088x1920(dev, fx, bundled, model, frames):
+    """The reference's own bits_B container through the HIP decoder: every integer the range decoder produces equals the
+    reference encoder's, the uint8 frame is the reference's decoded.png up to isolated +-1 roundings."""
+    from vcamd import lhbdc
+    xb, _, xa = frames
+    trace = {}
+    with torch.no_grad():
+        lmbda, s_mv, s_res, sh_mv, sh_res = lhbdc.read_container(fx["container"].tobytes())
+        dec = lhbdc.decode_B(xb, xa, model, s_mv, s_res, sh_mv, sh_res, trace=trace)
+    assert lmbda == 1626
+    n = {f"{c}_{k}": flips(f"{c} {k}", trace[c][k], fx[f"enc_{c}_{k}"]) for c in ("mv", "res") for k in ("z_sym", "y_idx", "y_sym")}
+    ref_u8 = (fx["dec_u8_minus_current"].astype(np.int16) + bundled["current"].astype(np.int16)).astype(np.uint8)
+    u8 = to_u8(dec)
+    diff = u8.astype(np.int16) - ref_u8.astype(np.int16)
+    moved = float((diff != 0).mean())
+    d_psnr = abs(psnr_u8(u8, bundled["current"]) - float(fx["dec_psnr_u8"]))
+    d_sub = float((dec.cpu()[:, :, ::8, ::8] - torch.from_numpy(fx["dec_sub8"])).abs().max())
+    print(f"LHBDC decode_B of THE REFERENCE's container at 1088x1920: integers differing {n}; uint8 pixels differing "
+          f"{moved:.2e} (max {int(np.abs(diff).max())} level); float max|d| (1/8 grid) {d_sub:.2e}; dPSNR(uint8) {d_psnr:.2e} dB")
+    assert n["mv_z_sym"] == 0 and n["res_z_sym"] == 0              # decoded from the reference's strings with the same tables
+    assert n["mv_y_idx"] <= MAX_FLIPS and n["res_y_idx"] <= MAX_FLIPS
+    if n["mv_y_idx"] == 0:
+        assert n["mv_y_sym"] == 0
+    if n["res_y_idx"] == 0:
+        assert n["res_y_sym"] == 0
+    if not any(n.values()):
+        assert np.abs(diff).max() <= 1 and moved < 2e-3 and d_sub < 1e-4
+    assert d_psnr < 1e-3

@@ -44,7 +44,7 @@ extern "C" int vc_conv_chunk(int cfg, int k, int stride, int cin)
     case 1: return 32;
     case 3: return stride == 2 ? 8 : 32;
     case 5: return stride == 2 ? 8 : 16;
-    case 7: return (cfg == VC_CFG_N32 && cin <= 8) ? 8 : 16;
+    case 7: return ((cfg == VC_CFG_N32 || cfg == VC_CFG_N32T16) && cin <= 8) ? 8 : 16;   // (SPyNet's first layer: 8 input channels)
     }
     return -1;
 }
@@ -192,6 +192,7 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.out_f16 = (d->cfg & VC_CFG_OUT_F16) ? 1 : 0;
     if ((a.in_f16 || a.out_f16) && !f16) return VC_EINVAL;   // half-precision tensors exist on the fp16 path only
     a.res_f16 = (d->cfg & VC_CFG_RES_F16) ? 1 : 0;
+    a.pack128 = (d->cfg & VC_CFG_PACK128) ? 1 : 0;
     if (a.res_f16 && (!f16 || !d->res || (d->cfg & 0xff) != VC_CFG_PWS)) return VC_EINVAL;   // the streaming 1x1 kernel only
     a.res_first = (d->cfg & VC_CFG_RES_FIRST) ? 1 : 0;
     if (a.res_first && (!d->res || d->epi != VC_EPI_NONE || d->act == VC_ACT_SIGMOID || d->act == VC_ACT_CLAMP01)) return VC_EINVAL;

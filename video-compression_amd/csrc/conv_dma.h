@@ -113,7 +113,8 @@ template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0> struct
     } while (0)
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to lds_byte_addr + 16 * lane
-// (M0 is compiler-reserved: written, used and restored inside one statement -- cdna guide 5.7)
+// (M0 is compiler-managed: the restoring form saves and restores it inside one statement -- cdna guide 5.7 -- the
+// non-restoring forms declare it clobbered)
 template <bool RESTORE_M0 = true> __device__ __forceinline__ void vc_glds16(const void *src, unsigned lds_byte_addr)
 {
     if constexpr (RESTORE_M0) {
@@ -123,7 +124,7 @@ template <bool RESTORE_M0 = true> __device__ __forceinline__ void vc_glds16(cons
                      : "v"(src), "s"(lds_byte_addr)
                      : "memory");
     } else {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_byte_addr) : "memory", "m0");
     }
 }
 // the same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the address operand the issuing
@@ -132,7 +133,7 @@ template <bool RESTORE_M0 = true> __device__ __forceinline__ void vc_glds16(cons
 __device__ __forceinline__ void vc_glds16_sbase(const void *uniform_base, unsigned lane_off, unsigned lds_byte_addr)
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(uniform_base), "s"(lds_byte_addr)
-                 : "memory");
+                 : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void vc_wait_vmcnt()
 {

@@ -18,6 +18,9 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
     // weights and the bias to a multiple of 128 with zeros; the caller names this configuration only on such a packing)
     const int nt = (a.Cout >= 96) ? 4 : (a.Cout == 64 ? 2 : (a.Cout == 32 ? 1 : 0));
     if (!nt || (a.Cout % 4)) return VC_EINVAL;
+    if (nt == 4 && (a.Cout % 128) && !a.pack128) return VC_EINVAL;     // a partly padded last block needs the N128 packing
+    // per-lane source offsets are 32-bit: the footprint of a tile (KH + 15 rows, COLS <= 40 columns) must stay inside 2 GiB
+    if ((long long)(k + 15) * a.in_sh * 2 + 48ll * a.in_sw * 2 + 256 >= (1ll << 31)) return VC_EINVAL;
     a.tiles_x = (a.Wo + 31) / 32;
     a.tiles_y = (a.Ho + 15) / 16;
     a.nblks = (a.Cout + 32 * nt - 1) / (32 * nt);

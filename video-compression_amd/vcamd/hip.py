@@ -292,6 +292,7 @@ CFG_IN_F16 = 0x400
 CFG_OUT_F16 = 0x800
 CFG_RES_FIRST = 0x1000
 CFG_RES_F16 = 0x2000        # fp16 path, VC_CFG_PWS only: `res` is a half-precision tensor (the identity path of a bottleneck chain)
+CFG_PACK128 = 0x4000        # with CFG_DMA: weights / bias packed with the 128-channel configuration (padded to blocks of 128)
 CFG_DMA = 8               # fp16 path: LDS-DMA pipeline, one persistent workgroup per CU (csrc/conv_dma.h); half-precision input only
 CFG_PWS = 9               # streaming 1x1 kernel with LDS-DMA activation rings (csrc/conv_pws.hip)
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
@@ -469,7 +470,10 @@ class PackedConv:
         # (the tuned choice is per shape AND per epilogue class: the streaming 1x1 kernel, for one, takes plain / ReLU /
         #  GDN epilogues but not sigmoid or clamp, so a layer called both ways must not share one entry)
         key = (x.n, x.h, x.w, flags) if (act < ACT_SIGMOID and epi == EPI_NONE) else (x.n, x.h, x.w, flags, act, epi)
-        d.cfg = self._pick_cfg(d, key, flags)
+        # (stated on every call of a layer packed with the 128-channel configuration; only the LDS-DMA kernel reads it: its
+        #  blocks of 128 may run into the padding of 96 / 160 / 432 ... output channels.  Not part of the tuning key.)
+        pack = CFG_PACK128 if self.cfg == 0 else 0
+        d.cfg = self._pick_cfg(d, key, flags | pack) | pack
         what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})"
         if timer is None:
             check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
@@ -655,9 +659,12 @@ class PackedDeform:
         if out is None:
             out = T.empty(x1.n, x1.h, x1.w, self.cout, x1.buf.device)
         cg = self.cin // self.groups
+        # the half-precision-feature entry has ONE instance (csrc/deform.hip: vector gathers, <= 8 groups per reference, offset
+        # records fetched in 16-byte pieces): features AND both raw offset tensors 16-byte aligned with strides in whole float4s
         half_x = (_PRECISION == "fp16" and HALF_DEFORM and cg % 4 == 0 and cg >= 8 and self.groups <= 16 and raw1.c % 4 == 0
-                  and x1.dtype == "f32" and x2.dtype == "f32"
-                  and all(t.ptr % 16 == 0 and t.sw % 4 == 0 and t.sh % 4 == 0 and t.sn % 4 == 0 and t.c % 4 == 0 for t in (x1, x2)))
+                  and raw2.c % 4 == 0 and x1.dtype == "f32" and x2.dtype == "f32"
+                  and all(t.ptr % 16 == 0 and t.sw % 4 == 0 and t.sh % 4 == 0 and t.sn % 4 == 0 and t.c % 4 == 0 for t in (x1, x2))
+                  and all(t.ptr % 16 == 0 and t.sw % 4 == 0 and t.sh % 4 == 0 and t.sn % 4 == 0 for t in (raw1, raw2)))
         if half_x:
             x1, x2 = to_half(x1), to_half(x2)
         fn = lib().vc_offset_diversity_hx if half_x else lib().vc_offset_diversity

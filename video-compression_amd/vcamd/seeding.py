@@ -81,13 +81,19 @@ def seeded_state_dict(template, seed=1234, conv_gain=1.0):
 #   * the last synthesis convolutions shrink (the decoded residual is a small correction).
 # On the bench / test clips this lands at ~0.1-0.3 bpp and 27-31 dB (measured by bench.py's quality block).
 # ------------------------------------------------------------------------------------------------------------------
-CALIBRATION = {"flow_head": 0.02, "latent_gain_range": (0.01, 3.0), "latent_unit_std": {"mv_compressor": 0.26, "residual_compressor": 0.38},
+CALIBRATION = {"flow_head": 0.02, "latent_gain_range": (0.01, 3.0),
+               "latent_unit_std": {"mv_compressor": 0.26, "residual_compressor": 0.38, "flow_compressor": 1.1},
+               "latent_gain_scale": {"flow_compressor": 0.25},
                "hyper_latent": 8.0, "synthesis_out": 0.002, "scale_weight": 0.02, "mean_weight": 0.02, "scale_match": 1.0}
+# Flex-Rate (b_model.py:28-32): the U-Net flow predictor's output layer plays the part of SPyNet's flow heads, the
+# 19-channel flow codec that of the motion codec; gain matrices stay U[0.5, 2] (the four rate points differ by them).
+_FLOW_HEADS = ("flow_predictor.last",)
+_CODECS = ("mv_compressor", "residual_compressor", "flow_compressor")
 
 
 def calibrated_state_dict(template, seed=1234, cal=None):
     """``seeded_state_dict`` + the rescaling described above (LHBDC ``Model`` state dicts: FlowNet / mv_compressor /
-    residual_compressor keys).  Deterministic, host only.
+    residual_compressor keys; Flex-Rate ``BidirFlowRef``: flow_predictor / flow_compressor / residual_compressor).  Deterministic, host only.
 
     Latent channel c of a codec gets its own gain G_c, log-uniform over ``latent_gain_range`` (like a trained transform:
     most channels nearly dead, a few carrying the signal), and the scale head's bias for that channel is set to the
@@ -105,7 +111,9 @@ def calibrated_state_dict(template, seed=1234, cal=None):
     for k in list(sd):
         if k.startswith("FlowNet.") and k.endswith("netBasic.8.weight"):
             scale(k[: -len(".weight")], cal["flow_head"])
-    for codec in ("mv_compressor", "residual_compressor"):
+    for head in _FLOW_HEADS:
+        scale(head, cal["flow_head"])
+    for codec in _CODECS:
         wk, bk = f"{codec}.h_s.8.weight", f"{codec}.h_s.8.bias"
         if wk not in sd:
             continue
@@ -113,6 +121,7 @@ def calibrated_state_dict(template, seed=1234, cal=None):
         lo, hi = cal["latent_gain_range"]
         g = _rng(seed, codec + ":calibrated")
         gains = torch.from_numpy(np.exp(g.uniform(np.log(lo), np.log(hi), size=m))).to(sd[wk].dtype)
+        gains = gains * cal.get("latent_gain_scale", {}).get(codec, 1.0)       # (the 19-channel flow codec sees the frames themselves)
         scale(f"{codec}.g_a.6", gains)
         scale(f"{codec}.h_a.8", cal["hyper_latent"])
         scale(f"{codec}.g_s.7.0", cal["synthesis_out"])
@@ -122,4 +131,65 @@ def calibrated_state_dict(template, seed=1234, cal=None):
         b[:m] = cal["latent_unit_std"][codec] * cal["scale_match"] * gains
         b[m:] *= cal["mean_weight"]
         sd[wk], sd[bk] = w, b
+    return sd
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# An intra codec (compressai.zoo.mbt2018_mean architecture) that RECONSTRUCTS its input.  The zoo weights are not
+# available offline and plain seeded weights decode to noise (7 dB), which then feeds every B-frame of a GOP as its
+# reference.  This variant writes a linear transform codec into the same state-dict schema:
+#   analysis   conv 1: binomial low-pass + 2x decimation of R, G, B (3 channels in use);
+#              conv 2-4: space-to-depth (delta taps of the 5x5 stride-2 kernels): 3 -> 12 -> 48 -> 192 channels, exact;
+#              the last one also applies the latent gain (quantiser step = 1/gain of the intensity range);
+#   synthesis  the transposed twins: three depth-to-space stages (delta taps) and a 2x interpolation ([1 4 6 4 1]/8);
+#   GDN/IGDN   beta = 1, gamma ~ 0: the identity up to a 1e-3 perturbation;
+#   entropy    hyper-synthesis biases: scale = spread of the active latents, mean = their centre; idle channels at the
+#              scale floor.
+# Every structured tensor carries seeded noise of relative size ``noise`` on top, so no convolution degenerates into a
+# single-term sum (the numerics of the 5x5 kernels stay under test).  ~30 dB on the synthetic clips.
+# ------------------------------------------------------------------------------------------------------------------
+def calibrated_intra_state_dict(template, seed=1234, gain=16.0, noise=0.004):
+    sd = seeded_state_dict(template, seed=seed, conv_gain=noise)
+    n_mid, m_lat = sd["g_a.0.weight"].shape[0], sd["g_a.6.weight"].shape[0]
+    if n_mid < 48 or m_lat < 192:
+        raise ValueError("the pass-through construction needs N >= 48 and M >= 192")
+    b5 = torch.tensor([1.0, 4.0, 6.0, 4.0, 1.0], dtype=torch.float64)
+    low = torch.outer(b5, b5) / 256.0                       # analysis low-pass (sum 1)
+    up = torch.outer(b5, b5) / 64.0                         # synthesis interpolation (each output phase sums to 1)
+    dt = sd["g_a.0.weight"].dtype
+    for k in list(sd):
+        if k.endswith(".bias") and k.split(".")[0] in ("g_a", "g_s"):
+            sd[k] = sd[k] * 0.0
+    for c in range(3):
+        sd["g_a.0.weight"][c, c] += low.to(dt)
+        sd["g_s.6.weight"][c, c] += up.to(dt)
+    for stage, (wa, ws) in enumerate((("g_a.2.weight", "g_s.4.weight"), ("g_a.4.weight", "g_s.2.weight"),
+                                      ("g_a.6.weight", "g_s.0.weight"))):
+        cin = 3 * 4 ** stage
+        g = gain if stage == 2 else 1.0
+        for c in range(cin):
+            for p in range(2):
+                for q in range(2):
+                    o = 4 * c + 2 * p + q
+                    sd[wa][o, c, p + 2, q + 2] += g            # Conv2d weight [out, in, kh, kw]: pixel (2i+p, 2j+q) -> channel o
+                    sd[ws][o, c, p + 2, q + 2] += 1.0 / g      # ConvTranspose2d weight [in, out, kh, kw]: channel o -> pixel (2i+p, 2j+q)
+    for k in list(sd):
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "beta":
+            sd[k] = torch.sqrt(torch.ones_like(sd[k]) + 2.0 ** -36)
+        elif leaf == "gamma":
+            g_ = _rng(seed, k + ":intra")
+            eff = torch.from_numpy(g_.uniform(0.0, 1e-5, size=tuple(sd[k].shape)))
+            sd[k] = torch.sqrt(eff + 2.0 ** -36).to(sd[k].dtype)
+    # entropy parameters: [scales | means] biases of the last hyper-synthesis layer; its weights shrink so that the
+    # biases dominate (the hyper-latents of an untrained h_a carry nothing useful)
+    wk, bk = "h_s.4.weight", "h_s.4.bias"
+    sd[wk] = seeded_state_dict({wk: template[wk]}, seed=seed)[wk] * 0.02
+    b = torch.zeros_like(sd[bk])
+    b[:192] = 0.06 * gain                                  # spread of a band-limited texture's samples, in quantiser steps
+    b[192:m_lat] = 0.05
+    b[m_lat:m_lat + 192] = 0.5 * gain                      # mid-grey
+    sd[bk] = b
+    for k in ("h_a.0.weight", "h_a.2.weight", "h_a.4.weight", "h_s.0.weight", "h_s.2.weight"):
+        sd[k] = seeded_state_dict({k: template[k]}, seed=seed)[k]
     return sd
