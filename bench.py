@@ -252,6 +252,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--checkpoint", choices=["calibrated", "seeded"], default="calibrated",
                     help="LHBDC / Flex-Rate weights: calibrated = seeded weights rescaled to trained-like statistics (default), seeded = plain")
+    ap.add_argument("--skip-extras", action="store_true",
+                    help="N = 1: skip the whole-GOP-with-I-frame and real-bitstream blocks (profiling runs: the trace then holds the timed "
+                         "region and the one instrumented frame of the roofline block only)")
     ap.add_argument("--no-strong-block", action="store_true",
                     help="default (weak) LHBDC 1080p line: skip the extra `strong` block (one pass over a configs[3] test set sized by "
                          "--strong-seconds, GOP-sharded over the ranks, R-D table checksum)")
@@ -681,7 +684,7 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                        "model": args.model, "precision": args.precision, "resolution": args.resolution,
                        "conv_ms_per_frame": total_ms, "convolutions": rows, "hbm_kernels": result["hbm_kernels"]}, f, indent=1)
 
-    if not is_flex and not is_icip and args.resolution == "1080p" and args.scaling == "weak":
+    if not is_flex and not is_icip and args.resolution == "1080p" and args.scaling == "weak" and not args.skip_extras:
         # ---- whole GOP as testing.py codes it: 1 I-frame (mbt2018_mean q7 architecture) + 7 B-frames ----
         from vcamd import iframe
         i_model = iframe.mbt2018_mean(7, "mse", pretrained=False)
@@ -702,7 +705,7 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
         result["full_gop"] = {"frames_per_s": 8.0 / dt, "ms_per_gop": 1000.0 * dt,
                               "what": "1 I-frame (mbt2018_mean q7 architecture, vcamd.seeding.calibrated_intra_state_dict) + 7 B-frames per GOP, eager launches"}
 
-    if not is_flex and not is_icip and args.resolution == "1080p" and args.scaling == "weak" and not f16:
+    if not is_flex and not is_icip and args.resolution == "1080p" and args.scaling == "weak" and not f16 and not args.skip_extras:
         # ---- the same GOP through the REAL bitstream (encode_B / decode_B containers), host range coder pipelined ----
         from vcamd import bitstream
         model.mv_compressor.update(force=True)
@@ -880,15 +883,20 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                     tr = {}
                     mv_b, res_b = vlhbdc.encode_B(model, frames[pk[2]], frames[pk[1]], frames[pk[0]], trace=tr)
                     blob = vlhbdc.write_container(None, 1626, mv_b, res_b)
-                    nd = sum(int((torch.from_numpy(tr[c][k]).reshape(-1) != ref[c][k].reshape(-1)).sum())
-                             for c in ("mv", "res") for k in ("y_sym", "z_sym", "y_idx"))
+                    nd = {k: sum(int((torch.from_numpy(tr[c][k]).reshape(-1) != ref[c][k].reshape(-1)).sum()) for c in ("mv", "res"))
+                          for k in ("y_sym", "z_sym", "y_idx")}
                     same += blob == ref["container"]
-                    per.append({"frames": list(pk), "identical": blob == ref["container"], "bytes": len(blob), "integers_differing": nd})
+                    per.append({"frames": list(pk), "identical": blob == ref["container"], "bytes": len(blob),
+                                "symbols_differing": nd["y_sym"] + nd["z_sym"], "scale_indexes_differing": nd["y_idx"]})
             result["byte_equality"] = {"containers_identical": same, "of": len(picks), "triples": per, "oracle_s": round(t_oracle, 1),
                                        "oracle_workers_x_threads": list(pool.plan(len(picks))),
                                        "what": "end-to-end encode_B (frames -> bits_B container) against the CPU oracle's container, byte for "
-                                               "byte; calibrated checkpoint, 1088x1920; tests/test_byte_equality_gpu.py shows every miss to be "
-                                               "boundary-case flips"}
+                                               "byte; calibrated checkpoint, 1088x1920, ~1.2 M coded integers per frame.  A scale within fp32 "
+                                               "noise (3e-7) of one of the 64 log-spaced table entries falls into the neighbouring bin on "
+                                               "another platform: ~5e-6 per element, i.e. a handful of indexes per 1080p frame (the stream "
+                                               "carries no indexes: the CompressAI format's known cross-platform fragility); "
+                                               "tests/test_byte_equality_gpu.py shows every differing integer to be such a boundary case and "
+                                               ">= 6 of 8 containers identical at 192x256"}
         if not is_flex and not is_icip:
             # ---- the same frame on the OTHER checkpoint kind (plain seeded weights when the timed region ran the calibrated
             # ones: latents in the hundreds, 6 dB -- the integer parity has to hold there too) ----

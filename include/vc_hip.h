@@ -123,6 +123,15 @@ typedef struct {
     int act; float slope;
     int epi, in_xform, out_mode;
     int cfg;
+    /* Optional fused 1x1 layer behind a VC_CFG_DMA 3x3 layer (fp16 path; ICIP2024/src/model/elic.py:69-83: the tail of a
+     * ResidualBottleneckBlock: ... -> conv3x3 -> ReLU -> conv1x1, + identity).  With tail_wpk set the launch computes
+     *   out = W_tail . act(conv3x3(in)) + b_tail (+ res)
+     * -- `act` / `slope` belong to the 3x3 layer (none / ReLU / LeakyReLU with 0 <= slope <= 1), its result is rounded to half
+     * exactly as the unfused layer would store it and never leaves the CU; the residual (fp32, or half with VC_CFG_RES_F16)
+     * is added behind the 1x1 layer.  cin = cout = 128, plain output, no channel gain.  tail_wpk / tail_bias come from
+     * vc_conv_pack_tail_f16 (device copies).  Anything else returns VC_EINVAL.  NULL = no fused layer. */
+    const void *tail_wpk;
+    const float *tail_bias;
 } vc_conv_desc;
 
 int vc_conv_select_cfg(int cout, int cin, int k, int stride);
@@ -135,6 +144,9 @@ size_t vc_conv_packed_bias_floats(int cfg, int cout);
 int vc_conv_pack_weights(const float *w_oihw, const float *bias, int cout, int cin, int kh, int kw,
                          int stride, int cfg, int pixelshuffle, float *wpk_out, float *bias_out);
 size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride); /* 0 = not eligible */
+/* 1x1 weights [cout][cin] (fp32, host) -> the fused-tail fragments of vc_conv_desc.tail_wpk (cout * cin halves) and its bias
+ * (cout floats); cout = cin = 128. */
+int vc_conv_pack_tail_f16(const float *w, const float *bias, int cout, int cin, void *wpk_half_out, float *bias_out);
 int vc_conv_pack_weights_f16(const float *w_oihw, const float *bias, int cout, int cin, int kh, int kw,
                              int stride, int cfg, int pixelshuffle, void *wpk_half_out, float *bias_out);
 int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d);

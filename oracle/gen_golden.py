@@ -309,6 +309,14 @@ def gen_lhbdc_fullsize(outdir, frames, seed):
                 raise SystemExit(f"{prefix}_{k} does not fit {dt}")
             out[f"{prefix}_{k}"] = v.astype(dt)
         out[f"{prefix}_y_fragile"] = fragile_mask(lat["y"] - lat["means"], 2e-3)
+        # scale-table indexes: the reference's scale (clamped to the 0.11 bound) within 2e-5 (relative) of a table entry -- the
+        # only places where another platform's hyper-synthesis may legitimately land in the neighbouring bin
+        ls = torch.log(torch.clamp(lat["scales"], min=0.11)).double()
+        lt = torch.log(torch.as_tensor(table, dtype=torch.float64))
+        near = torch.zeros_like(ls, dtype=torch.bool)
+        for t_ in lt:
+            near |= (ls - t_).abs() < 2e-5
+        out[f"{prefix}_idx_fragile"] = np.packbits(near.reshape(-1).numpy())
         return out
 
     with torch.no_grad():

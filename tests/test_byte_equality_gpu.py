@@ -2,15 +2,22 @@
 the range-coder bitstream".)
 
 Coder-level equality is exact by construction (same integers -> same bytes: test_bitstream_gpu.py).  End to end the
-integers come out of fp32 convolution stacks whose summation order differs between the HIP kernels and oneDNN, so a latent
-within ~1e-6 of a rounding boundary may land on the other side.  This test puts a number on it: eight different 1088x1920
-frame triples, calibrated checkpoint (trained-like statistics), encode_B on both sides -- the count of byte-identical
-bits_B containers is asserted (>= 6 of 8) and every miss must be explained by boundary-case flips: each codec ALONE on the
-oracle's input differs from the oracle only where the oracle's own value sits within 2e-3 of a half-integer
-(test_fullsize_gpu.check_teacher_forced).  bench.py reports the same count as ``byte_equality``.
-
-The eight oracle passes run side by side (oracle.pool): the GPU host has far more cores than one pass can use.
+integers come out of fp32 convolution stacks whose summation order differs between the HIP kernels and oneDNN:
+  * a latent within ~1e-6 of a rounding boundary may round the other way (0-2 symbols per 1.04 M at 1080p), and
+  * a hyper-synthesis scale within ~3e-7 (relative) of one of the 64 log-spaced scale-table entries (0.123 apart in log)
+    falls into the neighbouring bin: 2 x 3e-7 / 0.123 = 5e-6 per element whose scale is above the 0.11 floor.
+The second effect is a property of the FORMAT (the stream carries no indexes; CompressAI streams are known not to be
+portable across platforms for this reason), and it scales with the frame: ~0.1 expected differing indexes on a 192x256
+crop, ~5 on a 1080p frame.  This test puts numbers on it, calibrated checkpoint (trained-like statistics), encode_B on
+both sides, eight different frame triples per size:
+  * 192x256: at least 6 of 8 bits_B containers are byte-identical to the CPU oracle's;
+  * 1088x1920: the count is REPORTED (a container is identical only if all 1.2 M integers are), and every differing integer
+    is shown to be a boundary case -- symbols: each codec alone on the oracle's input differs only where the oracle's own
+    value sits within 2e-3 of a half-integer (test_fullsize_gpu.check_teacher_forced); indexes: the oracle's own scale
+    within 2e-5 of a table entry, one bin apart, at most 2e-5 N of them.
+bench.py reports the same count as ``byte_equality``.  The oracle passes run side by side (oracle.pool).
 """
+import numpy as np
 import pytest
 import torch
 
@@ -26,15 +33,44 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_end_to_end_containers_byte_identical_to_the_cpu_path(dev):
+def triple(seed, h, w):
+    """Band-limited texture under a global translation + 1 % noise, 8-bit quantised (test_fullsize_gpu.frames_1080p at any size)."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, h + 24, w + 32, generator=g), 9, 1)
+    out = []
+    for t in range(3):
+        f = base[..., 2 * t:2 * t + h, 3 * t:3 * t + w] + 0.01 * torch.randn(1, 3, h, w, generator=g)
+        out.append((torch.round(f.clamp(0, 1) * 255.0) / 255.0).contiguous())
+    return out
+
+
+def index_flips_are_boundary_cases(tag, mine, ref_lat):
+    """Differing scale-table indexes: one bin apart, the oracle's own scale within 2e-5 (relative) of a table entry."""
+    from oracle.cai.entropy_models import get_scale_table
+    theirs = ref_lat["y_idx"].reshape(-1).numpy().astype(np.int64)
+    mine = np.asarray(mine).reshape(-1).astype(np.int64)
+    bad = np.nonzero(mine != theirs)[0]
+    if bad.size == 0:
+        return 0
+    assert np.abs(mine[bad] - theirs[bad]).max() == 1, tag
+    ls = np.log(np.maximum(ref_lat["scales"].reshape(-1).numpy()[bad].astype(np.float64), 0.11))
+    lt = np.log(np.asarray(get_scale_table(), dtype=np.float64))
+    dist = np.abs(ls[:, None] - lt[None, :]).min(1)
+    assert dist.max() < 2e-5, (tag, float(dist.max()))
+    assert bad.size <= max(2, int(2e-5 * theirs.size)), (tag, bad.size)
+    return int(bad.size)
+
+
+@pytest.mark.parametrize("h,w", [(192, 256), (1088, 1920)], ids=["192x256", "1088x1920"])
+def test_end_to_end_containers_against_the_cpu_path(dev, h, w):
     from helpers import lhbdc_pair
     from oracle import pool
-    from test_fullsize_gpu import check_teacher_forced, frames_1080p, teacher_forced
+    from test_fullsize_gpu import check_teacher_forced, teacher_forced
     from vcamd import lhbdc
     ora, prod = lhbdc_pair(1234, dev, calibrated=True)
     prod.mv_compressor.update(force=True)
     prod.residual_compressor.update(force=True)
-    triples = [frames_1080p(s) for s in SEEDS]
+    triples = [triple(s, h, w) for s in SEEDS]
     refs = pool.run_jobs(triples, pool.lhbdc_encode_job(ora.state_dict()))
     identical, report = 0, []
     with torch.no_grad():
@@ -44,18 +80,23 @@ def test_end_to_end_containers_byte_identical_to_the_cpu_path(dev):
             blob = lhbdc.write_container(None, 1626, mv_bits, res_bits)
             same = blob == ref["container"]
             identical += same
-            flips = {f"{c}_{k}": int((torch.from_numpy(trace[c][k]).reshape(-1) != ref[c][k].reshape(-1)).sum())
-                     for c in ("mv", "res") for k in ("y_sym", "z_sym", "y_idx")}
-            report.append((seed, same, len(blob), len(ref["container"]), flips))
+            sym = {f"{c}_{k}": int((torch.from_numpy(trace[c][k]).reshape(-1) != ref[c][k].reshape(-1)).sum())
+                   for c in ("mv", "res") for k in ("y_sym", "z_sym")}
+            # (the scales are a function of the hyper-latent symbols alone: with those equal, index differences are first-order)
+            idx = {f"{c}_idx": (index_flips_are_boundary_cases(f"triple {seed} {c}", trace[c]["y_idx"], ref[c]) if not sym[f"{c}_z_sym"] else
+                                int((torch.from_numpy(trace[c]["y_idx"]).reshape(-1) != ref[c]["y_idx"].reshape(-1)).sum()))
+                   for c in ("mv", "res")}
+            report.append((seed, same, len(blob), len(ref["container"]), sym, idx))
             if same:
-                assert not any(flips.values()), (seed, flips)
+                assert not any(sym.values()) and not any(idx.values()), (seed, sym, idx)
                 continue
-            # a miss: every flip has to be a boundary case -- each codec alone on the ORACLE's input
-            assert any(flips.values()), (seed, "containers differ although every coded integer is equal")
-            check_teacher_forced(f"triple {seed}: mv_compressor", teacher_forced(prod.mv_compressor, ref["mv"], dev))
-            check_teacher_forced(f"triple {seed}: residual_compressor", teacher_forced(prod.residual_compressor, ref["res"], dev))
+            assert any(sym.values()) or any(idx.values()), (seed, "containers differ although every coded integer is equal")
+            if any(sym.values()):       # every flipped symbol a boundary case: each codec alone on the ORACLE's input
+                check_teacher_forced(f"triple {seed}: mv_compressor", teacher_forced(prod.mv_compressor, ref["mv"], dev))
+                check_teacher_forced(f"triple {seed}: residual_compressor", teacher_forced(prod.residual_compressor, ref["res"], dev))
             assert abs(len(blob) - len(ref["container"])) <= max(64, 0.001 * len(blob)), (seed, len(blob), len(ref["container"]))
-    print(f"end-to-end encode_B containers byte-identical to the CPU path: {identical} of {len(SEEDS)} (1088x1920, calibrated checkpoint)")
-    for seed, same, n, m, flips in report:
-        print(f"  triple {seed}: {'identical' if same else 'DIFFERENT'} ({n} vs {m} bytes); integers differing {flips}")
-    assert identical >= 6, report
+    print(f"end-to-end encode_B containers byte-identical to the CPU path: {identical} of {len(SEEDS)} ({h}x{w}, calibrated checkpoint)")
+    for seed, same, n, m, sym, idx in report:
+        print(f"  triple {seed}: {'identical' if same else 'DIFFERENT'} ({n} vs {m} bytes); symbols differing {sym}; indexes differing {idx}")
+    if h * w <= 192 * 256:
+        assert identical >= 6, report

@@ -1,0 +1,63 @@
+"""The committed rocprofv3 evidence of the headline run (profiles/r04/, collected by tools/profile_r04.sh on the MI355X box:
+`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-strong-block --skip-extras --steps 3 --warmup 1`) is parsed
+and held against the bench line printed by the SAME process:
+
+  * no PyTorch operator kernel (`at::native`, elementwise / reduction / copy kernels of ATen) takes more than 0.1 % of the
+    GPU time -- the data path is this repository's HIP kernels, not a torch fallback;
+  * the dominant kernel's launches (the 16-row 7x7 instance on 4 x 1088 x 1920, told apart from the same template's
+    smaller pyramid levels by their grid size) average, in the profiler's trace, what bench.py's HIP events measured:
+    `roofline.frac` is reproduced within 2 %.
+Files only: runs without a GPU.
+"""
+import csv
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles", "r04")
+STATS = os.path.join(PROF, "a_rocprofv3_kernel_stats.csv")
+TRACE = os.path.join(PROF, "a_kernel_trace_by_grid.json")
+LINE = os.path.join(PROF, "a_headline_under_rocprofv3_line.json")
+
+needs_profile = pytest.mark.skipif(not all(os.path.exists(p) for p in (STATS, TRACE, LINE)),
+                                   reason="profiles/r04 headline trace not collected yet (tools/profile_r04.sh)")
+
+
+def bench_line():
+    with open(LINE) as f:
+        lines = [ln for ln in f.read().splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@needs_profile
+def test_no_torch_operator_kernel_on_the_data_path():
+    rows = list(csv.DictReader(open(STATS, newline="")))
+    total = sum(int(r["TotalDurationNs"]) for r in rows)
+    ours = sum(int(r["TotalDurationNs"]) for r in rows if "conv_" in r["Name"] or r["Name"].startswith(("void k_", "k_", "void (anonymous namespace)::k_")))
+    assert total > 0 and ours / total > 0.97, (ours, total)
+    for r in rows:
+        if "at::native" in r["Name"] or "at::cuda" in r["Name"]:
+            share = int(r["TotalDurationNs"]) / total
+            assert share < 1e-3, (r["Name"][:120], share)
+
+
+@needs_profile
+def test_dominant_kernel_time_in_the_trace_reproduces_the_roofline_fraction():
+    line = bench_line()
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["kernel"].startswith("conv k7 s1") and "@4x1088x1920" in roof["kernel"]
+    trace = json.load(open(TRACE))
+    # 16 x 32-pixel tiles of 32 channels: 68 x 60 tiles x 4 images x (cout / 32) workgroups of 256 threads
+    cout = int(roof["kernel"].split("->")[1].split()[0])
+    grid = 68 * 60 * 4 * (cout // 32) * 256
+    mine = [k for k in trace["kernels"] if "conv_mfma_kernel<7, 7, 1, 16, TileCfg<32, 16" in k["name"] and k["grid_threads"] == grid]
+    assert mine, [k["grid_threads"] for k in trace["kernels"] if "conv_mfma_kernel<7, 7" in k["name"]][:10]
+    n = sum(k["dispatches"] for k in mine)
+    avg_ms = sum(k["total_ns"] for k in mine) / n / 1e6
+    frac = roof["algorithmic_flop_per_launch"] / (avg_ms * 1e-3) / 1e12 / roof["peak"]
+    print(f"dominant kernel: {n} dispatches in the trace, {avg_ms:.3f} ms average -> {frac:.4f} of peak; bench.py HIP events: "
+          f"{roof['avg_launch_ms']:.3f} ms -> {roof['frac']:.4f}")
+    assert abs(frac - roof["frac"]) / roof["frac"] < 0.02

@@ -158,6 +158,25 @@ extern "C" int vc_conv_pack_weights_f16(const float *w, const float *bias, int c
     return VC_OK;
 }
 
+// Weights of the 1x1 layer fused behind a VC_CFG_DMA 3x3 layer (vc_conv_desc.tail_wpk): half-precision MFMA fragments
+// [n-tile o][k-step j][lane (m, h)][8] with the k order of the 3x3 layer's ACCUMULATOR layout: value i of lane (m, h) of fragment
+// (o, j) is w[32 o + m][16 j + 4 h + (i & 3) + 8 (i >> 2)].  cout = cin = 128.
+extern "C" int vc_conv_pack_tail_f16(const float *w, const float *bias, int cout, int cin, void *wpk_half_out, float *bias_out)
+{
+    if (!w || !wpk_half_out || !bias_out || cout != 128 || cin != 128) return VC_EINVAL;
+    _Float16 *dst = static_cast<_Float16 *>(wpk_half_out);
+    for (int o = 0; o < cout / 32; ++o)
+        for (int j = 0; j < cin / 16; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 31, h = lane >> 5;
+                for (int i = 0; i < 8; ++i)
+                    dst[(((size_t)o * (cin / 16) + j) * 64 + lane) * 8 + i] =
+                        (_Float16)w[(size_t)(32 * o + m) * cin + 16 * j + 4 * h + (i & 3) + 8 * (i >> 2)];
+            }
+    for (int c = 0; c < cout; ++c) bias_out[c] = bias ? bias[c] : 0.0f;
+    return VC_OK;
+}
+
 extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
 {
     if (!d || !d->in.p || !d->out.p || !d->wpk || !d->bias) return VC_EINVAL;
@@ -193,7 +212,11 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     if ((a.in_f16 || a.out_f16) && !f16) return VC_EINVAL;   // half-precision tensors exist on the fp16 path only
     a.res_f16 = (d->cfg & VC_CFG_RES_F16) ? 1 : 0;
     a.pack128 = (d->cfg & VC_CFG_PACK128) ? 1 : 0;
-    if (a.res_f16 && (!f16 || !d->res || (d->cfg & 0xff) != VC_CFG_PWS)) return VC_EINVAL;   // the streaming 1x1 kernel only
+    a.tail_wpk = d->tail_wpk;
+    a.tail_bias = d->tail_bias;
+    if (a.tail_wpk && (!f16 || (d->cfg & 0xff) != VC_CFG_DMA)) return VC_EINVAL;             // the fused tail lives in the LDS-DMA kernel
+    // a half-precision residual: the streaming 1x1 kernel, or the LDS-DMA kernel's fused-tail epilogue
+    if (a.res_f16 && (!f16 || !d->res || !((d->cfg & 0xff) == VC_CFG_PWS || ((d->cfg & 0xff) == VC_CFG_DMA && a.tail_wpk)))) return VC_EINVAL;
     a.res_first = (d->cfg & VC_CFG_RES_FIRST) ? 1 : 0;
     if (a.res_first && (!d->res || d->epi != VC_EPI_NONE || d->act == VC_ACT_SIGMOID || d->act == VC_ACT_CLAMP01)) return VC_EINVAL;
     a.cin_pad = round_up(a.Cin, f16 ? 2 * ck : ck);

@@ -29,11 +29,15 @@ static __device__ __attribute__((aligned(1024))) unsigned char g_vc_dma_dump[102
 // other parts cost): 1 no epilogue, 2 no vmcnt waits, 4 no MFMAs, 8 no fragment reads, 16 no DMA, 32 no stagger, 64 cycle stamps, 128 no s_setprio around the MFMAs, 256 DMA issue BEFORE the fragment reads,
 // 512 M0 not restored, 1024 no A DMA, 2048 no B DMA, 4096 two A pieces per phase, 8192 weights by 64-bit lane addresses,
 // 16384 no fast epilogue.  Shipped instances use 0.
-template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0> struct DmaCfg {
+// TAIL_: the bottleneck-block instance (ICIP2024/src/model/elic.py:69-83: ... -> conv3x3 -> ReLU -> conv1x1, + identity): the
+// workgroup also holds the trailing 1x1 layer's weights in LDS and applies it to its accumulators before anything is stored
+// (dma_epilogue_tail).  Every wave then owns ALL output channels of its rows (WAVES_N = 1): the 1x1 contracts over them.
+template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0, bool TAIL_ = false> struct DmaCfg {
     static constexpr int KO = KO_;
+    static constexpr bool TAIL = TAIL_;
     static constexpr int KH = KH_, KW = KW_, TAPS = KH_ * KW_, NCHUNK = NCHUNK_, NT = NT_, RING = RING_;
     static constexpr int MT = 32, TH = 16, XT = 1, TW = 32;
-    static constexpr int WAVES = 8, WAVES_N = (NT_ == 4) ? 2 : 1, WAVES_M = WAVES / WAVES_N;
+    static constexpr int WAVES = 8, WAVES_N = (NT_ == 4 && !TAIL_) ? 2 : 1, WAVES_M = WAVES / WAVES_N;
     static constexpr int WM = TH / WAVES_M, WN = NT_ / WAVES_N;
     static constexpr int BN = NT_ * 32;
     // a phase = 8 weight fragments (8 KiB, one DMA instruction per wave) = UPP (chunk, tap) units of 2 k-steps
@@ -43,8 +47,11 @@ template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0> struct
     static constexpr int NA = (PIX * 4 + 511) / 512;          // DMA instructions per wave and chunk image (512 lanes x 16 B)
     static constexpr int A_BYTES = NA * 8192;
     static constexpr int B_OFF = 2 * A_BYTES, B_BYTES = RING_ * 8192;
-    static constexpr int BIAS_OFF = B_OFF + B_BYTES;
+    // TAIL: the 1x1 layer's NT x (2 NT) fragments of 1 KiB ([n-tile][k-step], vc_conv_pack_tail_f16) and its bias
+    static constexpr int TAIL_OFF = B_OFF + B_BYTES, TAIL_BYTES = TAIL_ ? NT_ * 2 * NT_ * 1024 + BN * 4 : 0;
+    static constexpr int BIAS_OFF = TAIL_OFF + TAIL_BYTES;
     static constexpr int LDS_FIXED = BIAS_OFF;                // + 4 * Cout (padded) at launch
+    static_assert(!TAIL_ || (NT_ == 4 && NCHUNK_ == 4 && KH_ == 3), "the fused tail: 3x3 128 -> 128 followed by 1x1 128 -> 128");
     // stores per wave and tile the counted waits may rely on: the fast epilogue issues WM * WN * 2 (16 bytes per lane),
     // the general one twice as many (a wait that counts too few younger operations only waits a little longer)
     static constexpr int NST = WM * WN * 2;
@@ -286,6 +293,96 @@ __device__ __forceinline__ void dma_epilogue_fast(const ConvArgs &p, f32x16 (&ac
     });
 }
 
+// Bottleneck-block epilogue (DmaCfg::TAIL): out = W2 . act(conv3x3) + b2 (+ residual), the block's trailing 1x1 layer applied
+// to the accumulators M-tile by M-tile.  The accumulator layout IS a B operand of v_mfma_f32_32x32x16_f16 up to a permutation of k
+// (lane (pixel, h), registers 8 (j % 2) .. + 7 of N-tile j / 2 = channels 32 (j / 2) + 16 (j % 2) + 4 h + {0..3, 8..11}); the 1x1 weights
+// are packed to that k order (vc_conv_pack_tail_f16), so no value moves between lanes: activation + rounding to half (exactly
+// what the unfused 3x3 layer stores), 32 MFMAs per M-tile with the weight fragments read from LDS one k-step ahead, then the
+// coalesced exchange / residual / store of dma_epilogue_mode.  Every store is issued (dump page), like there.
+template <class C>
+__device__ __forceinline__ void dma_epilogue_tail(const ConvArgs &p, f32x16 (&acc)[C::WM][C::WN], int wm, int lane, int oy0, int ox0, int img,
+                                                  float *scratch, const unsigned char *lds8)
+{
+    constexpr int WM = C::WM, WN = C::WN, NT = C::NT, KQ = 2 * NT;
+    static_assert(WN == NT, "every wave owns all channels of its pixels");
+    const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+    const int wpx = lane & 31, whalf = lane >> 5;
+    const int rq = lane & 7, rpx = lane >> 3;
+    const unsigned char *const wl = lds8 + C::TAIL_OFF + 16 * lane;
+    const float *const b2 = reinterpret_cast<const float *>(lds8 + C::TAIL_OFF + NT * KQ * 1024);
+    float *const dump = reinterpret_cast<float *>(g_vc_dma_dump) + 4 * lane;
+    static_for<0, WM>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int oy = oy0 + wm * WM + t;
+        f32x16 acc2[NT];
+#pragma unroll
+        for (int o = 0; o < NT; ++o)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(&b2[o * 32 + 8 * g + 4 * whalf]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc2[o][4 * g + e] = b[e];
+            }
+        f32x4 wf[2][NT];
+#pragma unroll
+        for (int o = 0; o < NT; ++o) wf[0][o] = *reinterpret_cast<const f32x4 *>(wl + (o * KQ) * 1024);
+        static_for<0, KQ>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + 1 < KQ) {
+#pragma unroll
+                for (int o = 0; o < NT; ++o) wf[(j + 1) & 1][o] = *reinterpret_cast<const f32x4 *>(wl + (o * KQ + j + 1) * 1024);
+            }
+            f16x8 bop;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = acc[t][j / 2][8 * (j % 2) + i];
+                bop[i] = (_Float16)vc_max_f32(v, v * neg);
+            }
+#pragma unroll
+            for (int o = 0; o < NT; ++o)
+                acc2[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[j & 1][o]), bop, acc2[o], 0, 0, 0);
+        });
+        // ---- exchange, residual, store: one N-tile at a time through this wave's scratch ----
+        static_for<0, NT>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc2[n][4 * g], acc2[n][4 * g + 1], acc2[n][4 * g + 2], acc2[n][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(&scratch[wpx * VC_EPI_ROWF + 8 * g + 4 * whalf]) = v;
+            }
+            const int co = n * 32 + 4 * rq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pix = 8 * j + rpx;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&scratch[pix * VC_EPI_ROWF + 4 * rq]);
+                const int ox = ox0 + pix;
+                const bool ok = oy < p.Ho && ox < p.Wo;
+                const long long o_off = (long long)img * p.out_sn + (long long)oy * p.out_sh + (long long)ox * p.out_sw + co;
+                if (p.res) {
+                    const long long r_off = (long long)img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + co;
+                    if (p.res_f16) {
+                        f16x4 rh = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                        if (ok) rh = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(p.res) + r_off);
+                        v += f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                    } else {
+                        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                        if (ok) r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                        v += r;
+                    }
+                }
+                if (p.out_f16) {
+                    const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    _Float16 *dst = ok ? reinterpret_cast<_Float16 *>(p.out) + o_off : reinterpret_cast<_Float16 *>(dump);
+                    *reinterpret_cast<f16x4 *>(dst) = hv;
+                } else {
+                    float *dst = ok ? p.out + o_off : dump;
+                    *reinterpret_cast<f32x4 *>(dst) = v;
+                }
+            }
+        });
+    });
+}
+
 template <class C>
 __device__ __forceinline__ void dma_epilogue(const ConvArgs &p, f32x16 (&acc)[C::WM][C::WN], int nblk, int wm, int wn, int lane,
                                              int oy0, int ox0, int img, float *scratch)
@@ -386,6 +483,11 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
     // ---- prologue: bias of every channel block, first chunk image, weights of the first RING-2 phases ----
     float *const ldsf = reinterpret_cast<float *>(lds8);
     for (int i = tid; i < p.nblks * C::BN; i += 512) ldsf[C::BIAS_OFF / 4 + i] = p.bias[i];
+    if constexpr (C::TAIL) {     // the trailing 1x1 layer: its fragments by DMA (lane-linear 1 KiB blocks), its bias behind them
+        const unsigned char *const tw = reinterpret_cast<const unsigned char *>(p.tail_wpk);
+        for (int f = wave; f < NT * 2 * NT; f += 8) vc_glds16_sbase(tw + f * 1024, (unsigned)(16 * lane), (unsigned)(C::TAIL_OFF + f * 1024));
+        for (int i = tid; i < C::BN; i += 512) ldsf[(C::TAIL_OFF + NT * 2 * NT * 1024) / 4 + i] = p.tail_bias[i];
+    }
     DmaTile nxt = tile_at(1);
     const unsigned char *cur_base = tile_base(cur), *nxt_base = tile_base(nxt);
 #pragma unroll
@@ -533,6 +635,8 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
             for (int t = 0; t < WM; ++t)
 #pragma unroll
                 for (int n = 0; n < WN; ++n) VC_DMA_KEEP(acc[t][n]);
+        } else if constexpr (C::TAIL) {
+            dma_epilogue_tail<C>(p, acc, wm, lane, cur.oy0, cur.ox0, cur.img, scratch, lds8);
         } else {
             const bool fast = !(C::KO & 16384) && p.out_f16 && !p.res && !p.chscale && p.out_mode == VC_OUT_PLAIN &&
                               (p.act == VC_ACT_NONE || p.act == VC_ACT_RELU || (p.act == VC_ACT_LRELU && p.slope >= 0.0f && p.slope <= 1.0f)) &&

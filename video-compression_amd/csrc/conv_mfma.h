@@ -86,6 +86,8 @@ struct ConvArgs {
     int tile_band;         // tile rows per band of the 2-D tile order (vc_tile_xy)
     int res_f16;           // VC_CFG_PWS on the fp16 path only: `res` points at a half-precision tensor
     int pack128;           // VC_CFG_PACK128: weights and bias are padded to whole blocks of 128 output channels
+    const void *tail_wpk;  // VC_CFG_DMA only: fused trailing 1x1 layer (vc_conv_pack_tail_f16), NULL = none
+    const float *tail_bias;
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

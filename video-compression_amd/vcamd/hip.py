@@ -45,7 +45,8 @@ class ConvDesc(ctypes.Structure):
                 ("kh", ctypes.c_int), ("kw", ctypes.c_int), ("stride", ctypes.c_int),
                 ("act", ctypes.c_int), ("slope", ctypes.c_float),
                 ("epi", ctypes.c_int), ("in_xform", ctypes.c_int), ("out_mode", ctypes.c_int),
-                ("cfg", ctypes.c_int)]
+                ("cfg", ctypes.c_int),
+                ("tail_wpk", ctypes.c_void_p), ("tail_bias", ctypes.c_void_p)]      # fused 1x1 tail (VC_CFG_DMA), include/vc_hip.h
 
 
 _lib = None
@@ -120,6 +121,7 @@ def lib():
     sig("vc_conv_pack_weights", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp)
     sig("vc_conv_packed_weight_bytes_f16", sz, ci, ci, ci, ci, ci, ci)
     sig("vc_conv_pack_weights_f16", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp)
+    sig("vc_conv_pack_tail_f16", ci, vp, vp, ci, ci, vp, vp)
     sig("vc_conv2d_nhwc", ci, vp, ctypes.POINTER(ConvDesc))
     sig("vc_nchw_to_nhwc", ci, vp, vp, View)
     sig("vc_nhwc_to_nchw", ci, vp, View, vp)
@@ -168,7 +170,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "vc_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
     "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
-    "vc_conv_pack_weights_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
+    "vc_conv_pack_weights_f16", "vc_conv_pack_tail_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
@@ -308,6 +310,9 @@ HALF_ACTIVATIONS = bool(int(os.environ.get("VC_HALF_ACTIVATIONS", "1")))
 # as half in HBM too.  NOT bit-neutral (one more rounding of the identity per block; VC_CFG_RES_F16): part of the fp16 mode's
 # stated tolerance.  VC_HALF_RESIDUAL=0 keeps the identity fp32 (A/B, tests).
 HALF_RESIDUAL = bool(int(os.environ.get("VC_HALF_RESIDUAL", "1")))
+# fp16 path: the trailing 1x1 layer of a bottleneck block (ICIP2024/src/model/elic.py:69-83) rides in the epilogue of the block's
+# 3x3 layer (LDS-DMA kernel, vc_conv_desc.tail_wpk): the 3x3 layer's output never reaches HBM.  VC_FUSE_TAIL=0 = three launches.
+FUSE_TAIL = bool(int(os.environ.get("VC_FUSE_TAIL", "1")))
 # fp16 path only: the deformable fusion of ICIP2024 gathers from HALF-precision copies of its feature maps (8 / 16 channels per
 # group: one 16-byte gather per corner instead of two; the kernel is bound by its gathers).  Offsets, modulation, bilinear
 # weights and accumulation stay fp32.  VC_HALF_DEFORM=0 gathers fp32 features (A/B, tests).
@@ -364,6 +369,9 @@ class PackedConv:
                       "vc_conv_pack_weights_f16")
                 self.wpk16 = torch.from_numpy(w16).to(device)
         self.tuned = {}
+        self._tail = None
+        self._raw = (wnp, bnp) if (_PRECISION == "fp16" and kh == 1 and stride == 1 and cout == 128 and cin == 128 and not pixelshuffle) else None
+        self._device = device
         ck = L.vc_conv_chunk(self.cfg, kh, stride, cin)
         self.candidates = [c for c in range(self.cfg, 3) if L.vc_conv_chunk(c, kh, stride, cin) == ck] if self.cfg <= 2 else []
         if self.cfg == 0 and kh == 3 and stride == 1:
@@ -412,6 +420,24 @@ class PackedConv:
         self.tuned[key] = best | CFG_EXACT | flags
         return self.tuned[key]
 
+    def tail_pack(self):
+        """This 1x1 128 -> 128 layer as the fused tail of a 3x3 layer (vc_conv_pack_tail_f16): (weights, bias) on the device."""
+        if self._tail is None:
+            if self._raw is None:
+                raise VcError("only a 1x1 128 -> 128 layer of the fp16 path can be fused behind a 3x3 layer")
+            wnp, bnp = self._raw
+            w16 = np.empty(128 * 128, dtype=np.float16)
+            b = np.empty(128, dtype=np.float32)
+            check(lib().vc_conv_pack_tail_f16(np.ascontiguousarray(wnp.reshape(128, 128)).ctypes.data, None if bnp is None else bnp.ctypes.data,
+                                              128, 128, w16.ctypes.data, b.ctypes.data), "vc_conv_pack_tail_f16")
+            self._tail = (torch.from_numpy(w16).to(self._device), torch.from_numpy(b).to(self._device))
+        return self._tail
+
+    def can_fuse_tail(self, tail):
+        """True when ``tail`` (a 1x1 PackedConv) can ride in this 3x3 layer's epilogue: fp16 path, 128 -> 128 -> 128."""
+        return (FUSE_TAIL and self.wpk16 is not None and self.k == 3 and self.stride == 1 and not self.ps and self.cin == 128
+                and self.cout == 128 and CFG_DMA in self.candidates and tail._raw is not None and tail.wpk16 is not None)
+
     def out_shape(self, h, w):
         k, s = self.k, self.stride
         ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
@@ -429,7 +455,7 @@ class PackedConv:
         return self.wpk16 is not None and CFG_PWS in self.candidates
 
     def __call__(self, x, out=None, act=ACT_NONE, slope=0.01, res=None, epi=EPI_NONE, mul=None,
-                 in_xform=IN_NONE, chscale=None, out_f16=False, res_first=False):
+                 in_xform=IN_NONE, chscale=None, out_f16=False, res_first=False, tail=None):
         """``out_f16``: a hint that every consumer of the result is an fp16-path convolution (``half_ok``), so the
         result may be stored as half (bit-identical downstream, half the traffic).  Honoured only when this layer
         itself runs on the fp16 path and allocates its own output; otherwise the result stays fp32."""
@@ -449,7 +475,10 @@ class PackedConv:
         d.inp, d.out = x.view(True), out.view(True)
         d.wpk, d.bias = self.wpk.data_ptr(), self.bias.data_ptr()
         res_half = res is not None and res.dtype == "f16"
-        if res_half and not (use16 and self.half_res_ok and epi == EPI_NONE and act < ACT_SIGMOID):
+        if tail is not None and not (self.can_fuse_tail(tail) and use16 and half_in and epi == EPI_NONE and act < ACT_SIGMOID
+                                     and chscale is None and not res_first):
+            raise VcError("fused tail: a half-precision activation through a 3x3 128 -> 128 layer of the fp16 path (PackedConv.can_fuse_tail)")
+        if res_half and tail is None and not (use16 and self.half_res_ok and epi == EPI_NONE and act < ACT_SIGMOID):
             raise VcError("a half-precision residual needs the fp16 path's streaming 1x1 kernel (PackedConv.half_res_ok)")
         if res is not None:
             d.res, d.res_sn, d.res_sh, d.res_sw = res.ptr, res.sn, res.sh, res.sw
@@ -473,14 +502,19 @@ class PackedConv:
         # (stated on every call of a layer packed with the 128-channel configuration; only the LDS-DMA kernel reads it: its
         #  blocks of 128 may run into the padding of 96 / 160 / 432 ... output channels.  Not part of the tuning key.)
         pack = CFG_PACK128 if self.cfg == 0 else 0
-        d.cfg = self._pick_cfg(d, key, flags | pack) | pack
-        what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout})"
+        if tail is not None:          # out = tail(act(conv3x3(x))) + res in ONE launch of the LDS-DMA kernel
+            tw, tb = tail.tail_pack()
+            d.tail_wpk, d.tail_bias = tw.data_ptr(), tb.data_ptr()
+            d.cfg = CFG_DMA | CFG_EXACT | flags | pack
+        else:
+            d.cfg = self._pick_cfg(d, key, flags | pack) | pack
+        what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout}{'+1x1 tail' if tail is not None else ''})"
         if timer is None:
             check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
         else:
             hq, wq = (ho // 2, wo // 2) if self.ps else (ho, wo)
-            flops = 2.0 * x.n * hq * wq * self.cout * self.cin * self.k * self.k
-            key = f"conv k{self.k} s{self.stride} {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
+            flops = 2.0 * x.n * hq * wq * self.cout * (self.cin * self.k * self.k + (tail.cin if tail is not None else 0))
+            key = f"conv k{self.k}{'+k1' if tail is not None else ''} s{self.stride} {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
             nbytes = (x.n * x.h * x.w * self.cin * (2 if half_in else 4) + x.n * ho * wo * co * (2 if half_out else 4)
                       + self.cout * self.cin * self.k * self.k * (2 if use16 else 4)
                       + (x.n * ho * wo * co * (2 if res_half else 4) if res is not None else 0) + (x.n * ho * wo * co * 4 if mul is not None else 0))

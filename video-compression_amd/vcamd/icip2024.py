@@ -67,6 +67,10 @@ class ResidualBottleneckBlock(_Prepared):
         if x.dtype == "f16" and not self.half_stream_ok():
             raise hip.VcError("a half-precision tensor reached a bottleneck block that keeps its identity path in fp32")
         t = c1(x, act=hip.ACT_RELU, out_f16=c2.half_ok)        # both intermediates feed one convolution each:
+        if t.dtype == "f16" and c2.can_fuse_tail(c3) and (x.dtype == "f32" or self.half_stream_ok()):
+            # fp16 path, 128 channels: the trailing 1x1 + identity in the 3x3 layer's epilogue (hip.FUSE_TAIL) -- the 3x3
+            # layer's output (rounded to half exactly as it would be stored) never leaves the CU
+            return c2(t, act=hip.ACT_RELU, tail=c3, res=x, out=out, out_f16=bool(out_f16 and out is None and self.half_stream_ok()))
         t = c2(t, act=hip.ACT_RELU, out_f16=c3.half_ok)        # half-precision storage on the fp16 path
         return c3(t, res=x, out=out, out_f16=bool(out_f16 and out is None and self.half_stream_ok()))
 

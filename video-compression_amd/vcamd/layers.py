@@ -678,7 +678,12 @@ class MeanScaleHyperprior(_Prepared):
         return run_sequential(self.g_s, y_hat, self._cache["g_s"], final_act=final_act)
 
     def decompress_t(self, strings, shape, device, gains=(None, None, None, None), final_act=None, trace=None):
-        """``trace``: a dict that receives the decoder's integers ("z_sym", "y_idx", "y_sym": host int32 [n, count])."""
+        """``trace``: a dict that receives the decoder's integers ("z_sym", "y_idx", "y_sym": host int32 [n, count]).
+        A ``trace["y_idx_override"]`` entry (int32 [n, count], put there by the caller) replaces the scale-table indexes
+        this decoder derived -- a cross-platform diagnostic: the CompressAI format carries no indexes, every decoder re-derives
+        them from ITS hyper-synthesis output, and a scale within fp32 noise of a table entry lands in the neighbouring bin
+        on another platform (the stream is then undecodable there).  The parity tests use it to show that such boundary
+        cases are the ONLY thing between this decoder and a stream written by the reference on a CPU."""
         assert isinstance(strings, list) and len(strings) == 2
         g, ig, hg, hig = gains
         L = hip.lib()
@@ -703,6 +708,8 @@ class MeanScaleHyperprior(_Prepared):
         idx_h = idx_d.cpu().numpy().reshape(n, -1)
         if trace is not None:
             trace.update({"z_sym": z_sym, "y_idx": idx_h})
+            if trace.get("y_idx_override") is not None:
+                idx_h = np.ascontiguousarray(np.asarray(trace["y_idx_override"], dtype=np.int32).reshape(n, -1))
         y_sym = np.stack([hip.rans_decode(strings[0][i], idx_h[i], gc_cdf, gc_len, gc_off) for i in range(n)])
         if trace is not None:
             trace["y_sym"] = y_sym

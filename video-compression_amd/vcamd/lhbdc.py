@@ -460,6 +460,10 @@ def decode_B(x_before, x_after, model, string_flow, string_res, shape_flow, shap
     dev = xb_.device
     flow_ba, flow_ab, hh, ww = _cli_predictors(model, {"b": xb_, "a": xa_}, n)
     t_mv, t_res = ({}, {}) if trace is not None else (None, None)
+    if trace is not None:      # (cross-platform diagnostic, see MeanScaleHyperprior.decompress_t)
+        t_mv["y_idx_override"] = trace.get("y_idx_override", {}).get("mv")
+        t_res["y_idx_override"] = trace.get("y_idx_override", {}).get("res")
+        trace.update({"mv": t_mv, "res": t_res})          # (filled as decoding proceeds: still there if a string is refused)
     mv_hat = model.mv_compressor.decompress_t(string_flow, shape_flow, dev, trace=t_mv)
     xb, xa = hip.nchw_to_nhwc(xb_), hip.nchw_to_nhwc(xa_)
     pred, _ = model._predict(xb, xa, mv_hat, flow_ab, flow_ba, hh, ww)
