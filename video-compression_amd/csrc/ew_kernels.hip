@@ -514,6 +514,27 @@ __global__ void k_warp(int convention, vc_view img, vc_view flow, vc_view out)
     }
 }
 
+// frames (3 channels, or any count not a multiple of 4 up to 4): one thread per PIXEL -- the flow vector is read and the grid
+// coordinate computed once per pixel instead of once per channel, neighbouring lanes read neighbouring pixels.  Same
+// arithmetic per value (sample_bilinear per channel).
+__global__ void k_warp_px(int convention, vc_view img, vc_view flow, vc_view out)
+{
+    const long long total = (long long)out.n * out.h * out.w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % out.w);
+        long long t = i / out.w;
+        const int y = (int)(t % out.h);
+        const int n = (int)(t / out.h);
+        const float *f = flow.p + view_off(flow, n, y, x);
+        const float gx = grid_coord(convention, x, f[0], flow.w, img.w);
+        const float gy = grid_coord(convention, y, f[1], flow.h, img.h);
+        float *o = out.p + view_off(out, n, y, x);
+        for (int c = 0; c < out.c; ++c)
+            o[c] = sample_bilinear(img.p + (long long)n * img.sn + c, img.sh, img.sw, img.h, img.w, gx, gy,
+                                   convention != VC_WARP_W2, convention == VC_WARP_W3);
+    }
+}
+
 // 4 channels per thread: the sample position and the bilinear weights are computed once per 16 bytes (feature maps
 // of 64-128 channels in ICIP2024 made the scalar version recompute them per element).  Same arithmetic per value.
 __global__ void k_warp_v4(int convention, vc_view img, vc_view flow, vc_view out)
@@ -563,6 +584,8 @@ extern "C" int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, v
     const long long total = (long long)out.n * out.h * out.w * out.c;
     if (out.c % 4 == 0 && view_vec4(img) && view_vec4(out))
         hipLaunchKernelGGL(k_warp_v4, dim3(ew_grid(total / 4, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);
+    else if (out.c <= 4)
+        hipLaunchKernelGGL(k_warp_px, dim3(ew_grid(total / out.c, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);
     else
         hipLaunchKernelGGL(k_warp, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);
     VC_LAUNCH_CHECK();
@@ -600,7 +623,8 @@ extern "C" int vc_spynet_preprocess(vc_stream s, const float *src, vc_view dst)
     return VC_OK;
 }
 
-__global__ void k_spynet_level_input(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool VEC> __global__ void k_spynet_level_input(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
 {
     const long long total = (long long)feat.n * feat.h * feat.w;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -629,13 +653,22 @@ __global__ void k_spynet_level_input(vc_view first, vc_view second, vc_view fc, 
         const float *f1 = first.p + view_off(first, n, y, x);
         const float *s2 = second.p + (long long)n * second.sn;
         float *o = feat.p + view_off(feat, n, y, x);
-        o[0] = f1[0]; o[1] = f1[1]; o[2] = f1[2];
-        o[3] = sample_bilinear(s2 + 0, second.sh, second.sw, second.h, second.w, gx, gy, true);
-        o[4] = sample_bilinear(s2 + 1, second.sh, second.sw, second.h, second.w, gx, gy, true);
-        o[5] = sample_bilinear(s2 + 2, second.sh, second.sw, second.h, second.w, gx, gy, true);
-        o[6] = u; o[7] = v;
+        const float w0 = sample_bilinear(s2 + 0, second.sh, second.sw, second.h, second.w, gx, gy, true);
+        const float w1 = sample_bilinear(s2 + 1, second.sh, second.sw, second.h, second.w, gx, gy, true);
+        const float w2 = sample_bilinear(s2 + 2, second.sh, second.sw, second.h, second.w, gx, gy, true);
         float *q = up.p + view_off(up, n, y, x);
-        q[0] = u; q[1] = v;
+        if (VEC) {      // the 8 channels of a pixel as two 16-byte stores (eight 4-byte stores touched every line eight times)
+            const f32x4 lo = {f1[0], f1[1], f1[2], w0}, hi = {w1, w2, u, v};
+            *reinterpret_cast<f32x4 *>(o) = lo;
+            *reinterpret_cast<f32x4 *>(o + 4) = hi;
+            const f32x2 uv = {u, v};
+            *reinterpret_cast<f32x2 *>(q) = uv;
+        } else {
+            o[0] = f1[0]; o[1] = f1[1]; o[2] = f1[2];
+            o[3] = w0; o[4] = w1; o[5] = w2;
+            o[6] = u; o[7] = v;
+            q[0] = u; q[1] = v;
+        }
     }
 }
 
@@ -648,8 +681,13 @@ extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second,
     if (fc.p && (fc.c != 2 || (2 * fc.h != feat.h && 2 * fc.h + 1 != feat.h) || (2 * fc.w != feat.w && 2 * fc.w + 1 != feat.w)))
         return VC_EINVAL;
     const long long total = (long long)feat.n * feat.h * feat.w;
-    hipLaunchKernelGGL(k_spynet_level_input, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
-                       fc, feat, up);
+    const bool vec = view_vec4(feat) && reinterpret_cast<uintptr_t>(up.p) % 8 == 0 && up.sn % 2 == 0 && up.sh % 2 == 0 && up.sw % 2 == 0;
+    if (vec)
+        hipLaunchKernelGGL(k_spynet_level_input<true>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
+                           fc, feat, up);
+    else
+        hipLaunchKernelGGL(k_spynet_level_input<false>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
+                           fc, feat, up);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
