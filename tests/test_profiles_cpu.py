@@ -4,9 +4,9 @@ and held against the bench line printed by the SAME process:
 
   * no PyTorch operator kernel (`at::native`, elementwise / reduction / copy kernels of ATen) takes more than 0.1 % of the
     GPU time -- the data path is this repository's HIP kernels, not a torch fallback;
-  * the dominant kernel's launches (the 16-row 7x7 instance on 4 x 1088 x 1920, told apart from the same template's
-    smaller pyramid levels by their grid size) average, in the profiler's trace, what bench.py's HIP events measured:
-    `roofline.frac` is reproduced within 2 %.
+  * the dominant kernel's launch of bench.py's instrumented frame (the 16-row 7x7 instance on 4 x 1088 x 1920: the last
+    dispatch of its (template, grid) class in the trace) lasts, by the profiler's timestamps, what bench.py's HIP events
+    measured: `roofline.frac` is reproduced within 2 %.
 Files only: runs without a GPU.
 """
 import csv
@@ -54,10 +54,12 @@ def test_dominant_kernel_time_in_the_trace_reproduces_the_roofline_fraction():
     cout = int(roof["kernel"].split("->")[1].split()[0])
     grid = 68 * 60 * 4 * (cout // 32) * 256
     mine = [k for k in trace["kernels"] if "conv_mfma_kernel<7, 7, 1, 16, TileCfg<32, 16" in k["name"] and k["grid_threads"] == grid]
-    assert mine, [k["grid_threads"] for k in trace["kernels"] if "conv_mfma_kernel<7, 7" in k["name"]][:10]
-    n = sum(k["dispatches"] for k in mine)
-    avg_ms = sum(k["total_ns"] for k in mine) / n / 1e6
+    assert len(mine) == 1, [k["grid_threads"] for k in trace["kernels"] if "conv_mfma_kernel<7, 7" in k["name"]][:10]
+    # the same (template, grid) also serves other launches of the run (64 -> 32 on 8 images, 32 images of the half-size pyramid
+    # level ...): the instrumented frame is the LAST thing bench.py launches, so its launch is the class's last dispatch
+    avg_ms = mine[0]["last_ns"] / 1e6
+    n = 1
     frac = roof["algorithmic_flop_per_launch"] / (avg_ms * 1e-3) / 1e12 / roof["peak"]
-    print(f"dominant kernel: {n} dispatches in the trace, {avg_ms:.3f} ms average -> {frac:.4f} of peak; bench.py HIP events: "
+    print(f"dominant kernel: {n} dispatch (instrumented frame) in the trace, {avg_ms:.3f} ms -> {frac:.4f} of peak; bench.py HIP events: "
           f"{roof['avg_launch_ms']:.3f} ms -> {roof['frac']:.4f}")
     assert abs(frac - roof["frac"]) / roof["frac"] < 0.02

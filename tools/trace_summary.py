@@ -39,18 +39,22 @@ def main():
         name = r["Kernel_Name"]
         ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         key = (name, grid_of(r))
-        a = acc.setdefault(key, [0, 0, None, 0])
+        a = acc.setdefault(key, [0, 0, None, 0, -1, 0])
         a[0] += 1
         a[1] += ns
         a[2] = ns if a[2] is None else min(a[2], ns)
         a[3] = max(a[3], ns)
+        if int(r["Start_Timestamp"]) > a[4]:          # the class's LAST dispatch in time order
+            a[4], a[5] = int(r["Start_Timestamp"]), ns
         by_name[name] = by_name.get(name, 0) + ns
         total += ns
-    kernels = [{"name": k[0], "grid_threads": k[1], "dispatches": v[0], "total_ns": v[1], "avg_ns": v[1] / v[0], "min_ns": v[2], "max_ns": v[3]}
+    kernels = [{"name": k[0], "grid_threads": k[1], "dispatches": v[0], "total_ns": v[1], "avg_ns": v[1] / v[0], "min_ns": v[2], "max_ns": v[3],
+                "last_ns": v[5]}
                for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])]
     names = [{"name": n, "total_ns": t, "share": t / max(total, 1)} for n, t in sorted(by_name.items(), key=lambda kv: -kv[1])]
     with open(out, "w") as f:
-        json.dump({"what": "rocprofv3 --kernel-trace folded by (kernel name, grid size); durations = End - Start timestamps (ns)",
+        json.dump({"what": "rocprofv3 --kernel-trace folded by (kernel name, grid size); durations = End - Start timestamps (ns); last_ns = the "
+                           "class's last dispatch in time order (bench.py's instrumented frame runs last: its launches are the last of their class)",
                    "gpu_time_ns": total, "names": names, "kernels": kernels[:400]}, f, indent=1)
     print(f"{len(acc)} (kernel, grid) classes, {sum(v[0] for v in acc.values())} dispatches, {total / 1e9:.3f} s of GPU time -> {out}")
 
