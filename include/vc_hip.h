@@ -128,7 +128,7 @@ typedef struct {
      *   out = W_tail . act(conv3x3(in)) + b_tail (+ res)
      * -- `act` / `slope` belong to the 3x3 layer (none / ReLU / LeakyReLU with 0 <= slope <= 1), its result is rounded to half
      * exactly as the unfused layer would store it and never leaves the CU; the residual (fp32, or half with VC_CFG_RES_F16)
-     * is added behind the 1x1 layer.  cin = cout = 128, plain output, no channel gain.  tail_wpk / tail_bias come from
+     * is added behind the 1x1 layer.  cin = cout = 128 or 64, plain output, no channel gain.  tail_wpk / tail_bias come from
      * vc_conv_pack_tail_f16 (device copies).  Anything else returns VC_EINVAL.  NULL = no fused layer. */
     const void *tail_wpk;
     const float *tail_bias;
@@ -145,7 +145,7 @@ int vc_conv_pack_weights(const float *w_oihw, const float *bias, int cout, int c
                          int stride, int cfg, int pixelshuffle, float *wpk_out, float *bias_out);
 size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int kw, int stride); /* 0 = not eligible */
 /* 1x1 weights [cout][cin] (fp32, host) -> the fused-tail fragments of vc_conv_desc.tail_wpk (cout * cin halves) and its bias
- * (cout floats); cout = cin = 128. */
+ * (cout floats); cout = cin = 128 or 64. */
 int vc_conv_pack_tail_f16(const float *w, const float *bias, int cout, int cin, void *wpk_half_out, float *bias_out);
 int vc_conv_pack_weights_f16(const float *w_oihw, const float *bias, int cout, int cin, int kh, int kw,
                              int stride, int cfg, int pixelshuffle, void *wpk_half_out, float *bias_out);

@@ -83,6 +83,7 @@ def test_half_precision_activations_do_not_change_a_bit(dev):
     hip.set_conv_precision("fp16")
     hip.HALF_RESIDUAL = False          # (the half-precision identity path is NOT bit-neutral: its own test below)
     hip.HALF_DEFORM = False            # (nor are half-precision features under the deformable gather: test_icip2024_gpu.py)
+    hip.FUSE_TAIL = False              # (nor the fused bottleneck tail, which needs the half activation: test_ops_gpu.py)
     try:
         for name, (build, run) in builders.items():
             m = build()
@@ -111,6 +112,7 @@ def test_half_precision_activations_do_not_change_a_bit(dev):
         hip.HALF_ACTIVATIONS = True
         hip.HALF_RESIDUAL = True
         hip.HALF_DEFORM = True
+        hip.FUSE_TAIL = True
         hip.set_conv_precision("fp32")
 
 

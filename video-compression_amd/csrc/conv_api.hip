@@ -160,10 +160,10 @@ extern "C" int vc_conv_pack_weights_f16(const float *w, const float *bias, int c
 
 // Weights of the 1x1 layer fused behind a VC_CFG_DMA 3x3 layer (vc_conv_desc.tail_wpk): half-precision MFMA fragments
 // [n-tile o][k-step j][lane (m, h)][8] with the k order of the 3x3 layer's ACCUMULATOR layout: value i of lane (m, h) of fragment
-// (o, j) is w[32 o + m][16 j + 4 h + (i & 3) + 8 (i >> 2)].  cout = cin = 128.
+// (o, j) is w[32 o + m][16 j + 4 h + (i & 3) + 8 (i >> 2)].  cout = cin = 128 or 64.
 extern "C" int vc_conv_pack_tail_f16(const float *w, const float *bias, int cout, int cin, void *wpk_half_out, float *bias_out)
 {
-    if (!w || !wpk_half_out || !bias_out || cout != 128 || cin != 128) return VC_EINVAL;
+    if (!w || !wpk_half_out || !bias_out || cout != cin || (cout != 128 && cout != 64)) return VC_EINVAL;
     _Float16 *dst = static_cast<_Float16 *>(wpk_half_out);
     for (int o = 0; o < cout / 32; ++o)
         for (int j = 0; j < cin / 16; ++j)

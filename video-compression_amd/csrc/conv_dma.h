@@ -51,7 +51,7 @@ template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0, bool T
     static constexpr int TAIL_OFF = B_OFF + B_BYTES, TAIL_BYTES = TAIL_ ? NT_ * 2 * NT_ * 1024 + BN * 4 : 0;
     static constexpr int BIAS_OFF = TAIL_OFF + TAIL_BYTES;
     static constexpr int LDS_FIXED = BIAS_OFF;                // + 4 * Cout (padded) at launch
-    static_assert(!TAIL_ || (NT_ == 4 && NCHUNK_ == 4 && KH_ == 3), "the fused tail: 3x3 128 -> 128 followed by 1x1 128 -> 128");
+    static_assert(!TAIL_ || ((NT_ == 4 || NT_ == 2) && NCHUNK_ == NT_ && KH_ == 3), "the fused tail: 3x3 C -> C followed by 1x1 C -> C, C = 64 or 128");
     // stores per wave and tile the counted waits may rely on: the fast epilogue issues WM * WN * 2 (16 bytes per lane),
     // the general one twice as many (a wait that counts too few younger operations only waits a little longer)
     static constexpr int NST = WM * WN * 2;
@@ -342,7 +342,59 @@ __device__ __forceinline__ void dma_epilogue_tail(const ConvArgs &p, f32x16 (&ac
             for (int o = 0; o < NT; ++o)
                 acc2[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[j & 1][o]), bop, acc2[o], 0, 0, 0);
         });
-        // ---- exchange, residual, store: one N-tile at a time through this wave's scratch ----
+        // ---- exchange, residual, store ----
+        if (p.out_f16 && (p.out_sw & 7) == 0 && (p.out_sh & 7) == 0 && (p.out_sn & 7) == 0 &&
+            (!p.res || (((p.res_sw | p.res_sh | p.res_sn) & (p.res_f16 ? 7 : 3)) == 0))) {
+            // half-precision output: 16 pixels x 64 channels at a time through the scratch ([16][64 + 4] floats + a dump row the
+            // lanes of the other 16 pixels write to), read back as 8 consecutive channels per lane: one 16-byte residual load
+            // and one 16-byte store per lane and pass, every store instruction 8 whole 128-byte lines (a 32-channel tile alone
+            // would write every line in two halves, 8 bytes per lane: twice the vector-memory instructions)
+            constexpr int RF = 68;
+            const int rp8 = lane >> 3, ro = lane & 7;
+            static_for<0, NT / 2>([&](auto pc) {
+                constexpr int pr = decltype(pc)::value;
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    const int row = ((wpx >> 4) == part) ? (wpx & 15) * RF : 16 * RF;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = {acc2[2 * pr + hh][4 * g], acc2[2 * pr + hh][4 * g + 1], acc2[2 * pr + hh][4 * g + 2],
+                                             acc2[2 * pr + hh][4 * g + 3]};
+                            *reinterpret_cast<f32x4 *>(&scratch[row + 32 * hh + 8 * g + 4 * whalf]) = v;
+                        }
+                    const int co = pr * 64 + 8 * ro;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int pix = 8 * j + rp8;
+                        f32x4 v0 = *reinterpret_cast<const f32x4 *>(&scratch[pix * RF + 8 * ro]);
+                        f32x4 v1 = *reinterpret_cast<const f32x4 *>(&scratch[pix * RF + 8 * ro + 4]);
+                        const int ox = ox0 + 16 * part + pix;
+                        const bool ok = oy < p.Ho && ox < p.Wo;
+                        const long long o_off = (long long)img * p.out_sn + (long long)oy * p.out_sh + (long long)ox * p.out_sw + co;
+                        if (p.res) {
+                            const long long r_off = (long long)img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + co;
+                            if (p.res_f16) {
+                                f32x4 raw = {0.f, 0.f, 0.f, 0.f};
+                                if (ok) raw = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const _Float16 *>(p.res) + r_off);
+                                const f16x8 rh = __builtin_bit_cast(f16x8, raw);
+                                v0 += f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                                v1 += f32x4{(float)rh[4], (float)rh[5], (float)rh[6], (float)rh[7]};
+                            } else if (ok) {
+                                v0 += *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                                v1 += *reinterpret_cast<const f32x4 *>(p.res + r_off + 4);
+                            }
+                        }
+                        const f16x8 hv = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
+                                          (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+                        _Float16 *dst = ok ? reinterpret_cast<_Float16 *>(p.out) + o_off : reinterpret_cast<_Float16 *>(dump);
+                        *reinterpret_cast<f16x8 *>(dst) = hv;
+                    }
+                }
+            });
+        } else {
+        // (fp32 output -- the end of a chain -- or unaligned rows: one N-tile at a time, 4 channels per lane)
         static_for<0, NT>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
 #pragma unroll
@@ -380,6 +432,7 @@ __device__ __forceinline__ void dma_epilogue_tail(const ConvArgs &p, f32x16 (&ac
                 }
             }
         });
+        }
     });
 }
 

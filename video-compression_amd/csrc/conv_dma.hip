@@ -26,10 +26,11 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
     a.nblks = (a.Cout + 32 * nt - 1) / (32 * nt);
     if (a.nblks * 32 * nt != a.Cout && a.out_mode != VC_OUT_PLAIN) return VC_EINVAL;
     a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
-    if (a.tail_wpk) {      // bottleneck block: 3x3 128 -> 128 (activation) -> 1x1 128 -> 128 (+ residual) in one launch
-        if (k != 3 || a.Cin != 128 || a.Cout != 128 || !a.tail_bias || a.chscale || a.out_mode != VC_OUT_PLAIN || a.res_first ||
+    if (a.tail_wpk) {      // bottleneck block: 3x3 C -> C (activation) -> 1x1 C -> C (+ residual) in one launch, C = 128 or 64
+        if (k != 3 || a.Cin != a.Cout || (a.Cout != 128 && a.Cout != 64) || !a.tail_bias || a.chscale || a.out_mode != VC_OUT_PLAIN || a.res_first ||
             (a.act != VC_ACT_NONE && a.act != VC_ACT_RELU && !(a.act == VC_ACT_LRELU && a.slope >= 0.0f && a.slope <= 1.0f)))
             return VC_EINVAL;
+        if (a.Cout == 64) return launch_conv_dma<DmaCfg<3, 3, 2, 2, 3, 0, true>>(st, a);
         return launch_conv_dma<DmaCfg<3, 3, 4, 4, 4, 0, true>>(st, a);
     }
     if (a.res_f16) return VC_EINVAL;                 // (a half-precision residual is read by the fused-tail epilogue only)

@@ -370,7 +370,7 @@ class PackedConv:
                 self.wpk16 = torch.from_numpy(w16).to(device)
         self.tuned = {}
         self._tail = None
-        self._raw = (wnp, bnp) if (_PRECISION == "fp16" and kh == 1 and stride == 1 and cout == 128 and cin == 128 and not pixelshuffle) else None
+        self._raw = (wnp, bnp) if (_PRECISION == "fp16" and kh == 1 and stride == 1 and cout == cin and cin in (64, 128) and not pixelshuffle) else None
         self._device = device
         ck = L.vc_conv_chunk(self.cfg, kh, stride, cin)
         self.candidates = [c for c in range(self.cfg, 3) if L.vc_conv_chunk(c, kh, stride, cin) == ck] if self.cfg <= 2 else []
@@ -421,22 +421,24 @@ class PackedConv:
         return self.tuned[key]
 
     def tail_pack(self):
-        """This 1x1 128 -> 128 layer as the fused tail of a 3x3 layer (vc_conv_pack_tail_f16): (weights, bias) on the device."""
+        """This 1x1 C -> C layer (C = 64 or 128) as the fused tail of a 3x3 layer (vc_conv_pack_tail_f16): (weights, bias) on the device."""
         if self._tail is None:
             if self._raw is None:
-                raise VcError("only a 1x1 128 -> 128 layer of the fp16 path can be fused behind a 3x3 layer")
+                raise VcError("only a 1x1 64 -> 64 / 128 -> 128 layer of the fp16 path can be fused behind a 3x3 layer")
             wnp, bnp = self._raw
-            w16 = np.empty(128 * 128, dtype=np.float16)
-            b = np.empty(128, dtype=np.float32)
-            check(lib().vc_conv_pack_tail_f16(np.ascontiguousarray(wnp.reshape(128, 128)).ctypes.data, None if bnp is None else bnp.ctypes.data,
-                                              128, 128, w16.ctypes.data, b.ctypes.data), "vc_conv_pack_tail_f16")
+            c = self.cout
+            w16 = np.empty(c * c, dtype=np.float16)
+            b = np.empty(c, dtype=np.float32)
+            check(lib().vc_conv_pack_tail_f16(np.ascontiguousarray(wnp.reshape(c, c)).ctypes.data, None if bnp is None else bnp.ctypes.data,
+                                              c, c, w16.ctypes.data, b.ctypes.data), "vc_conv_pack_tail_f16")
             self._tail = (torch.from_numpy(w16).to(self._device), torch.from_numpy(b).to(self._device))
         return self._tail
 
     def can_fuse_tail(self, tail):
-        """True when ``tail`` (a 1x1 PackedConv) can ride in this 3x3 layer's epilogue: fp16 path, 128 -> 128 -> 128."""
-        return (FUSE_TAIL and self.wpk16 is not None and self.k == 3 and self.stride == 1 and not self.ps and self.cin == 128
-                and self.cout == 128 and CFG_DMA in self.candidates and tail._raw is not None and tail.wpk16 is not None)
+        """True when ``tail`` (a 1x1 PackedConv) can ride in this 3x3 layer's epilogue: fp16 path, C -> C -> C with C = 64 / 128."""
+        return (FUSE_TAIL and self.wpk16 is not None and self.k == 3 and self.stride == 1 and not self.ps and self.cin == self.cout
+                and self.cin in (64, 128) and CFG_DMA in self.candidates and tail._raw is not None and tail.cin == self.cout
+                and tail.wpk16 is not None)
 
     def out_shape(self, h, w):
         k, s = self.k, self.stride
@@ -477,7 +479,7 @@ class PackedConv:
         res_half = res is not None and res.dtype == "f16"
         if tail is not None and not (self.can_fuse_tail(tail) and use16 and half_in and epi == EPI_NONE and act < ACT_SIGMOID
                                      and chscale is None and not res_first):
-            raise VcError("fused tail: a half-precision activation through a 3x3 128 -> 128 layer of the fp16 path (PackedConv.can_fuse_tail)")
+            raise VcError("fused tail: a half-precision activation through a 3x3 C -> C layer of the fp16 path (PackedConv.can_fuse_tail)")
         if res_half and tail is None and not (use16 and self.half_res_ok and epi == EPI_NONE and act < ACT_SIGMOID):
             raise VcError("a half-precision residual needs the fp16 path's streaming 1x1 kernel (PackedConv.half_res_ok)")
         if res is not None:

@@ -146,9 +146,12 @@ def calibrated_state_dict(template, seed=1234, cal=None):
 #   entropy    hyper-synthesis biases: scale = spread of the active latents, mean = their centre; idle channels at the
 #              scale floor.
 # Every structured tensor carries seeded noise of relative size ``noise`` on top, so no convolution degenerates into a
-# single-term sum (the numerics of the 5x5 kernels stay under test).  ~30 dB on the synthetic clips.
+# single-term sum (the numerics of the 5x5 kernels stay under test).  ~31 dB on the synthetic clips.  ``gain`` = quantiser
+# steps per unit intensity: a latent that rounds the other way on another platform (fp32 summation order) moves ONE low-pass
+# pixel by 1 / gain, and the flip probability grows with gain while the squared error of a flip falls with its square -- at
+# 64 the worst I-frame of the test() loop fixtures stays well inside 1e-3 dB (at 16: 1.05e-3 dB measured on MI355X).
 # ------------------------------------------------------------------------------------------------------------------
-def calibrated_intra_state_dict(template, seed=1234, gain=16.0, noise=0.004):
+def calibrated_intra_state_dict(template, seed=1234, gain=64.0, noise=0.004):
     sd = seeded_state_dict(template, seed=seed, conv_gain=noise)
     n_mid, m_lat = sd["g_a.0.weight"].shape[0], sd["g_a.6.weight"].shape[0]
     if n_mid < 48 or m_lat < 192:
@@ -167,6 +170,7 @@ def calibrated_intra_state_dict(template, seed=1234, gain=16.0, noise=0.004):
                                       ("g_a.6.weight", "g_s.0.weight"))):
         cin = 3 * 4 ** stage
         g = gain if stage == 2 else 1.0
+        sd[wa], sd[ws] = sd[wa] * g, sd[ws] / g            # (the seeded perturbation keeps its size RELATIVE to the structure)
         for c in range(cin):
             for p in range(2):
                 for q in range(2):
