@@ -267,8 +267,8 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
         if (!conv_pws_eligible(a, k, st, f16)) return VC_EINVAL;
         return conv_dispatch_pws(stream, a, f16);
     }
-    if (cfg == VC_CFG_DMA)                  // fp16-path LDS-DMA pipeline: only ever chosen explicitly (autotuner)
-        return f16 ? conv_dispatch_dma(stream, a, k, st) : VC_EINVAL;
+    if (cfg == VC_CFG_DMA)                  // LDS-DMA pipeline (fp16 path; fp32: the two big 7x7 layers): only ever chosen explicitly (autotuner)
+        return conv_dispatch_dma(stream, a, k, st, f16);
     switch (k) {
     case 1: return f16 ? conv_dispatch_k1_f16(stream, a, st, cfg, ck) : conv_dispatch_k1_f32(stream, a, st, cfg, ck);
     case 3: return f16 ? conv_dispatch_k3_f16(stream, a, st, cfg, ck) : conv_dispatch_k3_f32(stream, a, st, cfg, ck);

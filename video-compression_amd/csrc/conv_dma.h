@@ -32,9 +32,15 @@ static __device__ __attribute__((aligned(1024))) unsigned char g_vc_dma_dump[102
 // TAIL_: the bottleneck-block instance (ICIP2024/src/model/elic.py:69-83: ... -> conv3x3 -> ReLU -> conv1x1, + identity): the
 // workgroup also holds the trailing 1x1 layer's weights in LDS and applies it to its accumulators before anything is stored
 // (dma_epilogue_tail).  Every wave then owns ALL output channels of its rows (WAVES_N = 1): the 1x1 contracts over them.
-template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0, bool TAIL_ = false> struct DmaCfg {
+// F32_: the EXACT fp32 path on the same pipeline (fp32 tensors, v_mfma_f32_32x32x2_f32): a chunk is 16 channels -- the same
+// 64 bytes of a pixel, the same 1 KiB weight fragments ([lane][4 floats] = four k-sub-steps), the same addressing -- but every
+// fragment pair feeds four 64-cycle MFMAs instead of one 32-cycle one: the operand streams that bound the fp16 instances
+// disappear behind 8x more matrix time.  Accumulation order (16-channel chunk, tap, k-step, sub-step) = the classic fp32
+// 7x7 / 5x5 instances' (CK = 16): bit-identical to them.
+template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0, bool TAIL_ = false, bool F32_ = false> struct DmaCfg {
     static constexpr int KO = KO_;
-    static constexpr bool TAIL = TAIL_;
+    static constexpr bool TAIL = TAIL_, F32 = F32_;
+    static constexpr int ESZ = F32_ ? 4 : 2;                   // bytes per input element; a chunk = 64 / ESZ channels
     static constexpr int KH = KH_, KW = KW_, TAPS = KH_ * KW_, NCHUNK = NCHUNK_, NT = NT_, RING = RING_;
     static constexpr int MT = 32, TH = 16, XT = 1, TW = 32;
     static constexpr int WAVES = 8, WAVES_N = (NT_ == 4 && !TAIL_) ? 2 : 1, WAVES_M = WAVES / WAVES_N;
@@ -42,7 +48,9 @@ template <int KH_, int KW_, int NCHUNK_, int NT_, int RING_, int KO_ = 0, bool T
     static constexpr int BN = NT_ * 32;
     // a phase = 8 weight fragments (8 KiB, one DMA instruction per wave) = UPP (chunk, tap) units of 2 k-steps
     static constexpr int UPP = 4 / NT_;
-    static constexpr int UT = NCHUNK_ * TAPS, PT = (UT + UPP - 1) / UPP;
+    // (phases per tile: rounded up to a multiple of the ring so that a phase's slot is a compile-time constant; the units
+    //  past UT read zero fragments and are skipped by the contraction)
+    static constexpr int UT = NCHUNK_ * TAPS, PT = ((UT + UPP - 1) / UPP + RING_ - 1) / RING_ * RING_;
     static constexpr int ROWS_IN = TH + KH_ - 1, COLS = TW + KW_ - 1, PIX = ROWS_IN * COLS;
     static constexpr int NA = (PIX * 4 + 511) / 512;          // DMA instructions per wave and chunk image (512 lanes x 16 B)
     static constexpr int A_BYTES = NA * 8192;
@@ -484,7 +492,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
 
     const unsigned char *const in_b = reinterpret_cast<const unsigned char *>(p.in);
     const unsigned char *const wpk = reinterpret_cast<const unsigned char *>(p.wpk);
-    const int kst = p.cin_pad >> 4;                  // packed k-steps (16 channels) per tap
+    const int kst = p.cin_pad >> (C::F32 ? 3 : 4);   // packed k-steps (16 halves / 8 floats) per tap
     const unsigned char *const zero_lane = g_vc_dma_zero + 16 * lane;
 
     // ---- issue helpers ----
@@ -499,11 +507,11 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         const int q = s >> 2;
         const int row = q / C::COLS, col = q - row * C::COLS;
         const int g = (s & 3) ^ ((col >> 2) & 3);
-        a_off[k] = 2 * (row * (int)p.in_sh + col * (int)p.in_sw + g * 8);
+        a_off[k] = C::ESZ * (row * (int)p.in_sh + col * (int)p.in_sw + g * (16 / C::ESZ));
         a_rc[k] = q < C::PIX ? (row | (col << 8)) : 0x7f7f7f;       // (a row / column no image reaches)
     }
     auto tile_base = [&](const DmaTile &t) {           // address of the footprint's first pixel (may lie outside the tensor)
-        return in_b + 2 * ((long long)t.img * p.in_sn + (long long)(t.oy0 - C::KH / 2) * p.in_sh + (long long)(t.ox0 - KW / 2) * p.in_sw);
+        return in_b + C::ESZ * ((long long)t.img * p.in_sn + (long long)(t.oy0 - C::KH / 2) * p.in_sh + (long long)(t.ox0 - KW / 2) * p.in_sw);
     };
     auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {
         // (the two per-lane constants pass through an empty asm: the address is then computed HERE, not hoisted to the top
@@ -643,9 +651,16 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
 #pragma unroll
                         for (int t = 0; t < WM; ++t)
 #pragma unroll
-                            for (int n = 0; n < WN; ++n)
-                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[uu][ks][n]),
-                                                                                   __builtin_bit_cast(f16x8, af[uu][ks][t]), acc[t][n], 0, 0, 0);
+                            for (int n = 0; n < WN; ++n) {
+                                if constexpr (C::F32) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[uu][ks][n][e], af[uu][ks][t][e], acc[t][n], 0, 0, 0);
+                                } else {
+                                    acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[uu][ks][n]),
+                                                                                       __builtin_bit_cast(f16x8, af[uu][ks][t]), acc[t][n], 0, 0, 0);
+                                }
+                            }
                 }
             });
             if constexpr (!(C::KO & 128)) __builtin_amdgcn_s_setprio(0);

@@ -10,8 +10,27 @@ static bool dma_views_ok(const ConvArgs &a)
     return a.in_f16 && a.vec4 && a.vec_out && a.epi == VC_EPI_NONE && a.in_xform == VC_IN_NONE;
 }
 
-int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride)
+// the exact fp32 instances (DmaCfg::F32): SPyNet's two big 7x7 layers (LHBDC/model/flow.py:52-62), fp32 tensors either side
+static int conv_dispatch_dma_f32(hipStream_t st, ConvArgs a, int k, int stride)
 {
+    if (stride != 1 || k != 7 || a.in_f16 || a.out_f16 || !a.vec4 || !a.vec_out || a.epi != VC_EPI_NONE || a.in_xform != VC_IN_NONE ||
+        a.tail_wpk || a.res_f16 || a.out_mode != VC_OUT_PLAIN)
+        return VC_EINVAL;
+    if ((long long)(k + 15) * a.in_sh * 4 + 48ll * a.in_sw * 4 + 256 >= (1ll << 31)) return VC_EINVAL;
+    const int nchunk = a.Cin / 16, nt = a.Cout / 32;
+    if (a.Cin != nchunk * 16 || a.Cout != nt * 32) return VC_EINVAL;
+    a.tiles_x = (a.Wo + 31) / 32;
+    a.tiles_y = (a.Ho + 15) / 16;
+    a.nblks = 1;
+    a.total_blocks = a.tiles_x * a.tiles_y * a.N;
+    if (nchunk == 4 && nt == 1) return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 0, false, true>>(st, a);     // 64 -> 32
+    if (nchunk == 2 && nt == 2) return launch_conv_dma<DmaCfg<7, 7, 2, 2, 5, 0, false, true>>(st, a);     // 32 -> 64
+    return VC_EINVAL;
+}
+
+int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride, bool f16)
+{
+    if (!f16) return conv_dispatch_dma_f32(st, a, k, stride);
     if (stride != 1 || !dma_views_ok(a) || (a.Cin & 31)) return VC_EINVAL;
     const int nchunk = a.Cin / 32;
     // 96 output channels and more: blocks of 128, the last one partly padding (the packing of VC_CFG_N128 / N128B pads the

@@ -859,7 +859,7 @@ bool conv_pws_eligible(const ConvArgs &a, int k, int stride, bool f16);
 int conv_dispatch_pws(hipStream_t st, const ConvArgs &a, bool f16);
 int conv_dispatch_pw(hipStream_t st, const ConvArgs &a, bool f16);
 // fp16-path LDS-DMA pipeline (conv_dma.hip): same packed weights again; sets the tile geometry of `a` itself
-int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride);
+int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride, bool f16);
 VC_DECLARE_DISPATCH(k1)
 VC_DECLARE_DISPATCH(k3)
 VC_DECLARE_DISPATCH(k5)

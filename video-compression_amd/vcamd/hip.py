@@ -388,6 +388,11 @@ class PackedConv:
         if (self.candidates and kh in (3, 7) and stride == 1 and cin % 32 == 0 and dma_cout
                 and os.environ.get("VC_DMA_KERNELS", "1") != "0"):
             self.candidates.append(CFG_DMA)
+        # the exact fp32 instances of the same pipeline (csrc/conv_dma.h, DmaCfg::F32): SPyNet's two big 7x7 layers
+        self.dma_f32 = (bool(self.candidates) and kh == 7 and stride == 1 and (cin, cout) in ((64, 32), (32, 64)) and not self.ps
+                        and os.environ.get("VC_DMA_KERNELS", "1") != "0" and os.environ.get("VC_DMA_F32", "1") != "0")
+        if self.dma_f32 and CFG_DMA not in self.candidates:
+            self.candidates.append(CFG_DMA)
         # every alternative must read THIS packing: same channel chunk (the zero padding of cin depends on it)
         self.candidates = [c for c in self.candidates if L.vc_conv_chunk(c, kh, stride, cin) == ck]
 
@@ -399,8 +404,8 @@ class PackedConv:
         cands = self.candidates
         if flags & CFG_F16 and 5 in cands:
             cands = [c for c in cands if c != 0]     # the 4x1 128-channel fp16 instance spills registers
-        if not (flags & CFG_F16 and flags & CFG_IN_F16):
-            cands = [c for c in cands if c != CFG_DMA]   # the LDS-DMA pipeline copies half-precision pixels as they are
+        if not (flags & CFG_F16 and flags & CFG_IN_F16) and not (self.dma_f32 and not flags & CFG_F16):
+            cands = [c for c in cands if c != CFG_DMA]   # the LDS-DMA pipeline copies pixels as they are: half tensors, or fp32 on its fp32 instances
         if not AUTOTUNE or len(cands) < 2 or torch.cuda.is_current_stream_capturing():
             return (cands[0] if cands else self.cfg) | flags
         best, best_ms = self.cfg, float("inf")
