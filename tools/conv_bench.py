@@ -55,6 +55,13 @@ def main():
             res.buf.normal_()
         for _ in range(2):
             pc(x, out=out, act=hip.ACT_LRELU, res=res)
+        stamps = hasattr(hip.lib(), "vc_debug_dma_stamps") and os.environ.get("VC_DMA_VARIANT") == "64"
+        if stamps:          # diagnostic library (make dma_diag): shader-clock totals per segment of the LDS-DMA kernel
+            import ctypes
+            import numpy as np
+            buf = np.zeros(8, dtype=np.uint64)
+            hip.lib().vc_debug_dma_stamps.argtypes = [ctypes.c_void_p]
+            hip.lib().vc_debug_dma_stamps(buf.ctypes.data)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
@@ -62,6 +69,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
+        if stamps:
+            hip.lib().vc_debug_dma_stamps(buf.ctypes.data)
+            tot = float(buf[7]) or 1.0
+            names = ["DMA issue", "fragment reads", "vmcnt wait", "barrier after R", "MFMA issue", "barrier after M", "epilogue", "wave lifetime"]
+            print("   stamps: " + "; ".join(f"{nm} {100.0 * float(v) / tot:.1f} %" for nm, v in zip(names, buf)))
         flop = 2.0 * n * ho * wo * cout * cin * k * k
         print(f"conv k{k} s{s} {cin:4d}->{cout:4d} @{n}x{h}x{w} cfg{[v for v in pc.tuned.values()][0] & 0xff if pc.tuned else pc.cfg} {args.precision}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s "
               f"({flop / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)")

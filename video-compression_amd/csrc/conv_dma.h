@@ -645,22 +645,27 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
                             VC_DMA_KEEP(af[uu][ks][t]);
                             VC_DMA_KEEP(bf[uu][ks][t % WN]);
                         }
+                } else if constexpr (ph * UPP + uu < UT && C::F32) {
+                    // (sub-steps outermost: consecutive MFMAs go to different accumulators; per accumulator the order
+                    //  k-step, sub-step is the classic kernel's)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int t = 0; t < WM; ++t)
+#pragma unroll
+                                for (int n = 0; n < WN; ++n)
+                                    acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[uu][ks][n][e], af[uu][ks][t][e], acc[t][n], 0, 0, 0);
                 } else if constexpr (ph * UPP + uu < UT) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                         for (int t = 0; t < WM; ++t)
 #pragma unroll
-                            for (int n = 0; n < WN; ++n) {
-                                if constexpr (C::F32) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[uu][ks][n][e], af[uu][ks][t][e], acc[t][n], 0, 0, 0);
-                                } else {
-                                    acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[uu][ks][n]),
-                                                                                       __builtin_bit_cast(f16x8, af[uu][ks][t]), acc[t][n], 0, 0, 0);
-                                }
-                            }
+                            for (int n = 0; n < WN; ++n)
+                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[uu][ks][n]),
+                                                                                   __builtin_bit_cast(f16x8, af[uu][ks][t]), acc[t][n], 0, 0, 0);
                 }
             });
             if constexpr (!(C::KO & 128)) __builtin_amdgcn_s_setprio(0);

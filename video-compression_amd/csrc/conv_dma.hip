@@ -23,6 +23,25 @@ static int conv_dispatch_dma_f32(hipStream_t st, ConvArgs a, int k, int stride)
     a.tiles_y = (a.Ho + 15) / 16;
     a.nblks = 1;
     a.total_blocks = a.tiles_x * a.tiles_y * a.N;
+#ifdef VC_DMA_DIAG      // diagnostic build only (make dma_diag): knock-out variants of the fp32 64 -> 32 instance
+    if (nchunk == 4 && nt == 1) {
+        const char *e = getenv("VC_DMA_VARIANT");
+        switch (e ? atoi(e) : 0) {
+        case 1: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 1, false, true>>(st, a);
+        case 8: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 8, false, true>>(st, a);
+        case 16: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 16, false, true>>(st, a);
+        case 32: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 32, false, true>>(st, a);
+        case 64: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 64, false, true>>(st, a);
+        case 128: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 128, false, true>>(st, a);
+        case 25: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 25, false, true>>(st, a);      // MFMAs + barriers only
+        case 1024: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 1024, false, true>>(st, a);  // no A DMA
+        case 2048: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 2048, false, true>>(st, a);  // no B DMA
+        case 256: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 256, false, true>>(st, a);    // DMA issue before the fragment reads
+        case 1025: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 1025, false, true>>(st, a);  // no A DMA, no epilogue
+        case 17: return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 17, false, true>>(st, a);      // no DMA, no epilogue
+        }
+    }
+#endif
     if (nchunk == 4 && nt == 1) return launch_conv_dma<DmaCfg<7, 7, 4, 1, 5, 0, false, true>>(st, a);     // 64 -> 32
     if (nchunk == 2 && nt == 2) return launch_conv_dma<DmaCfg<7, 7, 2, 2, 5, 0, false, true>>(st, a);     // 32 -> 64
     return VC_EINVAL;
