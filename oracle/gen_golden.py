@@ -378,6 +378,56 @@ def gen_lhbdc_fullsize(outdir, frames, seed):
     print(f"  wrote lhbdc_fullsize_1080p.npz ({os.path.getsize(os.path.join(outdir, 'lhbdc_fullsize_1080p.npz')) / 1e6:.1f} MB)")
 
 
+def gen_flex_fullsize(outdir, frames, seed):
+    """BASELINE configs[2] at its real size: the reference's BidirFlowRef.forward (Flex-Rate.../b_model/b_model.py:49-96: depth-5
+    U-Net flow predictor, W2 warps, 19-channel gained flow codec, depth-4 mask U-Net, gained residual codec) on the FULL bundled
+    frames (1088x1920) at two operating points -- a table point (n = 1, l = 1) and an interpolated one (n = 2, l = 0.66) --
+    calibrated checkpoint.  Oracle == reference; the fixture keeps the entropy models' integers and sub-sampled floats."""
+    ref_b = import_reference_flex()
+    torch.manual_seed(0)
+    ref = ref_b.BidirFlowRef(n=4).eval()
+    sd = calibrated_state_dict(ref.state_dict(), seed=seed)
+    ref.load_state_dict(sd)
+    ora = oflex.FlexModel(n=4).eval()
+    ora.load_state_dict(sd)
+    table = cai.entropy_models.get_scale_table()
+    store = dict(seed=np.int64(seed), checkpoint="calibrated",
+                 frames_sha256=np.array([hashlib.sha256(frames[k].tobytes()).hexdigest() for k in ("ref_1", "current", "ref_2")]))
+    sub = (slice(None), slice(None), slice(0, None, 8), slice(0, None, 8))
+    h, w = frames["current"].shape[:2]
+    with torch.no_grad():
+        xb, xc, xa = (olhbdc.pad64(to_tensor(frames[k])) for k in ("ref_1", "current", "ref_2"))
+        print(f"  Flex full-size fixture: frames {tuple(xc.shape)}")
+        for tag, (n, l) in {"n1": (1, 1.0), "n2l066": (2, 0.66)}.items():
+            with CallLog(ref.Mask) as mask_r, CodecTrace(ref.flow_compressor) as t_fl, CodecTrace(ref.residual_compressor) as t_res:
+                rr = ref(xb, xc, xa, n=[n], l=l, train=False)
+                lat = {"flow": t_fl.latents(table), "res": t_res.latents(table)}
+            ro = ora(xb, xc, xa, n=[n], l=l, train=False)
+            check(f"BidirFlowRef x_hat 1088x1920 {tag}", ro["x_hat"], rr["x_hat"])
+            check(f"BidirFlowRef size {tag}", ro["size"], rr["size"])
+            check(f"BidirFlowRef rate {tag}", ro["rate"], rr["rate"])
+            u8 = np.round(np.clip(rr["x_hat"][0].numpy(), 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)[:h, :w]
+            mse = np.mean((u8.astype(np.float64) - frames["current"].astype(np.float64)) ** 2)
+            store[f"{tag}_cfg"] = np.array([n, l], dtype=np.float64)
+            store[f"{tag}_x_hat_sub8"] = rr["x_hat"][sub].numpy()
+            store[f"{tag}_mask_sub8"] = torch.sigmoid(mask_r.outputs[-1])[sub].numpy()
+            store[f"{tag}_flow_input_sub8"] = lat["flow"]["x"][sub].numpy()
+            store[f"{tag}_res_input_sub8"] = lat["res"]["x"][sub].numpy()
+            store[f"{tag}_size"] = np.float64(rr["size"].item())
+            store[f"{tag}_psnr_u8"] = np.float64(10.0 * np.log10(255.0 ** 2 / mse))
+            for c in ("flow", "res"):          # forward() quantises the GAINED y (b_model/layers.py:140-147)
+                for k, dt in (("y_sym", np.int16), ("z_sym", np.int16)):
+                    v = lat[c][k].numpy()
+                    if np.abs(v).max() > np.iinfo(dt).max:
+                        raise SystemExit(f"{tag} {c}_{k} does not fit {dt}")
+                    store[f"{tag}_{c}_{k}"] = v.astype(dt)
+                store[f"{tag}_{c}_y_fragile"] = fragile_mask(lat[c]["y"] - lat[c]["means"], 2e-3)
+            print(f"    {tag}: {store[f'{tag}_psnr_u8']:.3f} dB (uint8), {rr['size'].item() / (h * w):.4f} bpp; "
+                  f"{100 * float((lat['res']['y_sym'] != 0).float().mean()):.1f} % of the residual symbols non-zero")
+    np.savez_compressed(os.path.join(outdir, "flex_fullsize_1080p.npz"), **store)
+    print(f"  wrote flex_fullsize_1080p.npz ({os.path.getsize(os.path.join(outdir, 'flex_fullsize_1080p.npz')) / 1e6:.1f} MB)")
+
+
 def gen_flex(outdir, frames, seed):
     ref_b = import_reference_flex()
     torch.manual_seed(0)
@@ -791,7 +841,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--only", choices=["lhbdc", "fullsize", "flex", "harness", "icip2024", "testloop", "flextestloop"], default=None)
+    ap.add_argument("--only", choices=["lhbdc", "fullsize", "flexfullsize", "flex", "harness", "icip2024", "testloop", "flextestloop"], default=None)
     ap.add_argument("--loop-checkpoint", choices=["seeded", "calibrated"], default="calibrated",
                     help="checkpoint of the B-frame model in the test() loop fixtures (calibrated: trained-like statistics)")
     args = ap.parse_args()
@@ -807,6 +857,8 @@ def main():
         gen_lhbdc(args.out, frames, args.seed)
     if args.only in (None, "fullsize"):
         gen_lhbdc_fullsize(args.out, frames, args.seed)
+    if args.only in (None, "flexfullsize"):
+        gen_flex_fullsize(args.out, frames, args.seed)
     if args.only in (None, "flex"):
         gen_flex(args.out, frames, args.seed)
     if args.only in (None, "icip2024"):

@@ -226,3 +226,47 @@ def test_decode_B_reads_the_reference_container_at_1088x1920(dev, fx, bundled, m
     assert not any(n.values()), n        # every symbol the reference coded comes back (same strings, same tables, same indexes)
     assert np.abs(diff).max() <= 1 and moved < 2e-3 and d_sub < 1e-4
     assert d_psnr < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Flex-Rate (BASELINE configs[2]) against the reference's own BidirFlowRef.forward at 1088x1920
+# (fixture flex_fullsize_1080p.npz, oracle/gen_golden.py --only flexfullsize)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["n1", "n2l066"])
+def test_flex_forward_meets_the_reference_at_1088x1920(dev, bundled, frames, tag):
+    """Flex-Rate.../b_model/b_model.py:49-96 on the full bundled frames, calibrated checkpoint, a table operating point and an
+    interpolated one: the gained codecs' integers against the reference's (<= 2 boundary-case symbols per tensor), the 19-channel
+    flow-codec input (U-Net flow predictor + W2 warps), mask and residual input on the 1/8 grid, PSNR / size at 1e-3."""
+    from vcamd import flex
+    from vcamd.seeding import calibrated_state_dict
+    fx = load_fixture("flex_fullsize_1080p.npz")
+    assert str(fx["checkpoint"]) == "calibrated"
+    prod = flex.BidirFlowRef(n=4)
+    prod.load_state_dict(calibrated_state_dict(prod.state_dict(), seed=int(fx["seed"])))
+    prod = prod.to(dev).eval()
+    xb, xc, xa = frames
+    n_, l_ = int(fx[f"{tag}_cfg"][0]), float(fx[f"{tag}_cfg"][1])
+    trace = {}
+    with torch.no_grad():
+        x_hat, tot = prod.forward_device(xb, xc, xa, n=[n_], l=l_, trace=trace)
+        bits = float(tot.sum())
+    stage = {
+        "flow_input": float((nchw(trace["buf"])[:, :, ::8, ::8] - torch.from_numpy(fx[f"{tag}_flow_input_sub8"])).abs().max()),
+        "mask": float((nchw(trace["mask"])[:, :, ::8, ::8] - torch.from_numpy(fx[f"{tag}_mask_sub8"])).abs().max()),
+        "res_input": float((nchw(trace["resid"])[:, :, ::8, ::8] - torch.from_numpy(fx[f"{tag}_res_input_sub8"])).abs().max()),
+    }
+    n = {"flow_z": flips("flow z", trace["flow"]["z_sym"], fx[f"{tag}_flow_z_sym"]), "res_z": flips("res z", trace["res"]["z_sym"], fx[f"{tag}_res_z_sym"])}
+    n["flow_y"] = flips("flow y", trace["flow"]["y_sym"], fx[f"{tag}_flow_y_sym"], fx[f"{tag}_flow_y_fragile"] if not n["flow_z"] else None)
+    upstream = n["flow_z"] or n["flow_y"]
+    n["res_y"] = flips("res y", trace["res"]["y_sym"], fx[f"{tag}_res_y_sym"], fx[f"{tag}_res_y_fragile"] if not (upstream or n["res_z"]) else None)
+    d_psnr = abs(psnr_u8(to_u8(x_hat), bundled["current"]) - float(fx[f"{tag}_psnr_u8"]))
+    d_bits = abs(bits - float(fx[f"{tag}_size"])) / float(fx[f"{tag}_size"])
+    d_hat = float((x_hat.cpu()[:, :, ::8, ::8] - torch.from_numpy(fx[f"{tag}_x_hat_sub8"])).abs().max())
+    print(f"Flex-Rate forward (n = {n_}, l = {l_}) vs THE REFERENCE at 1088x1920 ({float(fx[f'{tag}_psnr_u8']):.3f} dB, "
+          f"{float(fx[f'{tag}_size']) / (H * W):.4f} bpp): stage max|d| {stage}; symbols differing {n}; x_hat max|d| (1/8 grid) {d_hat:.2e}; "
+          f"dPSNR(uint8) {d_psnr:.2e} dB; bits rel {d_bits:.2e}")
+    assert stage["flow_input"] < 2e-4, stage
+    assert all(v <= MAX_FLIPS for v in n.values()), n
+    if not upstream:
+        assert stage["mask"] < 2e-4 and stage["res_input"] < 2e-4, stage
+    assert d_psnr < 1e-3 and d_bits < 1e-3
