@@ -888,18 +888,23 @@ def test_fused_bottleneck_tail_equals_the_two_layers(dev, c, n, h, w):
         c2(x32, act=hip.ACT_RELU, tail=c3)
 
 
-@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 32, 2, 50, 70), (32, 64, 1, 34, 60), (64, 32, 4, 160, 288), (32, 64, 3, 17, 33)])
-def test_lds_dma_fp32_kernel_is_bit_identical(dev, cin, cout, n, h, w):
+@pytest.mark.parametrize("cin,cout,k,n,h,w", [(64, 32, 7, 2, 50, 70), (32, 64, 7, 1, 34, 60), (64, 32, 7, 4, 160, 288), (32, 64, 7, 3, 17, 33),
+                                              (128, 128, 3, 1, 40, 72), (128, 128, 3, 3, 17, 33), (128, 512, 3, 1, 34, 60), (64, 64, 3, 2, 33, 50),
+                                              (64, 128, 3, 1, 50, 70), (128, 64, 3, 1, 20, 36), (256, 128, 3, 1, 16, 40), (128, 128, 3, 2, 160, 288)])
+def test_lds_dma_fp32_kernel_is_bit_identical(dev, cin, cout, k, n, h, w):
     """The EXACT fp32 instances of the LDS-DMA pipeline (csrc/conv_dma.h, DmaCfg::F32: fp32 tensors, v_mfma_f32_32x32x2_f32,
-    16-channel chunks): SPyNet's two big 7x7 layers (LHBDC/model/flow.py:52-62).  Same accumulation order as the classic fp32
+    16-channel chunks): SPyNet's two big 7x7 layers (LHBDC/model/flow.py:52-62) and the 3x3 stride-1 layers of the residual blocks
+    and U-Nets (pixel shuffle included).  Same accumulation order as the classic fp32
     instances (16-channel chunk, tap, k-step, sub-step) and the same epilogue arithmetic: every result bit for bit equal --
     ReLU / plain / residual / sigmoid epilogues, ragged sizes, several images, more tiles than workgroups."""
     from vcamd import hip
     x = _rand((n, cin, h, w), 81)
-    pc = hip.PackedConv(_rand((cout, cin, 7, 7), 82, 1.0 / np.sqrt(cin * 49)), _rand((cout,), 83, 0.1), device=dev)
+    ps = cout == 512
+    pc = hip.PackedConv(_rand((cout, cin, k, k), 82, 1.0 / np.sqrt(cin * k * k)), _rand((cout,), 83, 0.1), pixelshuffle=ps, device=dev)
     assert pc.dma_f32 and hip.CFG_DMA in pc.candidates and pc.wpk16 is None
     xt = hip.nchw_to_nhwc(x.to(dev))
-    res = hip.nchw_to_nhwc(_rand((n, cout, h, w), 84).to(dev))
+    ho, wo, co = pc.out_shape(h, w)
+    res = hip.nchw_to_nhwc(_rand((n, co, ho, wo), 84).to(dev))
     outs = {}
     for cfg in [c for c in pc.candidates]:
         pc.tuned = {(n, h, w, 0): cfg | hip.CFG_EXACT, (n, h, w, 0, hip.ACT_SIGMOID, hip.EPI_NONE): cfg | hip.CFG_EXACT}
@@ -911,12 +916,10 @@ def test_lds_dma_fp32_kernel_is_bit_identical(dev, cin, cout, n, h, w):
         for a, c in zip(ref, outs[hip.CFG_DMA]):
             assert torch.equal(a, c), (cfg, (a - c).abs().max().item())
     # and against the CPU's fp32 convolution (summation order differs: tolerance)
-    exact = torch.relu(torch.nn.functional.conv2d(x, pc_weight(82, cout, cin), _rand((cout,), 83, 0.1), padding=3))
-    _close(hip.nhwc_to_nchw(_as_t(outs[hip.CFG_DMA][0], n, h, w, cout, dev)).cpu(), exact, 2e-5, "fp32 LDS-DMA conv vs F.conv2d")
-
-
-def pc_weight(seed, cout, cin):
-    return _rand((cout, cin, 7, 7), seed, 1.0 / np.sqrt(cin * 49))
+    exact = torch.relu(torch.nn.functional.conv2d(x, _rand((cout, cin, k, k), 82, 1.0 / np.sqrt(cin * k * k)), _rand((cout,), 83, 0.1), padding=k // 2))
+    if ps:
+        exact = torch.nn.functional.pixel_shuffle(exact, 2)
+    _close(hip.nhwc_to_nchw(_as_t(outs[hip.CFG_DMA][0], n, ho, wo, co, dev)).cpu(), exact, 2e-5, "fp32 LDS-DMA conv vs F.conv2d")
 
 
 def _as_t(buf, n, h, w, c, dev):

@@ -10,19 +10,31 @@ static bool dma_views_ok(const ConvArgs &a)
     return a.in_f16 && a.vec4 && a.vec_out && a.epi == VC_EPI_NONE && a.in_xform == VC_IN_NONE;
 }
 
-// the exact fp32 instances (DmaCfg::F32): SPyNet's two big 7x7 layers (LHBDC/model/flow.py:52-62), fp32 tensors either side
+// the exact fp32 instances (DmaCfg::F32), fp32 tensors either side: SPyNet's two big 7x7 layers (LHBDC/model/flow.py:52-62) and
+// the 3x3 stride-1 layers of the residual blocks / U-Nets (LHBDC/model/layers.py:123-166, Flex-Rate.../b_model/unet.py:9-91)
 static int conv_dispatch_dma_f32(hipStream_t st, ConvArgs a, int k, int stride)
 {
-    if (stride != 1 || k != 7 || a.in_f16 || a.out_f16 || !a.vec4 || !a.vec_out || a.epi != VC_EPI_NONE || a.in_xform != VC_IN_NONE ||
-        a.tail_wpk || a.res_f16 || a.out_mode != VC_OUT_PLAIN)
+    if (stride != 1 || (k != 7 && k != 3) || a.in_f16 || a.out_f16 || !a.vec4 || !a.vec_out || a.epi != VC_EPI_NONE ||
+        a.in_xform != VC_IN_NONE || a.tail_wpk || a.res_f16)
         return VC_EINVAL;
     if ((long long)(k + 15) * a.in_sh * 4 + 48ll * a.in_sw * 4 + 256 >= (1ll << 31)) return VC_EINVAL;
-    const int nchunk = a.Cin / 16, nt = a.Cout / 32;
-    if (a.Cin != nchunk * 16 || a.Cout != nt * 32) return VC_EINVAL;
+    const int nchunk = a.Cin / 16;
+    const int nt = a.Cout >= 128 ? 4 : a.Cout / 32;
+    if (a.Cin != nchunk * 16 || a.Cout % 32 || (nt == 4 && a.Cout % 128) || (nt != 1 && nt != 2 && nt != 4)) return VC_EINVAL;
     a.tiles_x = (a.Wo + 31) / 32;
     a.tiles_y = (a.Ho + 15) / 16;
-    a.nblks = 1;
-    a.total_blocks = a.tiles_x * a.tiles_y * a.N;
+    a.nblks = a.Cout / (32 * nt);
+    if (a.nblks != 1 && k != 3) return VC_EINVAL;
+    a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
+    if (k == 3) {
+        if (nchunk == 8 && nt == 4) return launch_conv_dma<DmaCfg<3, 3, 8, 4, 6, 0, false, true>>(st, a);     // 128 -> 128 k
+        if (nchunk == 4 && nt == 2) return launch_conv_dma<DmaCfg<3, 3, 4, 2, 3, 0, false, true>>(st, a);     // 64 -> 64
+        if (nchunk == 4 && nt == 4) return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 0, false, true>>(st, a);     // 64 -> 128 k
+        if (nchunk == 8 && nt == 2) return launch_conv_dma<DmaCfg<3, 3, 8, 2, 3, 0, false, true>>(st, a);     // 128 -> 64
+        if (nchunk == 16 && nt == 4) return launch_conv_dma<DmaCfg<3, 3, 16, 4, 6, 0, false, true>>(st, a);   // 256 -> 128 k
+        return VC_EINVAL;
+    }
+    if (a.out_mode != VC_OUT_PLAIN) return VC_EINVAL;
 #ifdef VC_DMA_DIAG      // diagnostic build only (make dma_diag): knock-out variants of the fp32 64 -> 32 instance
     if (nchunk == 4 && nt == 1) {
         const char *e = getenv("VC_DMA_VARIANT");

@@ -621,7 +621,9 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     // each over all taps, so that every output sums its k-steps in the order (32-channel chunk, tap, k-step) -- the order
     // of the 32-channel-chunk instances (5x5, 7x7) and of the LDS-DMA kernel (conv_dma.h), which is therefore
     // bit-identical to this one.  (1x1: a single tap, the order is the same either way.)
-    constexpr int SUBS = (F16 && KSTEPS == 4 && KH * KW > 1) ? 2 : 1;
+    // fp32, 32-wide tiles, round 4: the same split (two 16-channel halves of a 32-channel chunk, each over all taps), so that the
+    // exact fp32 LDS-DMA instances (DmaCfg::F32, 16-channel chunks) are bit-identical to these.
+    constexpr int SUBS = (KSTEPS == 4 && KH * KW > 1 && (F16 || C::MT == 32)) ? 2 : 1;
     constexpr int KSS = KSTEPS / SUBS;               // k-steps per tap and pass
     constexpr int RING = F16 ? vc_ring_depth(KW * KSS, vc_ring_regs_classic(WM, WN, M::NREG, C::MIN_WAVES), WN) : 1;
     f32x4 ring[RING][WN];
@@ -729,46 +731,48 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
                 });
             }
         } else {
-        load_b(bc, wchunk, 0);
-        load_a(ac, 0, 0);
+        // (pass, kernel row): a pass covers KSS of the chunk's k-steps over all taps (SUBS = 1: the whole chunk)
+        constexpr int STEPS_R = KW * KSS;
+        auto load_b2 = [&](f32x4(&b)[WN], const float *wrow, int sx) {
+            const int kx = sx / KSS, ks = sx % KSS;
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+                b[n] = *reinterpret_cast<const f32x4 *>(wrow + n * ntile_stride + ((long long)kx * ksteps_total + ks) * FR);
+        };
+        auto load_a2 = [&](f32x4(&a)[WM], int rowoff, int sx) {
+            const int kx = sx / KSS, ks = sx % KSS;
+            const int koff = (G::LS == 2) ? ((kx & 1) * G::HALF + (kx >> 1)) * G::CKP : kx * G::CKP;
+#pragma unroll
+            for (int t = 0; t < WM; ++t) a[t] = *reinterpret_cast<const f32x4 *>(&lds[abase[t] + rowoff + koff + ks * KS]);
+        };
+        load_b2(bc, wchunk, 0);
+        load_a2(ac, 0, 0);
 #pragma unroll 1
-        for (int ky = 0; ky < KH; ++ky) {
-            const float *wrow = wchunk + (long long)ky * KW * ksteps_total * FR;
-            const int rowoff = ky * G::COLS_L * G::CKP;
+        for (int r = 0; r < SUBS * KH; ++r) {
+            const int sub = r / KH, ky = r - sub * KH;
+            const float *wrow = wchunk + ((long long)ky * KW * ksteps_total + sub * KSS) * FR;
+            const int rowoff = ky * G::COLS_L * G::CKP + sub * KSS * KS;
             // the row after this one (clamped: the last row re-fetches itself, a harmless extra load)
-            const int kyn = ky + 1 < KH ? ky + 1 : ky;
-            const float *wrow_n = wchunk + (long long)kyn * KW * ksteps_total * FR;
-            const int rowoff_n = kyn * G::COLS_L * G::CKP;
-            static_for<0, STEPS_X>([&](auto sc) {
+            const int rn = r + 1 < SUBS * KH ? r + 1 : r;
+            const int subn = rn / KH, kyn = rn - subn * KH;
+            const float *wrow_n = wchunk + ((long long)kyn * KW * ksteps_total + subn * KSS) * FR;
+            const int rowoff_n = kyn * G::COLS_L * G::CKP + subn * KSS * KS;
+            static_for<0, STEPS_R>([&](auto sc) {
                 constexpr int sx = decltype(sc)::value;
-                if constexpr (sx + 1 < STEPS_X) {
-                    load_b(bn, wrow, sx + 1);
-                    load_a(an, rowoff, sx + 1);
+                if constexpr (sx + 1 < STEPS_R) {
+                    load_b2(bn, wrow, sx + 1);
+                    load_a2(an, rowoff, sx + 1);
                 } else {
-                    load_b(bn, wrow_n, 0);
-                    load_a(an, rowoff_n, 0);
+                    load_b2(bn, wrow_n, 0);
+                    load_a2(an, rowoff_n, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (F16) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int t = 0; t < WM; ++t)
 #pragma unroll
-                        for (int n = 0; n < WN; ++n) {
-                            if constexpr (MT == 32)
-                                acc[t][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bc[n]),
-                                                                                   __builtin_bit_cast(f16x8, ac[t]), acc[t][n], 0, 0, 0);
-                            else
-                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bc[n]),
-                                                                                   __builtin_bit_cast(f16x8, ac[t]), acc[t][n], 0, 0, 0);
-                        }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int t = 0; t < WM; ++t)
-#pragma unroll
-                            for (int n = 0; n < WN; ++n) acc[t][n] = M::run(bc[n][e], ac[t][e], acc[t][n]);
-                }
+                        for (int n = 0; n < WN; ++n) acc[t][n] = M::run(bc[n][e], ac[t][e], acc[t][n]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int n = 0; n < WN; ++n) bc[n] = bn[n];
