@@ -14,7 +14,7 @@ static bool dma_views_ok(const ConvArgs &a)
 // the 3x3 stride-1 layers of the residual blocks / U-Nets (LHBDC/model/layers.py:123-166, Flex-Rate.../b_model/unet.py:9-91)
 static int conv_dispatch_dma_f32(hipStream_t st, ConvArgs a, int k, int stride)
 {
-    if (stride != 1 || (k != 7 && k != 3) || a.in_f16 || a.out_f16 || !a.vec4 || !a.vec_out || a.epi != VC_EPI_NONE ||
+    if (stride != 1 || (k != 7 && k != 3 && k != 5) || a.in_f16 || a.out_f16 || !a.vec4 || !a.vec_out || a.epi != VC_EPI_NONE ||
         a.in_xform != VC_IN_NONE || a.tail_wpk || a.res_f16)
         return VC_EINVAL;
     if ((long long)(k + 15) * a.in_sh * 4 + 48ll * a.in_sw * 4 + 256 >= (1ll << 31)) return VC_EINVAL;
@@ -35,6 +35,12 @@ static int conv_dispatch_dma_f32(hipStream_t st, ConvArgs a, int k, int stride)
         return VC_EINVAL;
     }
     if (a.out_mode != VC_OUT_PLAIN) return VC_EINVAL;
+    if (k == 5) {          // the mask U-Net's 5x5 layers (LHBDC/model/layers.py:202-209)
+        if (nchunk == 6 && nt == 1) return launch_conv_dma<DmaCfg<5, 5, 6, 1, 5, 0, false, true>>(st, a);     // 96 -> 32
+        if (nchunk == 12 && nt == 2) return launch_conv_dma<DmaCfg<5, 5, 12, 2, 5, 0, false, true>>(st, a);   // 192 -> 64
+        if (nchunk == 2 && nt == 2) return launch_conv_dma<DmaCfg<5, 5, 2, 2, 5, 0, false, true>>(st, a);     // 32 -> 64
+        return VC_EINVAL;
+    }
 #ifdef VC_DMA_DIAG      // diagnostic build only (make dma_diag): knock-out variants of the fp32 64 -> 32 instance
     if (nchunk == 4 && nt == 1) {
         const char *e = getenv("VC_DMA_VARIANT");
