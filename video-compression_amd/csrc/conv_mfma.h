@@ -623,7 +623,11 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
     // bit-identical to this one.  (1x1: a single tap, the order is the same either way.)
     // fp32, 32-wide tiles, round 4: the same split (two 16-channel halves of a 32-channel chunk, each over all taps), so that the
     // exact fp32 LDS-DMA instances (DmaCfg::F32, 16-channel chunks) are bit-identical to these.
+#ifdef VC_NO_F32_SUBS          // A/B builds only (tools/subs_ab.sh): the round-1..3 order of the fp32 3x3 loop
+    constexpr int SUBS = (F16 && KSTEPS == 4 && KH * KW > 1) ? 2 : 1;
+#else
     constexpr int SUBS = (KSTEPS == 4 && KH * KW > 1 && (F16 || C::MT == 32)) ? 2 : 1;
+#endif
     constexpr int KSS = KSTEPS / SUBS;               // k-steps per tap and pass
     constexpr int RING = F16 ? vc_ring_depth(KW * KSS, vc_ring_regs_classic(WM, WN, M::NREG, C::MIN_WAVES), WN) : 1;
     f32x4 ring[RING][WN];
@@ -747,16 +751,52 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
         };
         load_b2(bc, wchunk, 0);
         load_a2(ac, 0, 0);
+        if constexpr (SUBS == 2) {
+            // two passes, each over all taps: the taps of a pass fully unrolled (KH * STEPS_R steps), ONE rolled loop over the
+            // passes -- a rolled loop over (pass, kernel row) drains the operand pipeline at every back-edge (6 per chunk
+            // instead of 3: 4-9 % on the 3x3 layers, tools/subs_ab.sh)
 #pragma unroll 1
-        for (int r = 0; r < SUBS * KH; ++r) {
-            const int sub = r / KH, ky = r - sub * KH;
-            const float *wrow = wchunk + ((long long)ky * KW * ksteps_total + sub * KSS) * FR;
-            const int rowoff = ky * G::COLS_L * G::CKP + sub * KSS * KS;
+            for (int sub = 0; sub < SUBS; ++sub) {
+                const float *wpass = wchunk + (long long)sub * KSS * FR;
+                const int aoff = sub * KSS * KS;
+                const int subn = sub + 1 < SUBS ? sub + 1 : sub;          // (clamped: the last pass re-fetches its first step)
+                const float *wpass_n = wchunk + (long long)subn * KSS * FR;
+                const int aoff_n = subn * KSS * KS;
+                static_for<0, KH * STEPS_R>([&](auto sc) {
+                    constexpr int sxx = decltype(sc)::value;
+                    constexpr int ky = sxx / STEPS_R, sx = sxx % STEPS_R;
+                    constexpr int nxx = sxx + 1, kyn = nxx / STEPS_R, sxn = nxx % STEPS_R;
+                    if constexpr (nxx < KH * STEPS_R) {
+                        load_b2(bn, wpass + (long long)kyn * KW * ksteps_total * FR, sxn);
+                        load_a2(an, kyn * G::COLS_L * G::CKP + aoff, sxn);
+                    } else {
+                        load_b2(bn, wpass_n, 0);
+                        load_a2(an, aoff_n, 0);
+                    }
+                    (void)ky; (void)sx;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < WM; ++t)
+#pragma unroll
+                            for (int n = 0; n < WN; ++n) acc[t][n] = M::run(bc[n][e], ac[t][e], acc[t][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) bc[n] = bn[n];
+#pragma unroll
+                    for (int t = 0; t < WM; ++t) ac[t] = an[t];
+                });
+            }
+        } else {
+#pragma unroll 1
+        for (int ky = 0; ky < KH; ++ky) {
+            const float *wrow = wchunk + (long long)ky * KW * ksteps_total * FR;
+            const int rowoff = ky * G::COLS_L * G::CKP;
             // the row after this one (clamped: the last row re-fetches itself, a harmless extra load)
-            const int rn = r + 1 < SUBS * KH ? r + 1 : r;
-            const int subn = rn / KH, kyn = rn - subn * KH;
-            const float *wrow_n = wchunk + ((long long)kyn * KW * ksteps_total + subn * KSS) * FR;
-            const int rowoff_n = kyn * G::COLS_L * G::CKP + subn * KSS * KS;
+            const int kyn = ky + 1 < KH ? ky + 1 : ky;
+            const float *wrow_n = wchunk + (long long)kyn * KW * ksteps_total * FR;
+            const int rowoff_n = kyn * G::COLS_L * G::CKP;
             static_for<0, STEPS_R>([&](auto sc) {
                 constexpr int sx = decltype(sc)::value;
                 if constexpr (sx + 1 < STEPS_R) {
@@ -779,6 +819,7 @@ __global__ void __launch_bounds__(256, C::MIN_WAVES) conv_mfma_kernel(const Conv
 #pragma unroll
                 for (int t = 0; t < WM; ++t) ac[t] = an[t];
             });
+        }
         }
         }
         VC_T(t_e);
