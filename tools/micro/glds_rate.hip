@@ -7,6 +7,8 @@
 //   form 3: global_load_lds_dwordx4 with SGPR base + 32-bit lane offset, contiguous
 //   form 4: plain global_load_dwordx4 to VGPRs, contiguous (for comparison)
 //   form 5: global_load_lds_dword (4 B per lane), contiguous 256 B
+//   form 6: buffer_load_dwordx4 ... offen lds (SGPR resource descriptor + 32-bit lane offset), 16 px x 64 B
+//   form 7: global_load_lds_dwordx4 with SGPR base + 32-bit lane offset, 16 px x 64 B (form 1 with the cheaper address)
 // Build: hipcc --offload-arch=gfx950 -O3 glds_rate.hip -o glds_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -15,6 +17,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int FORM, int NI> __global__ void __launch_bounds__(512, 2)
 rate(const unsigned char *src, unsigned long long *out, int issuing_waves, int mfma_waves, int reps, float *sink)
@@ -28,6 +31,14 @@ rate(const unsigned char *src, unsigned long long *out, int issuing_waves, int m
     for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(lane * 0.01f + i); b[i] = (_Float16)(i - lane * 0.02f); }
     unsigned long long total = 0;
     f32x4 vsum = {0, 0, 0, 0};
+    i32x4 rsrc;          // raw buffer over this CU's 1 MiB window (stride 0: out-of-range offsets read zero)
+    {
+        const unsigned long long a = (unsigned long long)base;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+        rsrc[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffff));
+        rsrc[2] = __builtin_amdgcn_readfirstlane(1 << 20);
+        rsrc[3] = __builtin_amdgcn_readfirstlane(0x00020000);
+    }
     for (int r = 0; r < reps; ++r) {
         __syncthreads();
         if (wave < issuing_waves) {
@@ -49,6 +60,12 @@ rate(const unsigned char *src, unsigned long long *out, int issuing_waves, int m
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(p), "s"(ldsaddr) : "memory");
                 } else if constexpr (FORM == 3) {
                     const unsigned voff = (unsigned)(blk * 1024 + lane * 16);
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(ldsaddr) : "memory");
+                } else if constexpr (FORM == 6) {
+                    const unsigned voff = (unsigned)((blk & 511) * 2048 + (lane >> 2) * 256 + (lane & 3) * 16);
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(ldsaddr) : "memory");
+                } else if constexpr (FORM == 7) {
+                    const unsigned voff = (unsigned)((blk & 511) * 2048 + (lane >> 2) * 256 + (lane & 3) * 16);
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(ldsaddr) : "memory");
                 } else if constexpr (FORM == 4) {
                     vv[i] = *reinterpret_cast<const f32x4 *>(base + blk * 1024 + lane * 16);
@@ -108,5 +125,7 @@ int main()
     run<3>(src, out, sink, "glds x4, SGPR base + 32-bit offset, contiguous");
     run<4>(src, out, sink, "global_load_dwordx4 -> VGPR, contiguous");
     run<5>(src, out, sink, "glds x1 (4 B/lane), contiguous");
+    run<6>(src, out, sink, "buffer_load x4 lds, descriptor + 32-bit offset, 16 px x 64 B");
+    run<7>(src, out, sink, "glds x4, SGPR base + 32-bit offset, 16 px x 64 B");
     return 0;
 }
