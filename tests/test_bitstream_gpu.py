@@ -185,9 +185,11 @@ def test_lhbdc_encode_B_integers_against_the_reference(dev, lhbdc_model):
         # at most one latent in a thousand may flip (measured on MI355X: see the printed report).  The seeded (untrained)
         # transforms are not contractive: ONE flipped symbol of the motion codec moves the residual codec's whole input, so behind
         # an upstream flip the residual codec's integers are bounded an order of magnitude looser (the cascade, not first order).
-        for name in d:
-            upstream = k == "res" and any(report["mv"].values())
-            assert d[name] <= max(1, total[name] // (30 if upstream else 1000)), (k, name, d[name], total[name])
+        # The same holds inside a codec: a flipped HYPER-latent moves the means and scales every y of its neighbourhood is coded
+        # against.
+        for name in ("z_sym", "y_sym", "y_idx"):
+            cascade = (k == "res" and any(report["mv"].values())) or (name != "z_sym" and d["z_sym"] > 0)
+            assert d[name] <= max(1, total[name] // (30 if cascade else 1000)), (k, name, d[name], total[name])
         if d["z_sym"] == 0:
             assert strings[f"{k}_z"] == fx[f"{k}_z"].tobytes(), k
         if d["y_sym"] == 0 and d["y_idx"] == 0:
@@ -211,9 +213,13 @@ def test_flex_encode_B_integers_against_the_reference(dev, flex_model):
         d = {name: n_diff(trace[k][name], lat[f"{k}_{name}"]) for name in ("y_sym", "y_idx", "z_sym")}
         total = {name: lat[f"{k}_{name}"].size for name in d}
         report[k] = d
-        for name in d:        # (behind a flipped flow-codec symbol the residual codec sees another input: see the LHBDC twin)
-            upstream = k == "res" and any(report["flow"].values())
-            assert d[name] <= max(1, total[name] // (30 if upstream else 1000)), (k, name, d[name], total[name])
+        # (cascades behind a flipped upstream symbol / hyper-latent: see the LHBDC twin.  Flex-Rate's residual codec ALWAYS sits
+        #  behind an amplifier: its input went through the decoded flow field, two warps and the untrained depth-4 mask U-Net, which
+        #  turn the 1e-5 summation-order noise of the flow synthesis into ~1e-3 at the residual codec's input -- 0-8 of its 768
+        #  hyper-latents re-round depending on the loop order of the kernels in use; the flow codec is held to the first-order bound)
+        for name in ("z_sym", "y_sym", "y_idx"):
+            cascade = k == "res" or (name != "z_sym" and d["z_sym"] > 0)
+            assert d[name] <= max(1, total[name] // (30 if cascade else 1000)), (k, name, d[name], total[name])
         if d["z_sym"] == 0:
             assert strings[f"{k}_z"] == fx[f"{k}_z"].tobytes(), k
         if d["y_sym"] == 0 and d["y_idx"] == 0:
