@@ -215,14 +215,15 @@ def test_flex_encode_B_integers_against_the_reference(dev, flex_model):
     print("Flex encode_B integers differing from the reference's:", report, "of", totals)
     for k in ("flow", "res"):
         d, total = report[k], totals[k]
-        # (cascades behind a flipped upstream symbol / hyper-latent: see the LHBDC twin.  Flex-Rate's residual codec ALWAYS sits
-        #  behind an amplifier: its input went through the decoded flow field, two warps and the untrained depth-4 mask U-Net, which
-        #  turn the 1e-5 summation-order noise of the flow synthesis into ~1e-3 at the residual codec's input -- 0-8 of its 768
-        #  hyper-latents re-round depending on the loop order of the kernels in use (0 in rounds 1-3, 8 with round 4's), and each
-        #  of them moves the scales and means of a 16 x 16 neighbourhood: 5 % of the indexes.  The flow codec is held to the
-        #  first-order bound; the residual codec's first-order behaviour is pinned where nothing amplifies: the reference's own
-        #  latents (test_flex_reference_latents_give_the_reference_strings) and the calibrated checkpoint at 1088x1920 against the
-        #  reference itself (test_reference_1080p_gpu.py::test_flex_forward_meets_the_reference_at_1088x1920: <= 2 per tensor).)
+        # (cascades behind a flipped upstream symbol / hyper-latent: see the LHBDC twin.  Flex-Rate's residual codec sits behind an
+        #  amplifier the coded flow integers do not show: encode_B codes the UN-gained flow latent (quirk B.6) but reconstructs the
+        #  flow from the forward pass's GAINED rounding, and one such latent of this crop sits 1e-5 from its rounding boundary
+        #  (tools/flex_stage_diag.py: flow y max|d| 1.0e-5 either way; with the loop order of rounds 1-3 it stays on the
+        #  reference's side -- mask 1.5e-5, residual input 2.9e-4, 0 residual integers differ -- with round 4's it flips: decoded
+        #  flow -> two warps -> the untrained depth-4 mask U-Net -> mask 0.07, residual input 0.69, 8 of 768 hyper-latents, 5 % of
+        #  the indexes).  The flow codec is held to the first-order bound; the residual codec's first-order behaviour is pinned where
+        #  nothing amplifies: the reference's own latents (test_flex_reference_latents_give_the_reference_strings) and the
+        #  calibrated checkpoint at 1088x1920 against the reference itself (test_reference_1080p_gpu.py: <= 2 per tensor).)
         for name in ("z_sym", "y_sym", "y_idx"):
             cascade = k == "res" or (name != "z_sym" and d["z_sym"] > 0)
             assert d[name] <= max(1, total[name] // (12 if cascade else 1000)), (k, name, d[name], total[name])
