@@ -891,7 +891,8 @@ def test_fused_bottleneck_tail_equals_the_two_layers(dev, c, n, h, w):
 @pytest.mark.parametrize("cin,cout,k,n,h,w", [(64, 32, 7, 2, 50, 70), (32, 64, 7, 1, 34, 60), (64, 32, 7, 4, 160, 288), (32, 64, 7, 3, 17, 33),
                                               (128, 128, 3, 1, 40, 72), (128, 128, 3, 3, 17, 33), (128, 512, 3, 1, 34, 60), (64, 64, 3, 2, 33, 50),
                                               (64, 128, 3, 1, 50, 70), (128, 64, 3, 1, 20, 36), (256, 128, 3, 1, 16, 40), (128, 128, 3, 2, 160, 288),
-                                              (96, 32, 5, 2, 33, 50), (192, 64, 5, 1, 40, 72), (32, 64, 5, 1, 100, 170)])
+                                              (96, 32, 5, 2, 33, 50), (192, 64, 5, 1, 40, 72), (32, 64, 5, 1, 100, 170),
+                                              (32, 64, 3, 1, 100, 170)])
 def test_lds_dma_fp32_kernel_is_bit_identical(dev, cin, cout, k, n, h, w):
     """The EXACT fp32 instances of the LDS-DMA pipeline (csrc/conv_dma.h, DmaCfg::F32: fp32 tensors, v_mfma_f32_32x32x2_f32,
     16-channel chunks): SPyNet's two big 7x7 layers (LHBDC/model/flow.py:52-62) and the 3x3 stride-1 layers of the residual blocks

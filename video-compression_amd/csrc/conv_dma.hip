@@ -32,6 +32,9 @@ static int conv_dispatch_dma_f32(hipStream_t st, ConvArgs a, int k, int stride)
         if (nchunk == 4 && nt == 4) return launch_conv_dma<DmaCfg<3, 3, 4, 4, 6, 0, false, true>>(st, a);     // 64 -> 128 k
         if (nchunk == 8 && nt == 2) return launch_conv_dma<DmaCfg<3, 3, 8, 2, 3, 0, false, true>>(st, a);     // 128 -> 64
         if (nchunk == 16 && nt == 4) return launch_conv_dma<DmaCfg<3, 3, 16, 4, 6, 0, false, true>>(st, a);   // 256 -> 128 k
+        // (32 output channels: a 16-channel chunk of a 3x3 layer is only 2.25 phases of four units -- the next chunk image does not fit
+        //  its issue window; those layers stay on the classic instances)
+        if (nchunk == 2 && nt == 2) return launch_conv_dma<DmaCfg<3, 3, 2, 2, 3, 0, false, true>>(st, a);     // 32 -> 64
         return VC_EINVAL;
     }
     if (a.out_mode != VC_OUT_PLAIN) return VC_EINVAL;

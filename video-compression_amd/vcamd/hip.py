@@ -393,6 +393,7 @@ class PackedConv:
         #  included -- the library declines what it has no instance for and the tuner skips it)
         f32_shape = ((kh == 7 and (cin, cout) in ((64, 32), (32, 64)) and not self.ps) or
                      (kh == 3 and cin in (64, 128, 256) and (cout == 64 or cout % 128 == 0) and self.cfg in (0, 1)) or
+                     (kh == 3 and (cin, cout) == (32, 64) and not self.ps) or
                      (kh == 5 and (cin, cout) in ((96, 32), (192, 64), (32, 64)) and not self.ps))
         self.dma_f32 = (bool(self.candidates) and stride == 1 and f32_shape
                         and os.environ.get("VC_DMA_KERNELS", "1") != "0" and os.environ.get("VC_DMA_F32", "1") != "0")
