@@ -929,3 +929,33 @@ def _as_t(buf, n, h, w, c, dev):
     t = hip.T.empty(n, h, w, c, dev)
     t.buf.copy_(buf)
     return t
+
+
+@pytest.mark.parametrize("h,w,n", [(37, 75, 2), (136, 240, 1), (9, 50, 1), (300, 250, 1)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_on_the_streaming_kernel_is_bit_identical(dev, h, w, n, inverse):
+    """GDN / IGDN (compressai.layers.GDN: a 1x1 contraction of x^2, then x * rsqrt / sqrt of it, + the block's skip path) on
+    VC_CFG_PWS (csrc/conv_pws.hip, fp32 128 -> 128): the tile's own input stays in registers (B-operand layout == accumulator
+    layout), the residual is requested one 16-pixel unit ahead.  Bit for bit the general kernel's result, with and without
+    residual, three repetitions (a wrong wait count shows as run-to-run differences), ragged widths, more tiles than waves."""
+    from vcamd import hip
+    g = np.random.default_rng(91)
+    gamma = torch.from_numpy((0.1 * np.eye(128) + g.uniform(0.0, 0.004, size=(128, 128))).astype(np.float32))
+    beta = torch.from_numpy(g.uniform(0.5, 1.5, size=128).astype(np.float32))
+    pc = hip.PackedConv(gamma.view(128, 128, 1, 1), beta, device=dev)
+    assert hip.CFG_PWS in pc.candidates
+    x = hip.nchw_to_nhwc(_rand((n, 128, h, w), 92).to(dev))
+    res = hip.nchw_to_nhwc(_rand((n, 128, h, w), 93).to(dev))
+    epi = hip.EPI_IGDN if inverse else hip.EPI_GDN
+
+    def run(cfg):
+        pc.tuned = {(n, h, w, 0, hip.ACT_NONE, epi): cfg | hip.CFG_EXACT}
+        return [pc(x, epi=epi, mul=x, in_xform=hip.IN_SQUARE).buf.clone(), pc(x, epi=epi, mul=x, in_xform=hip.IN_SQUARE, res=res).buf.clone()]
+    base = run(pc.cfg if pc.cfg <= 2 else 2)
+    for rep in range(3):
+        for a, b in zip(base, run(hip.CFG_PWS)):
+            assert torch.equal(a, b), (a - b).abs().max().item()
+    xc = hip.nhwc_to_nchw(x).cpu()
+    norm = F.conv2d(xc * xc, gamma.view(128, 128, 1, 1), beta)
+    ref = xc * torch.sqrt(norm) if inverse else xc * torch.rsqrt(norm)
+    _close(hip.nhwc_to_nchw(_as_t(base[0], n, h, w, 128, dev)).cpu(), ref, 2e-5, "GDN vs torch")

@@ -6,7 +6,8 @@ The residual of a tile is requested by inline-asm loads whose results the compil
 chooses to insert (phi, tied operand, live-range split) in front of the `s_waitcnt vmcnt(N)` that retires the load reads stale
 registers -- the race `profiles/r03/o_pws_race_screen_both_schedules.log` shows (first build: `o_pw_check_first_version.log`).
 Nothing in the language forbids such a copy, so the build checks the assembly: for every kernel, load number k (unit k // 2 of
-the epilogue) may be mentioned again only after k // 2 + 1 inline-asm waits.
+the epilogue) may be mentioned again only after k // 2 + 1 inline-asm waits (units requested all at once), or -- the GDN
+instances, which request unit g + 1 before they wait for unit g -- after one more wait than the youngest unit still pending.
 
 Limitation: the scan is LINEAR over the assembly text, not a control-flow analysis -- it follows the order of the file.  With
 forward branches only, every execution path between a load and its wait is a sub-sequence of the text between them, so
@@ -35,6 +36,7 @@ def check_kernel(name, lines):
     pending = []            # [registers, waits still needed]
     in_asm = False
     nload = 0
+    unit_need = 1
     seen_labels, open_targets = set(), set()
     for ln, line in lines:
         t = line.strip()
@@ -69,7 +71,11 @@ def check_kernel(name, lines):
             for regs, _ in pending:
                 if regs & used:
                     problems.append((ln, t, "address uses an in-flight register"))
-            pending.append([regs_of(dst), nload // 2 + 1])
+            # a unit = two consecutive loads; it is retired by one more wait than the youngest unit still pending (units
+            # requested all at once need 1, 2, 3 ... waits; a unit requested one ahead of its predecessor's wait needs 2)
+            if nload % 2 == 0:
+                unit_need = max((p_[1] for p_ in pending), default=0) + 1
+            pending.append([regs_of(dst), unit_need])
             nload += 1
             total += 1
             continue

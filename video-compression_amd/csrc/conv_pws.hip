@@ -72,8 +72,15 @@ __device__ __forceinline__ f32x4 pws_load16(const void *uniform_base, unsigned l
     return v;
 }
 
-template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_kernel(const ConvArgs p)      // RES: 0 none, 1 fp32, 2 half
+// GDN (fp32 instances, 128 -> 128 only): 0 none; 1 GDN / 2 IGDN of compressai.layers -- the layer is a 1x1 contraction of x^2 and its
+// epilogue multiplies the un-squared x by rsqrt / sqrt of the result (conv_mfma.h: VC_IN_SQUARE + VC_EPI_GDN / IGDN with mul == in).
+// The B operand registers of lane (pixel, half) ARE the elements its accumulators belong to (k-step 4 t + g, element e <->
+// accumulator 4 g + e of N-tile t), so the tile's x stays in 64 registers (squared on the way into the MFMA) and no second read
+// of the input exists.  The residual (the block's skip path) is then requested 16 pixels ahead of its use instead of a tile at
+// once: 64 registers fewer.
+template <class C, int RES, int GDN = 0> __global__ void __launch_bounds__(512, 2) conv_pws_kernel(const ConvArgs p)      // RES: 0 none, 1 fp32, 2 half
 {
+    static_assert(GDN == 0 || (!C::F16 && C::KQ == 16 && C::NT == 4 && RES != 2), "GDN / IGDN: the fp32 128 -> 128 instance");
     constexpr int KQ = C::KQ, NT = C::NT, NSUB = C::NSUB, D = C::D, NI = C::NI, QPS = C::QPS, RPQ = C::RPQ, S = C::S;
     constexpr bool F16 = C::F16;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds8[];
@@ -200,8 +207,10 @@ template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_k
         for (int part = 0; part < 2; ++part)
 #pragma unroll
             for (int j = 0; j < 2; ++j) pxc[part][j] = min(part * 16 + 8 * j + rpx, wlim);
-        f32x4 rv[C::NG32][2];
+        constexpr bool res_jit = GDN != 0 && RES == 1;     // residual requested one 16-pixel unit ahead (GDN instances)
+        f32x4 rv[res_jit ? 2 : C::NG32][2];
         f32x2 rvh[C::NG32][2];                    // a half-precision residual: 4 halves per lane and load
+        f32x4 xk[GDN ? NSUB : 1][GDN ? C::NCUR : 1];       // GDN: the tile's own input, B-operand layout == accumulator layout
         // ---- accumulators start at the bias ----
         f32x16 acc[NT];
 #pragma unroll
@@ -217,6 +226,13 @@ template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_k
             constexpr int s = decltype(sc)::value;
 #pragma unroll
             for (int i = 0; i < C::NCUR; ++i) cur[i] = nxt[i];
+            if constexpr (GDN != 0) {
+#pragma unroll
+                for (int i = 0; i < C::NCUR; ++i) {
+                    xk[s][i] = cur[i];
+                    cur[i] = cur[i] * cur[i];                    // VC_IN_SQUARE (stage_chunk of conv_mfma.h squares the same way)
+                }
+            }
             if constexpr (C::nb(s) == 0) {
                 vc_wait_vmcnt<C::wait_a(s, false, false)>();
             } else {
@@ -234,7 +250,7 @@ template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_k
             read_b(slot);                                            // the next sub-row's operands ...
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... are in registers: its slot takes sub-row u+1+D
             issue_dma();
-            if constexpr (s == NSUB - 1 && has_res) {
+            if constexpr (s == NSUB - 1 && has_res && !res_jit) {
                 // residual of this tile: requested behind the tile's last refill, used in the epilogue (see PwsCfg)
                 const unsigned char *rbase =
                     res_b + ((long long)tl.img * p.res_sn + (long long)tl.y * p.res_sh + (long long)tl.x0 * p.res_sw) * (res_half ? 2 : 4);
@@ -325,12 +341,27 @@ template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_k
                 }
             });
         } else {
+            const unsigned char *const rbase_jit =
+                res_b + ((long long)tl.img * p.res_sn + (long long)tl.y * p.res_sh + (long long)tl.x0 * p.res_sw) * 4;
+            auto issue_res = [&](auto gc) {          // (GDN instances) the two residual loads of 16-pixel unit g
+                constexpr int g = decltype(gc)::value;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    rv[g & 1][j] = pws_load16(rbase_jit, (unsigned)(pxc[g & 1][j] * res_pix_bytes + ((g >> 1) * 32 + 4 * rq) * 4));
+            };
+            if constexpr (res_jit) issue_res(std::integral_constant<int, 0>{});
             static_for<0, C::NG32>([&](auto gc) {
                 constexpr int g = decltype(gc)::value, t = g >> 1, part = g & 1;
                 // (no register operand on the wait itself: a tied operand invites a copy of the in-flight registers in FRONT of
                 //  it.  The empty statement BEHIND it takes them instead: asm volatile statements keep their order, a copy made
                 //  for its operands sits between the two, and every use below depends on its result.)
-                if constexpr (has_res) {
+                if constexpr (res_jit) {
+                    // unit g + 1 is requested before unit g is waited for: younger than unit g's loads are then the two stores
+                    // of unit g - 1 and the two loads of unit g + 1
+                    if constexpr (g + 1 < C::NG32) issue_res(std::integral_constant<int, g + 1>{});
+                    vc_wait_vmcnt<(g + 1 < C::NG32 ? 2 : 0) + (g > 0 ? 2 : 0)>();
+                    asm volatile("" : "+v"(rv[g & 1][0]), "+v"(rv[g & 1][1]));
+                } else if constexpr (has_res) {
                     vc_wait_vmcnt<C::WAIT_RES>();
                     if constexpr (res_half) asm volatile("" : "+v"(rvh[g][0]), "+v"(rvh[g][1]));
                     else asm volatile("" : "+v"(rv[g][0]), "+v"(rv[g][1]));
@@ -338,7 +369,12 @@ template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_k
                 const int row = ((n >> 4) == part) ? (n & 15) : 16;
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
-                    const f32x4 v = {acc[t][4 * gg], acc[t][4 * gg + 1], acc[t][4 * gg + 2], acc[t][4 * gg + 3]};
+                    f32x4 v = {acc[t][4 * gg], acc[t][4 * gg + 1], acc[t][4 * gg + 2], acc[t][4 * gg + 3]};
+                    if constexpr (GDN != 0) {        // conv_epilogue MODE 1 / 2: IEEE sqrt and divide, like the CPU path's x * rsqrt(norm)
+                        const f32x4 x = xk[t][gg];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (GDN == 1) ? x[e] * (1.0f / sqrtf(v[e])) : x[e] * sqrtf(v[e]);
+                    }
                     *reinterpret_cast<f32x4 *>(scr + row * (VC_EPI_ROWF * 4) + (8 * gg + 4 * h) * 4) = v;
                 }
 #pragma unroll
@@ -349,7 +385,7 @@ template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_k
                         const f16x4 rh = __builtin_bit_cast(f16x4, rvh[g][j]);
                         r = f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
                     } else if constexpr (has_res) {
-                        r = rv[g][j];
+                        r = rv[res_jit ? (g & 1) : g][j];
                     }
                     if constexpr (has_res) { if (p.res_first) v += r; }
 #pragma unroll
@@ -370,9 +406,9 @@ template <class C, int RES> __global__ void __launch_bounds__(512, 2) conv_pws_k
     vc_wait_vmcnt<0>();
 }
 
-template <class C, int RES> int launch_pws_res(hipStream_t st, const ConvArgs &a)
+template <class C, int RES, int GDN = 0> int launch_pws_res(hipStream_t st, const ConvArgs &a)
 {
-    auto kern = conv_pws_kernel<C, RES>;
+    auto kern = conv_pws_kernel<C, RES, GDN>;
     static vc_lds_raised raised;
     if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), C::LDS_BYTES, raised)) return VC_ELAUNCH;
     const long long ntiles = (long long)a.N * a.H * ((a.W + 31) / 32);
@@ -383,6 +419,11 @@ template <class C, int RES> int launch_pws_res(hipStream_t st, const ConvArgs &a
 
 template <class C> int launch_pws(hipStream_t st, const ConvArgs &a)
 {
+    if constexpr (!C::F16 && C::KQ == 16 && C::NT == 4) {          // GDN / IGDN: the fp32 128 -> 128 instance
+        if (a.epi == VC_EPI_GDN) return a.res ? launch_pws_res<C, 1, 1>(st, a) : launch_pws_res<C, 0, 1>(st, a);
+        if (a.epi == VC_EPI_IGDN) return a.res ? launch_pws_res<C, 1, 2>(st, a) : launch_pws_res<C, 0, 2>(st, a);
+    }
+    if (a.epi != VC_EPI_NONE) return VC_EINVAL;
     if (!a.res) return launch_pws_res<C, 0>(st, a);
     if constexpr (C::F16) {
         if (a.res_f16) return launch_pws_res<C, 2>(st, a);
@@ -417,7 +458,16 @@ template <int PREC> int by_kq(hipStream_t st, const ConvArgs &a)
 
 bool conv_pws_eligible(const ConvArgs &a, int k, int stride, bool f16)
 {
-    if (k != 1 || stride != 1 || a.out_mode != VC_OUT_PLAIN || a.epi != VC_EPI_NONE || a.in_xform != VC_IN_NONE) return false;
+    if (k != 1 || stride != 1 || a.out_mode != VC_OUT_PLAIN) return false;
+    if (a.epi != VC_EPI_NONE) {
+        // GDN / IGDN: fp32, 128 -> 128, the layer's own input as the multiplicand (what compressai's GDN computes), no gain
+        const bool gdn = (a.epi == VC_EPI_GDN || a.epi == VC_EPI_IGDN) && !f16 && a.in_xform == VC_IN_SQUARE && a.Cin == 128 && a.Cout == 128 &&
+                         a.mul == a.in && a.mul_sn == a.in_sn && a.mul_sh == a.in_sh && a.mul_sw == a.in_sw && a.act == VC_ACT_NONE &&
+                         !a.chscale && !a.res_first && !a.res_f16;
+        if (!gdn) return false;
+    } else if (a.in_xform != VC_IN_NONE) {
+        return false;
+    }
     if (a.act != VC_ACT_NONE && a.act != VC_ACT_RELU && a.act != VC_ACT_LRELU) return false;
     if (!a.vec4 || !a.vec_out || (a.Cout % 32) || a.Cout > 128 || a.Cin > 128 || (a.Cin % 32)) return false;
     if ((long long)a.N * a.H * ((a.W + 31) / 32) >= (1ll << 31) || a.in_sw * 4 * 32 >= (1ll << 31) || a.res_sw * 4 * 32 >= (1ll << 31) ||
