@@ -641,6 +641,54 @@ def gen_icip2024(outdir, frames, seed):
     print("  ICIP2024 bookkeeping fixture:", {k: len(v) for k, v in book["refs"].items()})
 
 
+def gen_icip2024_fullsize(outdir, frames, seed):
+    """ICIP2024 FlowGuidedB at BASELINE size: the reference's own flow-resolution search (src/opt_helpers.py:23-51) and
+    FlowGuidedB.forward (src/model/m.py:181-260) on the FULL bundled frames (1088x1920), seeded checkpoint, quality level 2.
+    Oracle == reference; the fixture keeps the decision, sub-sampled floats and the rate figures.  (torchvision's DeformConv2d is
+    the stand-in of oracle/deform.py here too: parity unpinned at that operator, see the module docstring.)"""
+    nat = types.ModuleType("natsort")
+    nat.natsorted = sorted
+    sys.modules.setdefault("natsort", nat)
+    sys.path.insert(0, os.path.join(REF, "ICIP2024"))
+    from src.model import m as ref_m  # noqa
+    from src import opt_helpers as ref_opt  # noqa
+    from_reference(ref_m, ref_opt)
+    sys.path.pop(0)
+    torch.manual_seed(0)
+    ref = ref_m.FlowGuidedB().eval()
+    sd = seeded_state_dict(ref.state_dict(), seed=seed)
+    ref.load_state_dict(sd)
+    ora = oicip.FlowGuidedB().eval()
+    ora.load_state_dict(sd)
+    h, w = frames["current"].shape[:2]
+    sub = (slice(None), slice(None), slice(0, None, 8), slice(0, None, 8))
+    with torch.no_grad():
+        x1, xc, x2 = (olhbdc.pad64(to_tensor(frames[k])) for k in ("ref_1", "current", "ref_2"))
+        print(f"  ICIP2024 full-size fixture: frames {tuple(xc.shape)}")
+        best_r, psnr_r = ref_opt.get_best_down_ratio_prediction(ref, x1, x2, 0.5, 0.5, xc, 1, None)
+        best_o, psnr_o = oicip.get_best_down_ratio_prediction(ora, x1, x2, 0.5, 0.5, xc)
+        check("best down ratio 1088x1920", best_o, best_r)
+        check("best prediction psnr 1088x1920", psnr_o, psnr_r)
+        lvl = 2
+        rr = ref(xref1=x1, xref2=x2, scale1=0.5, scale2=0.5, xcur=xc, s=lvl, down_ratio=best_r)
+        ro = ora(x1, x2, 0.5, 0.5, xc, lvl, best_r)
+        check("FlowGuidedB x_hat 1088x1920", ro["x_hat"], rr["x_hat"])
+        check("FlowGuidedB size", ro["size"], rr["size"])
+        check("FlowGuidedB rate", ro["rate"], rr["rate"])
+        flow_r = ref.estimate_flow(x1, x2, best_r)
+        check("estimate_flow 1088x1920", ora.estimate_flow(x1, x2, best_r), flow_r)
+        u8 = np.round(np.clip(rr["x_hat"][0].numpy(), 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)[:h, :w]
+        mse = np.mean((u8.astype(np.float64) - frames["current"].astype(np.float64)) ** 2)
+        flow_r = flow_r if torch.is_tensor(flow_r) else torch.cat([torch.as_tensor(f) for f in flow_r], 1)
+    np.savez_compressed(os.path.join(outdir, "icip2024_fullsize_1080p.npz"), seed=np.int64(seed), level=np.int64(lvl),
+                        frames_sha256=np.array([hashlib.sha256(frames[k].tobytes()).hexdigest() for k in ("ref_1", "current", "ref_2")]),
+                        best_down_ratio=np.int64(best_r), best_pred_psnr=np.float64(float(psnr_r)),
+                        x_hat_sub8=rr["x_hat"][sub].numpy(), flow_sub8=flow_r[sub].numpy(), size=np.float64(rr["size"].item()),
+                        rate=np.float64(rr["rate"].item()), psnr_u8=np.float64(10.0 * np.log10(255.0 ** 2 / mse)))
+    print(f"    down ratio {int(best_r)}, {10.0 * np.log10(255.0 ** 2 / mse):.3f} dB (uint8), {rr['size'].item() / (h * w):.4f} bpp")
+    print(f"  wrote icip2024_fullsize_1080p.npz ({os.path.getsize(os.path.join(outdir, 'icip2024_fullsize_1080p.npz')) / 1e6:.1f} MB)")
+
+
 def gen_lhbdc_test_loop(outdir, seed, checkpoint="calibrated"):
     """The reference's own evaluation function ``test()`` (LHBDC/test/testing.py:88-196) run on seven tiny synthetic
     "videos" (the seven folder names are hard-coded there): UVGTestDataset reads PNGs this function writes to a temp
@@ -841,7 +889,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--only", choices=["lhbdc", "fullsize", "flexfullsize", "flex", "harness", "icip2024", "testloop", "flextestloop"], default=None)
+    ap.add_argument("--only", choices=["lhbdc", "fullsize", "flexfullsize", "icipfullsize", "flex", "harness", "icip2024", "testloop", "flextestloop"], default=None)
     ap.add_argument("--loop-checkpoint", choices=["seeded", "calibrated"], default="calibrated",
                     help="checkpoint of the B-frame model in the test() loop fixtures (calibrated: trained-like statistics)")
     args = ap.parse_args()
@@ -863,6 +911,8 @@ def main():
         gen_flex(args.out, frames, args.seed)
     if args.only in (None, "icip2024"):
         gen_icip2024(args.out, frames, args.seed)
+    if args.only in (None, "icipfullsize"):
+        gen_icip2024_fullsize(args.out, frames, args.seed)
     if args.only in (None, "testloop"):
         gen_lhbdc_test_loop(args.out, args.seed, args.loop_checkpoint)
     if args.only in (None, "flextestloop"):

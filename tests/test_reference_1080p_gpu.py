@@ -270,3 +270,39 @@ def test_flex_forward_meets_the_reference_at_1088x1920(dev, bundled, frames, tag
     if not upstream:
         assert stage["mask"] < 2e-4 and stage["res_input"] < 2e-4, stage
     assert d_psnr < 1e-3 and d_bits < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ICIP2024 FlowGuidedB against the reference's own search + forward at 1088x1920
+# (fixture icip2024_fullsize_1080p.npz, oracle/gen_golden.py --only icipfullsize; seeded checkpoint, quality level 2)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_icip2024_forward_meets_the_reference_at_1088x1920(dev, bundled, frames):
+    """ICIP2024/src/opt_helpers.py:41-51 (flow-resolution search) + src/model/m.py:181-260 (forward) on the full bundled frames:
+    the same down-ratio decision, the chosen flow field on the 1/8 grid, PSNR and estimated size at the north-star tolerances.
+    (Seeded weights: a latent that re-rounds moves its neighbourhood through untrained synthesis transforms, so pixels are held
+    through the PSNR, as in test_fullsize_gpu.py::test_icip2024_1080p_against_oracle.)"""
+    from vcamd import hip, icip2024
+    from vcamd.layers import BitCounter
+    from vcamd.seeding import seeded_state_dict
+    fx = load_fixture("icip2024_fullsize_1080p.npz")
+    prod = icip2024.FlowGuidedB()
+    prod.load_state_dict(seeded_state_dict(prod.state_dict(), seed=int(fx["seed"])))
+    prod = prod.to(dev).eval()
+    x1, xc, x2 = frames                                  # (ref_1, current, ref_2)
+    with torch.no_grad():
+        t1, tc, t2 = (hip.nchw_to_nhwc(x) for x in (x1, xc, x2))
+        flow_t, choice, _ = prod.search_flow_t(tc, t1, t2, 0.5, 0.5)
+        bits = BitCounter(dev, max_rows=12)
+        x_hat = hip.nhwc_to_nchw(prod.forward_device(t1, t2, 0.5, 0.5, tc, int(fx["level"]), None, bits, flow=flow_t))
+        size = float(bits.totals().sum())
+    best = (1, 2, 4, 8, 16)[int(choice.item())]
+    d_flow = float((nchw(flow_t)[:, :, ::8, ::8] - torch.from_numpy(fx["flow_sub8"])).abs().max())
+    d_psnr = abs(psnr_u8(to_u8(x_hat), bundled["current"]) - float(fx["psnr_u8"]))
+    size_rel = abs(size - float(fx["size"])) / float(fx["size"])
+    d_hat = float((x_hat.cpu()[:, :, ::8, ::8] - torch.from_numpy(fx["x_hat_sub8"])).abs().max())
+    print(f"ICIP2024 FlowGuidedB vs THE REFERENCE at 1088x1920 ({float(fx['psnr_u8']):.3f} dB, {float(fx['size']) / (H * W):.4f} bpp): "
+          f"down ratio {best} / {int(fx['best_down_ratio'])}; flow max|d| (1/8 grid) {d_flow:.2e}; x_hat max|d| (1/8 grid) {d_hat:.2e}; "
+          f"dPSNR(uint8) {d_psnr:.2e} dB; size rel {size_rel:.2e}")
+    assert best == int(fx["best_down_ratio"])
+    assert d_flow < 2e-3
+    assert d_psnr < 1e-3 and size_rel < 2e-3
