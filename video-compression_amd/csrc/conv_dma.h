@@ -319,6 +319,28 @@ __device__ __forceinline__ void dma_epilogue_tail(const ConvArgs &p, f32x16 (&ac
     const unsigned char *const wl = lds8 + C::TAIL_OFF + 16 * lane;
     const float *const b2 = reinterpret_cast<const float *>(lds8 + C::TAIL_OFF + NT * KQ * 1024);
     float *const dump = reinterpret_cast<float *>(g_vc_dma_dump) + 4 * lane;
+    // Half-precision output path: the residual (the block's identity, half or fp32) is requested ONE exchange step ahead of its
+    // use -- the first step of an M-tile before the M-tile's MFMAs.  Requested where it is added, each of the 2 * NT steps of a
+    // tile exposed a full HBM round trip (~1.5 us of a 44 us tile at 128 channels, eight times; of an 11 us tile at 64).
+    const bool half_path = p.out_f16 && (p.out_sw & 7) == 0 && (p.out_sh & 7) == 0 && (p.out_sn & 7) == 0 &&
+                           (!p.res || (((p.res_sw | p.res_sh | p.res_sn) & (p.res_f16 ? 7 : 3)) == 0));
+    constexpr int STEPS = 2 * (NT / 2);                  // exchange steps per M-tile: (channel pair, 16-pixel part)
+    const int rp8h = lane >> 3, roh = lane & 7;
+    f32x4 rnext[2] = {};                                 // [pass j]: 8 halves per lane (an fp32 residual is read where it is added)
+    const bool res_ahead = half_path && p.res && p.res_f16;
+    auto request = [&](int t, int step) {                // residual of exchange step `step` of M-tile t -> rnext
+        const int pr = step >> 1, part = step & 1;
+        const int oy = oy0 + wm * WM + t;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = ox0 + 16 * part + 8 * j + rp8h;
+            const bool ok = oy < p.Ho && ox < p.Wo;
+            const long long r_off = (long long)img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + pr * 64 + 8 * roh;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            rnext[j] = ok ? *reinterpret_cast<const f32x4 *>(reinterpret_cast<const _Float16 *>(p.res) + r_off) : z;
+        }
+    };
+    if (res_ahead) request(0, 0);
     static_for<0, WM>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
         const int oy = oy0 + wm * WM + t;
@@ -351,54 +373,51 @@ __device__ __forceinline__ void dma_epilogue_tail(const ConvArgs &p, f32x16 (&ac
                 acc2[o] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[j & 1][o]), bop, acc2[o], 0, 0, 0);
         });
         // ---- exchange, residual, store ----
-        if (p.out_f16 && (p.out_sw & 7) == 0 && (p.out_sh & 7) == 0 && (p.out_sn & 7) == 0 &&
-            (!p.res || (((p.res_sw | p.res_sh | p.res_sn) & (p.res_f16 ? 7 : 3)) == 0))) {
+        if (half_path) {
             // half-precision output: 16 pixels x 64 channels at a time through the scratch ([16][64 + 4] floats + a dump row the
             // lanes of the other 16 pixels write to), read back as 8 consecutive channels per lane: one 16-byte residual load
             // and one 16-byte store per lane and pass, every store instruction 8 whole 128-byte lines (a 32-channel tile alone
             // would write every line in two halves, 8 bytes per lane: twice the vector-memory instructions)
             constexpr int RF = 68;
-            const int rp8 = lane >> 3, ro = lane & 7;
-            static_for<0, NT / 2>([&](auto pc) {
-                constexpr int pr = decltype(pc)::value;
+            const int rp8 = rp8h, ro = roh;
+            static_for<0, STEPS>([&](auto sc) {
+                constexpr int step = decltype(sc)::value, pr = step >> 1, part = step & 1;
+                const f32x4 rcur[2] = {rnext[0], rnext[1]};
+                if (res_ahead) {                           // the next step's residual (of the next M-tile behind the last step)
+                    if constexpr (step + 1 < STEPS) request(t, step + 1);
+                    else if constexpr (t + 1 < WM) request(t + 1, 0);
+                }
+                const int row = ((wpx >> 4) == part) ? (wpx & 15) * RF : 16 * RF;
 #pragma unroll
-                for (int part = 0; part < 2; ++part) {
-                    const int row = ((wpx >> 4) == part) ? (wpx & 15) * RF : 16 * RF;
+                for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 v = {acc2[2 * pr + hh][4 * g], acc2[2 * pr + hh][4 * g + 1], acc2[2 * pr + hh][4 * g + 2],
-                                             acc2[2 * pr + hh][4 * g + 3]};
-                            *reinterpret_cast<f32x4 *>(&scratch[row + 32 * hh + 8 * g + 4 * whalf]) = v;
-                        }
-                    const int co = pr * 64 + 8 * ro;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int pix = 8 * j + rp8;
-                        f32x4 v0 = *reinterpret_cast<const f32x4 *>(&scratch[pix * RF + 8 * ro]);
-                        f32x4 v1 = *reinterpret_cast<const f32x4 *>(&scratch[pix * RF + 8 * ro + 4]);
-                        const int ox = ox0 + 16 * part + pix;
-                        const bool ok = oy < p.Ho && ox < p.Wo;
-                        const long long o_off = (long long)img * p.out_sn + (long long)oy * p.out_sh + (long long)ox * p.out_sw + co;
-                        if (p.res) {
-                            const long long r_off = (long long)img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + co;
-                            if (p.res_f16) {
-                                f32x4 raw = {0.f, 0.f, 0.f, 0.f};
-                                if (ok) raw = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const _Float16 *>(p.res) + r_off);
-                                const f16x8 rh = __builtin_bit_cast(f16x8, raw);
-                                v0 += f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
-                                v1 += f32x4{(float)rh[4], (float)rh[5], (float)rh[6], (float)rh[7]};
-                            } else if (ok) {
-                                v0 += *reinterpret_cast<const f32x4 *>(p.res + r_off);
-                                v1 += *reinterpret_cast<const f32x4 *>(p.res + r_off + 4);
-                            }
-                        }
-                        const f16x8 hv = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
-                                          (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
-                        _Float16 *dst = ok ? reinterpret_cast<_Float16 *>(p.out) + o_off : reinterpret_cast<_Float16 *>(dump);
-                        *reinterpret_cast<f16x8 *>(dst) = hv;
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc2[2 * pr + hh][4 * g], acc2[2 * pr + hh][4 * g + 1], acc2[2 * pr + hh][4 * g + 2],
+                                         acc2[2 * pr + hh][4 * g + 3]};
+                        *reinterpret_cast<f32x4 *>(&scratch[row + 32 * hh + 8 * g + 4 * whalf]) = v;
                     }
+                const int co = pr * 64 + 8 * ro;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pix = 8 * j + rp8;
+                    f32x4 v0 = *reinterpret_cast<const f32x4 *>(&scratch[pix * RF + 8 * ro]);
+                    f32x4 v1 = *reinterpret_cast<const f32x4 *>(&scratch[pix * RF + 8 * ro + 4]);
+                    const int ox = ox0 + 16 * part + pix;
+                    const bool ok = oy < p.Ho && ox < p.Wo;
+                    const long long o_off = (long long)img * p.out_sn + (long long)oy * p.out_sh + (long long)ox * p.out_sw + co;
+                    if (res_ahead) {
+                        const f16x8 rh = __builtin_bit_cast(f16x8, rcur[j]);
+                        v0 += f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                        v1 += f32x4{(float)rh[4], (float)rh[5], (float)rh[6], (float)rh[7]};
+                    } else if (p.res && ok) {              // (fp32 identity: the first block of a chain)
+                        const long long r_off = (long long)img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + co;
+                        v0 += *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                        v1 += *reinterpret_cast<const f32x4 *>(p.res + r_off + 4);
+                    }
+                    const f16x8 hv = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
+                                      (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+                    _Float16 *dst = ok ? reinterpret_cast<_Float16 *>(p.out) + o_off : reinterpret_cast<_Float16 *>(dump);
+                    *reinterpret_cast<f16x8 *>(dst) = hv;
                 }
             });
         } else {
