@@ -549,6 +549,7 @@ def main():
         }
         sw.release()
         del sw
+        torch.cuda.empty_cache()          # (the test set and its graphs: ~100 GB of cached blocks nothing below needs)
     result["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)   # of 288 GB, this rank, graphs included
     if strong:
         table = vgop.RdTable()
@@ -599,6 +600,8 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
     # (three instrumented frames, averaged: a single launch of the dominant kernel varies by +-2 % with what ran before it)
     NFR = 3
     with torch.no_grad():
+        product_frame()                  # (untimed: the first eager frame behind another workload runs 2-3 % slow)
+        torch.cuda.synchronize()
         hip.timer = hip.KernelTimer()
         for _ in range(NFR):
             product_frame()
