@@ -252,6 +252,13 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--checkpoint", choices=["calibrated", "seeded"], default="calibrated",
                     help="LHBDC / Flex-Rate weights: calibrated = seeded weights rescaled to trained-like statistics (default), seeded = plain")
+    ap.add_argument("--byte-equality", action="store_true",
+                    help="N = 1 extras: eight encode_B containers against the CPU oracle's, byte for byte (eight 1088x1920 oracle passes, "
+                         "~50 s; tests/test_byte_equality_gpu.py asserts the same) -- off by default since round 5 to keep the driver's run short")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="time the CPU oracle at all physical cores as well as at 8 threads (round 2-4 default; the 128-thread run was always slower)")
+    ap.add_argument("--parity-both-checkpoints", action="store_true",
+                    help="repeat the parity block on the other checkpoint kind (one more oracle pass)")
     ap.add_argument("--skip-extras", action="store_true",
                     help="N = 1: skip the whole-GOP-with-I-frame and real-bitstream blocks (profiling runs: the trace then holds the timed "
                          "region and the one instrumented frame of the roofline block only)")
@@ -506,6 +513,9 @@ def main():
         # ONE pass over a UVG-shaped test set sized to ~--strong-seconds at this number of GPUs, contiguous GOP ranges per
         # rank, I-frames included, R-D records gathered over RCCL.  Frames and records are functions of (sequence, index)
         # alone, so the checksum over the part of the set EVERY world size codes (the N = 1 sizing) must agree across N. ----
+        # (the headline workload's high-water mark is taken BEFORE the strong block allocates its test set and graphs)
+        result["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)
+        torch.cuda.reset_peak_memory_stats(dev)
         fps_n = strong_frames_per_sequence(args.strong_seconds, world, args.sequences)
         fps_1 = strong_frames_per_sequence(args.strong_seconds, 1, args.sequences)
         sw = StrongWorkload(args, model, dev, world, rank, H, W, G, fps_n)
@@ -547,10 +557,11 @@ def main():
             "rd_checksum_common": dict(rd_checksum(s_rows.tolist(), frames_limit=fps_1), frames_per_sequence=fps_1,
                                        what="records of the frames every world size codes (the N = 1 sizing of the set): equal across N"),
         }
+        result["strong"]["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)   # test set + graphs of this block
         sw.release()
         del sw
         torch.cuda.empty_cache()          # (the test set and its graphs: ~100 GB of cached blocks nothing below needs)
-    result["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)   # of 288 GB, this rank, graphs included
+    result.setdefault("peak_hbm_gb", round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1))   # of 288 GB, this rank, graphs included
     if strong:
         table = vgop.RdTable()
         table.extend_from_records(rows.tolist(), level=7)
@@ -788,42 +799,49 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
         runs = {}
         ref_hat = ref_bits = None
         traces = None
+
+        def traced_oracle_frame():
+            """one call with the latent capture hooked in (the integer parity figures below): the untimed warm-up call"""
+            if is_icip:
+                return oracle_frame() + (None,)
+            mv_name = "flow_compressor" if is_flex else "mv_compressor"
+            with CodecTrace(getattr(ora, mv_name)) as t_mv, CodecTrace(ora.residual_compressor) as t_res, \
+                    CallLog(ora.Mask if is_flex else ora.masknet) as t_mask:
+                hat, bits = oracle_frame()
+                table_s = get_scale_table()
+                mask_ref = t_mask.outputs[-1]
+                tr = {"mv": t_mv.latents(table_s), "res": t_res.latents(table_s),
+                      "mask": torch.sigmoid(mask_ref) if is_flex else mask_ref}     # b_model.py:66 applies the sigmoid outside
+            return hat, bits, tr
+
         with torch.no_grad():
-            # 1 warm-up + 3 timed calls, median; at 8 threads (comparable with BASELINE.md section 2) and at all physical cores
-            for threads in sorted({min(8, physical_cores()), physical_cores()}):
+            # bounded sample: 1 warm-up (the traced call) + 2 timed calls at 8 threads (comparable with BASELINE.md section 2);
+            # --cpu-all-cores adds the all-physical-cores setting of rounds 2-4 (always the slower one on the 128-core hosts)
+            settings = [min(8, physical_cores())]
+            if args.cpu_all_cores and physical_cores() not in settings:
+                settings.append(physical_cores())
+            for threads in settings:
                 torch.set_num_threads(threads)
                 t1 = time.perf_counter()
-                oracle_frame()
+                if traces is None:
+                    ref_hat, ref_bits, traces = traced_oracle_frame()
+                else:
+                    oracle_frame()
                 warm = time.perf_counter() - t1
-                # (bounded sample: a setting whose warm-up call is already 1.5x slower than the best median so far gets
-                #  one timed call instead of three -- oversubscribed hosts would otherwise double the bench's run time)
-                best_so_far = min((r["median_s_per_frame"] for r in runs.values()), default=None)
-                reps = 1 if (best_so_far is not None and warm > 1.5 * best_so_far) else 3
                 times = []
-                for _ in range(reps):
+                for _ in range(2):
                     t1 = time.perf_counter()
                     ref_hat, ref_bits = oracle_frame()
                     times.append(time.perf_counter() - t1)
                 runs[threads] = {"threads": threads, "median_s_per_frame": statistics.median(times), "times_s": times,
                                  "warmup_s": warm}
-            # one more (untimed) call with the latent capture hooked in, for the integer parity figures below
             torch.set_num_threads(min(runs.values(), key=lambda r: r["median_s_per_frame"])["threads"])
-            if not is_icip:
-                mv_name = "flow_compressor" if is_flex else "mv_compressor"
-                with CodecTrace(getattr(ora, mv_name)) as t_mv, CodecTrace(ora.residual_compressor) as t_res, \
-                        CallLog(ora.Mask if is_flex else ora.masknet) as t_mask:
-                    ref_hat, ref_bits = oracle_frame()
-                    table_s = get_scale_table()
-                    mask_ref = t_mask.outputs[-1]
-                    traces = {"mv": t_mv.latents(table_s), "res": t_res.latents(table_s),
-                              "mask": torch.sigmoid(mask_ref) if is_flex else mask_ref}     # b_model.py:66 applies the sigmoid outside
         best = min(runs.values(), key=lambda r: r["median_s_per_frame"])
         result["cpu_baseline"] = {"value": 1.0 / best["median_s_per_frame"], "unit": "frames/s", "cores": best["threads"],
                                   "kind": "port",
                                   "sample": "1 B-frame 1088x1920 (middle frame of the same GOP) through the PyTorch-CPU fp32 oracle "
-                                            "(tensor-equal to the reference); 1 warm-up + 3 timed calls, median, at 8 threads and "
-                                            "at all physical cores (1 timed call where the warm-up was already 1.5x slower) -- "
-                                            "value = the faster setting",
+                                            "(tensor-equal to the reference); 1 warm-up + 2 timed calls at 8 threads, their mean "
+                                            "(--cpu-all-cores adds the all-cores setting: slower on every box so far)",
                                   "runs": list(runs.values()), "host_physical_cores": physical_cores()}
         def parity_block(gpu_hat, gpu_bits, trace, ref_hat, ref_bits, traces):
             src = frames[mid]
@@ -873,7 +891,7 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                 "psnr_db": float(vgop.psnr_uint8(ref_hat.to(dev), frames[mid], H, W)), "bpp_estimated": float(ref_bits) / (H * W),
                 "residual_symbols_nonzero": float((traces["res"]["y_sym"] != 0).float().mean()),
                 "what": "middle frame of the GOP (references 4 / 8 frames away: the hardest level), CPU oracle's figures"}
-        if not is_flex and not is_icip and not f16 and args.checkpoint == "calibrated":
+        if not is_flex and not is_icip and not f16 and args.checkpoint == "calibrated" and args.byte_equality:
             # ---- byte-equality statistics: eight frame triples of the bench clip through encode_B on both sides (the CPU
             # oracle's eight passes side by side: oracle.pool), the bits_B containers compared byte for byte ----
             from oracle import pool
@@ -905,7 +923,7 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                                                "carries no indexes: the CompressAI format's known cross-platform fragility); "
                                                "tests/test_byte_equality_gpu.py shows every differing integer to be such a boundary case and "
                                                ">= 6 of 8 containers identical at 192x256"}
-        if not is_flex and not is_icip:
+        if not is_flex and not is_icip and args.parity_both_checkpoints:
             # ---- the same frame on the OTHER checkpoint kind (plain seeded weights when the timed region ran the calibrated
             # ones: latents in the hundreds, 6 dB -- the integer parity has to hold there too) ----
             from vcamd import lhbdc as vlhbdc

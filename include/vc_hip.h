@@ -45,6 +45,11 @@ typedef struct {
  * Library info
  * ---------------------------------------------------------------------------------------- */
 const char *vc_version(void);
+/* ABI number of this header: bumped whenever a struct below changes size or layout (vc_conv_desc grew trailing fields in
+ * rounds 4 and 5).  A caller compiled against another number must not call the library (the Python binding checks it on
+ * load); descriptors must be zero-initialised (memset) so that fields a caller does not know stay NULL / 0. */
+#define VC_ABI_VERSION 5
+int vc_abi_version(void);
 /* Name of the code-object target compiled in ("gfx950"). */
 const char *vc_target_arch(void);
 

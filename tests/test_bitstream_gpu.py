@@ -135,6 +135,11 @@ def test_lhbdc_hip_decoder_reads_the_reference_container(dev, lhbdc_model):
     #  rounding boundary lands on the other grey level; measured 0.9-1.3e-4 of the pixels depending on the kernels' loop order)
     diff = u8.astype(np.int16) - fx["decoded_u8"].astype(np.int16)
     assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 4e-4
+    # the count alone could hide a wiring error -- every differing grey level must BE such a boundary case: the
+    # reference's own float value within 255 * max|d| of a half-integer grey level
+    v = np.clip(fx["decoded"][0].transpose(1, 2, 0)[:h, :w], 0.0, 1.0).astype(np.float64) * 255.0
+    dist = np.abs((v - np.floor(v)) - 0.5)[diff != 0]
+    assert dist.size == 0 or dist.max() <= 255.0 * err + 1e-6, (dist.max(), err)
 
 
 def test_flex_hip_decoder_reads_the_reference_strings(dev, flex_model):
@@ -212,7 +217,9 @@ def test_flex_encode_B_integers_against_the_reference(dev, flex_model):
     for k in ("flow", "res"):
         report[k] = {name: n_diff(trace[k][name], lat[f"{k}_{name}"]) for name in ("y_sym", "y_idx", "z_sym")}
         totals[k] = {name: lat[f"{k}_{name}"].size for name in report[k]}
-    print("Flex encode_B integers differing from the reference's:", report, "of", totals)
+    from vcamd import hip
+    res_input_moved = float((hip.nhwc_to_nchw(trace["resid"]).cpu() - torch.from_numpy(lat["res_x"])).abs().max())
+    print("Flex encode_B integers differing from the reference's:", report, "of", totals, f"; residual codec input max|d| {res_input_moved:.2e}")
     for k in ("flow", "res"):
         d, total = report[k], totals[k]
         # (cascades behind a flipped upstream symbol / hyper-latent: see the LHBDC twin.  Flex-Rate's residual codec sits behind an
@@ -224,9 +231,12 @@ def test_flex_encode_B_integers_against_the_reference(dev, flex_model):
         #  the indexes).  The flow codec is held to the first-order bound; the residual codec's first-order behaviour is pinned where
         #  nothing amplifies: the reference's own latents (test_flex_reference_latents_give_the_reference_strings) and the
         #  calibrated checkpoint at 1088x1920 against the reference itself (test_reference_1080p_gpu.py: <= 2 per tensor).)
+        #  the looser bound applies only when the amplification is OBSERVED in this run -- the residual codec's input
+        #  (trace["resid"]) against the reference's (lat["res_x"]): behind an input that moved by more than 1e-3 the residual
+        #  integers are a cascade; otherwise they are held to the first-order bound like everything else.
         for name in ("z_sym", "y_sym", "y_idx"):
-            cascade = k == "res" or (name != "z_sym" and d["z_sym"] > 0)
-            assert d[name] <= max(1, total[name] // (12 if cascade else 1000)), (k, name, d[name], total[name])
+            cascade = (k == "res" and (res_input_moved > 1e-3 or any(report["flow"].values()))) or (name != "z_sym" and d["z_sym"] > 0)
+            assert d[name] <= max(1, total[name] // (12 if cascade else 1000)), (k, name, d[name], total[name], res_input_moved)
         if d["z_sym"] == 0:
             assert strings[f"{k}_z"] == fx[f"{k}_z"].tobytes(), k
         if d["y_sym"] == 0 and d["y_idx"] == 0:

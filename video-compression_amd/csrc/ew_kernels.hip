@@ -580,8 +580,9 @@ extern "C" int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, v
 {
     if (!img.p || !flow.p || !out.p) return VC_EINVAL;
     if (convention != VC_WARP_W1 && convention != VC_WARP_W2 && convention != VC_WARP_W3) return VC_EINVAL;
-    if (flow.c < 2 || out.c > img.c || out.h != flow.h || out.w != flow.w || img.n != out.n || flow.n != out.n) return VC_EINVAL;
+    if (flow.c < 2 || out.c < 1 || out.c > img.c || out.h != flow.h || out.w != flow.w || img.n != out.n || flow.n != out.n) return VC_EINVAL;
     const long long total = (long long)out.n * out.h * out.w * out.c;
+    if (total <= 0) return VC_OK;            // (an empty tensor: nothing to launch)
     if (out.c % 4 == 0 && view_vec4(img) && view_vec4(out))
         hipLaunchKernelGGL(k_warp_v4, dim3(ew_grid(total / 4, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);
     else if (out.c <= 4)

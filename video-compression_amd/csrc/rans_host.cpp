@@ -242,5 +242,8 @@ extern "C" int vc_pmf_to_quantized_cdf(const float *pmf, int n, int precision, u
     return VC_OK;
 }
 
-extern "C" const char *vc_version(void) { return "vc_hip 0.2 (round 2)"; }
+// ABI number: bumped whenever a struct of include/vc_hip.h changes size or layout (vc_conv_desc grew in rounds 4 and 5); the Python
+// binding refuses a library whose number differs from the header it was written against
+extern "C" int vc_abi_version(void) { return VC_ABI_VERSION; }
+extern "C" const char *vc_version(void) { return "vc_hip 0.5 (abi 5)"; }
 extern "C" const char *vc_target_arch(void) { return "gfx950"; }

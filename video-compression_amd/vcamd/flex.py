@@ -315,7 +315,7 @@ def encode_B(model, x_before, x_current, x_after, n=None, l=1.0, train=False, tr
     _, resid = model._compensate_t(buf, flow_hat, cur=buf.channels(16, 19))
     strings, shape = rc.compress_t(resid, rc.gains([n], l), code_ungained_y=True, trace=t_res)
     if trace is not None:
-        trace.update({"flow": t_mv, "res": t_res})
+        trace.update({"flow": t_mv, "res": t_res, "resid": resid})
     return mv_bits, {"strings": strings, "shape": torch.Size(shape)}
 
 

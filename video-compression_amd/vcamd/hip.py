@@ -14,6 +14,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_PKG_DIR, "libvc_hip.so")
 
 VC_OK = 0
+ABI_VERSION = 5          # VC_ABI_VERSION of include/vc_hip.h (struct layouts below)
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_CLAMP01 = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GDN, EPI_IGDN = 0, 1, 2
 IN_NONE, IN_SQUARE = 0, 1
@@ -113,6 +114,10 @@ def lib():
         f.argtypes = list(args)
 
     sig("vc_version", ctypes.c_char_p)
+    sig("vc_abi_version", ci)
+    if L.vc_abi_version() != ABI_VERSION:
+        raise VcError(f"{LIB_PATH} has ABI {L.vc_abi_version()}, this binding was written against {ABI_VERSION} (include/vc_hip.h: "
+                      "VC_ABI_VERSION): rebuild with `make -C video-compression_amd/csrc`")
     sig("vc_target_arch", ctypes.c_char_p)
     sig("vc_conv_select_cfg", ci, ci, ci, ci, ci)
     sig("vc_conv_chunk", ci, ci, ci, ci, ci)
@@ -168,7 +173,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = [
-    "vc_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
+    "vc_version", "vc_abi_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
     "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
     "vc_conv_pack_weights_f16", "vc_conv_pack_tail_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
@@ -522,8 +527,18 @@ class PackedConv:
         else:
             d.cfg = self._pick_cfg(d, key, flags | pack) | pack
         what = f"vc_conv2d_nhwc(k={self.k},s={self.stride},{self.cin}->{self.cout}{'+1x1 tail' if tail is not None else ''})"
+
+        def launch_once():
+            # A tuned choice is keyed by shape and flags, not by the alignment class of the views: a later call of the same shape
+            # on a sliced / unaligned view may be refused by a configuration that needs 16-byte accesses (LDS-DMA, streaming 1x1).
+            # The general configuration of this packing takes any view: retry on it instead of failing the layer.
+            rc = lib().vc_conv2d_nhwc(stream(), ctypes.byref(d))
+            if rc == -1 and tail is None and (d.cfg & 0xff) != self.cfg:
+                d.cfg = self.cfg | (d.cfg & ~0x1ff)
+                rc = lib().vc_conv2d_nhwc(stream(), ctypes.byref(d))
+            return rc
         if timer is None:
-            check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
+            check(launch_once(), what)
         else:
             hq, wq = (ho // 2, wo // 2) if self.ps else (ho, wo)
             flops = 2.0 * x.n * hq * wq * self.cout * (self.cin * self.k * self.k + (tail.cin if tail is not None else 0))
@@ -531,7 +546,7 @@ class PackedConv:
             nbytes = (x.n * x.h * x.w * self.cin * (2 if half_in else 4) + x.n * ho * wo * co * (2 if half_out else 4)
                       + self.cout * self.cin * self.k * self.k * (2 if use16 else 4)
                       + (x.n * ho * wo * co * (2 if res_half else 4) if res is not None else 0) + (x.n * ho * wo * co * 4 if mul is not None else 0))
-            timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
+            timer.bracket(key, flops, lambda: check(launch_once(), what), nbytes)
         return out
 
 

@@ -70,7 +70,11 @@ class ResidualBottleneckBlock(_Prepared):
         if t.dtype == "f16" and c2.can_fuse_tail(c3) and (x.dtype == "f32" or self.half_stream_ok()):
             # fp16 path, 128 channels: the trailing 1x1 + identity in the 3x3 layer's epilogue (hip.FUSE_TAIL) -- the 3x3
             # layer's output (rounded to half exactly as it would be stored) never leaves the CU
-            return c2(t, act=hip.ACT_RELU, tail=c3, res=x, out=out, out_f16=bool(out_f16 and out is None and self.half_stream_ok()))
+            try:
+                return c2(t, act=hip.ACT_RELU, tail=c3, res=x, out=out, out_f16=bool(out_f16 and out is None and self.half_stream_ok()))
+            except hip.VcError as e:           # (views the fused launch cannot take -- unaligned slices: the two launches below can)
+                if "VC_EINVAL" not in str(e):
+                    raise
         t = c2(t, act=hip.ACT_RELU, out_f16=c3.half_ok)        # half-precision storage on the fp16 path
         return c3(t, res=x, out=out, out_f16=bool(out_f16 and out is None and self.half_stream_ok()))
 
