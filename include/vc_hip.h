@@ -84,7 +84,14 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
                         global_load_lds in whole 128-byte lines with counted vmcnt waits (no barriers), the residual
                         requested a tile ahead; cin 32/64/96/128, cout <= 128, plain/ReLU/LeakyReLU epilogue (+ gain,
                         residual), fp32 and both fp16-path input types; reads the packed weights of N128/N64/N32 and
-                        gives bit-identical results */ };
+                        gives bit-identical results */,
+       VC_CFG_SPLIT = 10 /* fp32 layer on the bf16 matrix pipe with SPLIT operands (csrc/conv_split.h): every fp32 operand is the
+                        exact sum of three bf16 pieces, all nine piece products (each exact in fp32) are accumulated in fp32 by
+                        v_mfma_f32_16x16x32_bf16 -- 9/16 of the native fp32 matrix time; same precision class as the native
+                        instances (errors against fp64 measured no larger), NOT bit-identical to them (summation order).
+                        5x5 / 7x7 stride 1, cin a multiple of 8, cout a multiple of 32, plain / ReLU / LeakyReLU epilogue
+                        (+ gain, residual); `in` must be a split tensor (VC_CFG_IN_SP3), `wpk` from
+                        vc_conv_pack_weights_split */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
  * same packed weights and produces bit-identical results); without it the library narrows the block for
  * small feature maps by itself. */
@@ -114,6 +121,12 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
  * above 64 that are no multiple of 128 (the kernel reads whole blocks); without it such a call returns VC_EINVAL instead of
  * reading past a narrower packing. */
 #define VC_CFG_PACK128 0x4000
+/* With VC_CFG_SPLIT: `in` (VC_CFG_IN_SP3, required) / `out` (VC_CFG_OUT_SP3, optional) are SPLIT tensors: dense
+ * [n][c/8][h][w][3 pieces][8 channels] bf16 -- per pixel and group of 8 channels one 48-byte record hi | mid | lo with
+ * hi + mid + lo == the fp32 value exactly.  The view's p is the buffer, n/h/w/c the logical shape, strides are ignored.
+ * Produced by vc_split3 or by the VC_CFG_OUT_SP3 epilogue of the layer in front (a chain of split layers never converts). */
+#define VC_CFG_IN_SP3 0x8000
+#define VC_CFG_OUT_SP3 0x10000
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */
     vc_view out;           /* [n,ho,wo,cout]  (PIXELSHUFFLE2: [n,2ho,2wo,cout/4]) */
@@ -154,6 +167,12 @@ size_t vc_conv_packed_weight_bytes_f16(int cfg, int cout, int cin, int kh, int k
 int vc_conv_pack_tail_f16(const float *w, const float *bias, int cout, int cin, void *wpk_half_out, float *bias_out);
 int vc_conv_pack_weights_f16(const float *w_oihw, const float *bias, int cout, int cin, int kh, int kw,
                              int stride, int cfg, int pixelshuffle, void *wpk_half_out, float *bias_out);
+/* Split-operand path: packed weights = bf16 piece fragments [n-block][chunk of 8 channels][tap unit][piece][n-tile][lane][8]
+ * (bytes incl. the slack the last DMA round may over-read; 0 = shape not served); bias_out: cout floats. */
+size_t vc_conv_packed_weight_bytes_split(int cout, int cin, int k);
+int vc_conv_pack_weights_split(const float *w_oihw, const float *bias, int cout, int cin, int k, void *wpk_out, float *bias_out);
+/* fp32 channels-last window (c % 8 == 0, 16-byte aligned rows) -> dense split tensor, 6 bytes per element */
+int vc_split3(vc_stream s, vc_view in, void *out_split);
 int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d);
 
 /* ------------------------------------------------------------------------------------------

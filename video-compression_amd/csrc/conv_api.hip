@@ -36,6 +36,7 @@ extern "C" int vc_conv_select_cfg(int cout, int cin, int k, int stride)
 
 extern "C" int vc_conv_chunk(int cfg, int k, int stride, int cin)
 {
+    if (cfg == VC_CFG_SPLIT) return (stride == 1 && (k == 5 || k == 7)) ? 8 : -1;   // 8-channel chunks of a split tensor
     if (cfg == VC_CFG_N4) {   // 64-pixel-wide tiles: smaller channel chunks keep the footprint in LDS
         if (stride != 1) return -1;
         return k == 3 ? 16 : ((k == 5 || k == 7) ? 8 : -1);
@@ -214,6 +215,9 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.pack128 = (d->cfg & VC_CFG_PACK128) ? 1 : 0;
     a.tail_wpk = d->tail_wpk;
     a.tail_bias = d->tail_bias;
+    a.in_sp3 = (d->cfg & VC_CFG_IN_SP3) ? 1 : 0;
+    a.out_sp3 = (d->cfg & VC_CFG_OUT_SP3) ? 1 : 0;
+    if ((a.in_sp3 || a.out_sp3) && (d->cfg & 0xff) != VC_CFG_SPLIT) return VC_EINVAL;       // split tensors are private to the split path
     if (a.tail_wpk && (!f16 || (d->cfg & 0xff) != VC_CFG_DMA)) return VC_EINVAL;             // the fused tail lives in the LDS-DMA kernel
     // a half-precision residual: the streaming 1x1 kernel, or the LDS-DMA kernel's fused-tail epilogue
     if (a.res_f16 && (!f16 || !d->res || !((d->cfg & 0xff) == VC_CFG_PWS || ((d->cfg & 0xff) == VC_CFG_DMA && a.tail_wpk)))) return VC_EINVAL;
@@ -267,6 +271,8 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
         if (!conv_pws_eligible(a, k, st, f16)) return VC_EINVAL;
         return conv_dispatch_pws(stream, a, f16);
     }
+    if (cfg == VC_CFG_SPLIT)                // split-operand fp32 pipeline: only ever chosen explicitly (its own packing and input format)
+        return conv_dispatch_split(stream, a, k, st);
     if (cfg == VC_CFG_DMA)                  // LDS-DMA pipeline (fp16 path; fp32: the two big 7x7 layers): only ever chosen explicitly (autotuner)
         return conv_dispatch_dma(stream, a, k, st, f16);
     switch (k) {

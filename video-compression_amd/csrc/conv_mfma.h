@@ -88,6 +88,7 @@ struct ConvArgs {
     int pack128;           // VC_CFG_PACK128: weights and bias are padded to whole blocks of 128 output channels
     const void *tail_wpk;  // VC_CFG_DMA only: fused trailing 1x1 layer (vc_conv_pack_tail_f16), NULL = none
     const float *tail_bias;
+    int in_sp3, out_sp3;   // VC_CFG_SPLIT only: `in` / `out` are split tensors ([n][c/8][h][w][3][8] bf16, conv_split.h)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -905,6 +906,8 @@ int conv_dispatch_pws(hipStream_t st, const ConvArgs &a, bool f16);
 int conv_dispatch_pw(hipStream_t st, const ConvArgs &a, bool f16);
 // fp16-path LDS-DMA pipeline (conv_dma.hip): same packed weights again; sets the tile geometry of `a` itself
 int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride, bool f16);
+// split-operand fp32 pipeline (conv_split.hip): its own packed weights (vc_conv_pack_weights_split), split input tensor
+int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride);
 VC_DECLARE_DISPATCH(k1)
 VC_DECLARE_DISPATCH(k3)
 VC_DECLARE_DISPATCH(k5)

@@ -1,0 +1,384 @@
+// fp32 convolution on the bf16 matrix pipe with SPLIT operands (VC_CFG_SPLIT; stride 1, K x K with K = 5 or 7).
+//
+// Why: the native fp32 MFMA runs at 1/16 of the bf16 rate and the headline path sits at 0.90 of it.  An fp32 value is the
+// exact sum of three bf16 pieces (hi + mid + lo, 8 + 8 + 8 significand bits, by truncation: every remainder is exact), the
+// product of two pieces is exact in fp32 (16 significand bits), so
+//     a * b = sum over the nine piece pairs (exact),  accumulated by the MFMA's own fp32 accumulate
+// -- nine v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) instead of sixteen v_mfma_f32_16x16x4_f32-equivalents: 9/16 of the
+// matrix time before the clock (tools/micro/mfma_split.hip: 1.39x the native k-step with its LDS operand traffic, error against
+// fp64 no worse than the native chain's; the 16 x 16 shape holds a ~15 % higher clock than 32 x 32 x 16 under this load).
+//
+// Data: the INPUT is a "split" tensor (vc_split3, or the split epilogue of the producing layer): [n][C/8][H][W][3 pieces][8
+// channels] bf16 -- per pixel and group of 8 channels ONE 48-byte record hi | mid | lo.  A channel chunk (8 channels) of a tile's
+// footprint is then a set of contiguous rows; it reaches LDS by global_load_lds_dwordx4 exactly as it lies (one 16-byte slot
+// per (pixel, piece)), borders from a zero page.  The WEIGHTS are split at pack time (vc_conv_pack_weights_split).
+//
+// Contraction: K of an MFMA = 32 = 4 taps x 8 channels.  The K x K taps of a chunk are walked as UNITS of four taps: 2 x 2
+// blocks over the taps with ky, kx < K - 1, vertical runs down the last column, horizontal runs along the last row (7 x 7: 9 +
+// 2 + 2 = 13 units for 49 taps, 6 % padding; padded k-groups carry zero weights and re-read the unit's last valid tap, never
+// stale LDS).  Lane (pixel l & 15, k-group l >> 4) reads its 16 bytes at (pixel + tap offset of its k-group, piece): the tap
+// offset is a per-lane constant per unit class, everything else an immediate.
+//
+// Pipeline: the LDS-DMA pipeline of conv_dma.h -- one persistent 512-thread workgroup per CU over a tile list in the banded
+// order, a phase = one unit {fragment reads, DMA issue, counted vmcnt wait, barrier, 9 x WM x WN MFMAs, barrier}, the two waves
+// of a SIMD half a phase apart, chunk images double-buffered, weights through a ring of RING slots fetched RING - 2 units
+// ahead -- with the CHUNK loop rolled (13 phases of code; the channel count is a launch parameter).
+// Accumulation order per output: (chunk, unit, product pair from lo x lo up to hi x hi); NOT the order of the native instances:
+// results differ from them by fp32 summation noise (like the native instances differ from the CPU reference), tested against
+// an fp64 reference beside them.
+#pragma once
+#include "conv_dma.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- the tap units of a K x K kernel (shared by the host packer and the kernel) ----
+template <int K> struct SplitUnits {
+    static constexpr int Q = (K / 2) * (K / 2);          // 2 x 2 blocks over ky, kx < K - 1
+    static constexpr int V = (K + 3) / 4;                // runs of <= 4 down the column kx = K - 1 (K taps)
+    static constexpr int H = (K - 1 + 3) / 4;            // runs of <= 4 along the row ky = K - 1, kx < K - 1 (K - 1 taps)
+    static constexpr int U = Q + V + H;
+    // type: 0 block, 1 vertical run, 2 horizontal run
+    static constexpr int type(int u) { return u < Q ? 0 : (u < Q + V ? 1 : 2); }
+    static constexpr int ky0(int u) { return u < Q ? 2 * (u / (K / 2)) : (u < Q + V ? 4 * (u - Q) : K - 1); }
+    static constexpr int kx0(int u) { return u < Q ? 2 * (u % (K / 2)) : (u < Q + V ? K - 1 : 4 * (u - Q - V)); }
+    static constexpr int nvalid(int u)
+    {
+        return u < Q ? 4 : (u < Q + V ? (K - 4 * (u - Q) < 4 ? K - 4 * (u - Q) : 4) : (K - 1 - 4 * (u - Q - V) < 4 ? K - 1 - 4 * (u - Q - V) : 4));
+    }
+    // tap of k-group q of unit u (q >= nvalid: padding, zero weight; the ADDRESS of a padded group is its unit's last valid tap)
+    static constexpr int ky(int u, int q)
+    {
+        const int qq = q < nvalid(u) ? q : nvalid(u) - 1;
+        return type(u) == 0 ? ky0(u) + (qq >> 1) : (type(u) == 1 ? ky0(u) + qq : ky0(u));
+    }
+    static constexpr int kx(int u, int q)
+    {
+        const int qq = q < nvalid(u) ? q : nvalid(u) - 1;
+        return type(u) == 0 ? kx0(u) + (qq & 1) : (type(u) == 1 ? kx0(u) : kx0(u) + qq);
+    }
+    static constexpr bool valid(int u, int q) { return q < nvalid(u); }
+    // per-lane offset class of a unit: lanes of k-group q add (dy(cls, q) * COLS + dx(cls, q)) pixels
+    static constexpr int cls(int u) { return type(u) * 4 + nvalid(u) - 1; }
+    static constexpr int NCLS = 12;
+    static constexpr int dy(int c, int q)
+    {
+        const int t = c / 4, nv = c % 4 + 1, qq = q < nv ? q : nv - 1;
+        return t == 0 ? (qq >> 1) : (t == 1 ? qq : 0);
+    }
+    static constexpr int dx(int c, int q)
+    {
+        const int t = c / 4, nv = c % 4 + 1, qq = q < nv ? q : nv - 1;
+        return t == 0 ? (qq & 1) : (t == 1 ? 0 : qq);
+    }
+    static constexpr bool covers_all()
+    {
+        int seen[K * K] = {};
+        for (int u = 0; u < U; ++u)
+            for (int q = 0; q < 4; ++q)
+                if (valid(u, q)) ++seen[ky(u, q) * K + kx(u, q)];
+        for (int i = 0; i < K * K; ++i)
+            if (seen[i] != 1) return false;
+        return true;
+    }
+    static_assert(covers_all(), "every tap in exactly one unit");
+};
+
+// NTW: N-tiles of 16 output channels per workgroup (2 or 4: blocks of 32 / 64 channels)
+template <int K_, int NTW_, int RING_ = 4, int KO_ = 0> struct SplitCfg {
+    typedef SplitUnits<K_> UN;
+    static constexpr int K = K_, NTW = NTW_, RING = RING_, KO = KO_, U = UN::U, PAD = K_ / 2;
+    static constexpr int TH = 16, TW = 32, BN = 16 * NTW_;
+    static constexpr int WAVES = 8, WM = 4, WN = NTW_;           // wave w: output rows 2 w, 2 w + 1; M-tile t: row t >> 1, columns 16 (t & 1) ..
+    static constexpr int ROWS_IN = TH + K_ - 1, COLS = TW + K_ - 1, PIX = ROWS_IN * COLS;
+    static constexpr int PXB = 48;                               // bytes per pixel of a chunk image: 3 pieces x 8 channels x 2
+    static constexpr int NA = (PIX * 3 + 511) / 512;             // DMA instructions per wave and chunk image
+    static constexpr int A_BYTES = NA * 8192;
+    static constexpr int FRAGS = 3 * NTW_;                       // weight fragments (1 KiB) per unit: [piece][n-tile]
+    static constexpr int NB = (FRAGS + 7) / 8;                   // DMA instructions per wave and unit (the tail of the last round over-reads into the next unit)
+    static constexpr int SLOTB = NB * 8192;
+    static constexpr int B_OFF = 2 * A_BYTES, BIAS_OFF = B_OFF + RING_ * SLOTB;
+    static constexpr int LDS_FIXED = BIAS_OFF;                   // + 4 * Cout at launch
+    static constexpr int D = RING_ - 2;                          // weights are requested D units ahead
+    // pieces of the NEXT chunk image: PPP per phase from phase 1 on; they must all be older than the weight request of phase U - D
+    static constexpr int WIN = U - D - 1, PPP = (NA + WIN - 1) / WIN;
+    static constexpr int piece_phase(int k) { return 1 + k / PPP; }
+    static constexpr int nA(int u)
+    {
+        int n = 0;
+        for (int k = 0; k < NA; ++k) n += piece_phase(k) == u;
+        return n;
+    }
+    // vmcnt of phase u: the weights of unit u + 1 were the LAST requests of phase u + 1 - D; younger: everything of the phases after it
+    static constexpr int nwait(int u)
+    {
+        int n = 0;
+        for (int j = u + 2 - D; j <= u; ++j) n += nA(((j % U) + U) % U) + NB;
+        return n;
+    }
+    static_assert(D >= 1 && nwait(U - 1) <= 63, "vmcnt is a 6-bit counter");
+};
+
+// bf16 pieces of an fp32 value by truncation: hi = top 16 bits, the remainder x - hi is exact, and so on; lo is exact (<= 8 bits left)
+__device__ __forceinline__ void vc_split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    const unsigned ux = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, ux);
+    const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, um);
+    h = ux;
+    m = um;
+    l = __builtin_bit_cast(unsigned, r2);
+}
+
+template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(const ConvArgs p)
+{
+    typedef typename C::UN UN;
+    constexpr int U = C::U, WM = C::WM, WN = C::WN, NA = C::NA, NB = C::NB, RING = C::RING, D = C::D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];   // the kernel's only LDS object: starts at LDS address 0
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int px = lane & 15, q = lane >> 4;
+
+    // ---- persistent tile list (as conv_dma_kernel): the 32 workgroups of an XCD walk one contiguous range of the banded order ----
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int total = per_img * p.N * p.nblks;
+    const int xcd = blockIdx.x & 7, xl = blockIdx.x >> 3;
+    const int tq = total >> 3, tr = total & 7;
+    const int x_start = xcd * tq + min(xcd, tr), x_count = tq + (xcd < tr ? 1 : 0);
+    auto tile_at = [&](int it) {
+        DmaTile t;
+        const int k = it * 32 + xl;
+        t.valid = k < x_count;
+        const int idx = x_start + (t.valid ? k : 0);
+        t.nblk = idx % p.nblks;
+        const int t1 = idx / p.nblks;
+        t.img = t1 / per_img;
+        int tx, ty;
+        vc_tile_xy(t1 - t.img * per_img, p.tiles_x, p.tiles_y, p.tile_band, tx, ty);
+        t.oy0 = ty * C::TH;
+        t.ox0 = tx * C::TW;
+        return t;
+    };
+    DmaTile cur = tile_at(0);
+    if (!cur.valid) return;
+
+    const int nchunk = p.Cin >> 3;                                // 8-channel chunks (runtime: the chunk loop is rolled)
+    const int upt = nchunk * U;                                   // units per tile
+    const unsigned char *const in_b = reinterpret_cast<const unsigned char *>(p.in);
+    const unsigned char *const wpk = reinterpret_cast<const unsigned char *>(p.wpk);
+    const long long plane = (long long)p.H * p.W * C::PXB;        // bytes of one 8-channel plane of one image
+    const unsigned char *const zero_lane = g_vc_dma_zero + 16 * lane;
+
+    // ---- A pieces: lane (k, tid) fills slot s = 512 k + tid = 3 * pixel + piece of the chunk image, from the same position of the plane ----
+    int a_off[NA], a_rc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int s = k * 512 + tid;
+        const int pix = s / 3, piece = s - 3 * pix;
+        const int row = pix / C::COLS, col = pix - row * C::COLS;
+        a_off[k] = (row * p.W + col) * C::PXB + piece * 16;
+        a_rc[k] = pix < C::PIX ? (row | (col << 8)) : 0x7f7f7f;
+    }
+    auto tile_base = [&](const DmaTile &t) {       // chunk 0's plane at the footprint's first pixel (may lie outside the tensor)
+        return in_b + (long long)t.img * nchunk * plane + ((long long)(t.oy0 - C::PAD) * p.W + (t.ox0 - C::PAD)) * C::PXB;
+    };
+    auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {
+        int rc = a_rc[k], off = a_off[k];
+        asm volatile("" : "+v"(rc), "+v"(off));
+        const unsigned iy = (unsigned)(t.oy0 - C::PAD + (rc & 0xff)), ix = (unsigned)(t.ox0 - C::PAD + (rc >> 8));
+        const bool ok = t.valid && iy < (unsigned)p.H && ix < (unsigned)p.W;
+        const unsigned char *sp = ok ? tbase + (c * plane + off) : zero_lane;
+        if constexpr (!(C::KO & 16)) vc_glds16<true>(sp, (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
+    };
+    // weights of tile-unit g (>= upt: of the next tile): NB rounds of one KiB per wave, [nblk][chunk][unit][piece][n-tile] order;
+    // ring slot = (ring position of the tile's first unit + g) mod RING
+    const unsigned lane16 = 16 * lane;
+    unsigned gbase = 0;
+    auto issue_b = [&](int g, int nblk_cur, int nblk_next) {
+        const int gg = g >= upt ? g - upt : g;
+        const int nblk = g >= upt ? nblk_next : nblk_cur;
+        const unsigned char *sbase = wpk + ((long long)nblk * upt + gg) * (C::FRAGS * 1024) + wave * 1024;
+        const unsigned dst = C::B_OFF + ((gbase + (unsigned)g) % RING) * C::SLOTB + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+            if constexpr (!(C::KO & 16)) vc_glds16_sbase(sbase + r * 8192, lane16, dst + r * 8192);
+    };
+
+    // ---- prologue: bias, first chunk image, weights of the first D units ----
+    float *const ldsf = reinterpret_cast<float *>(lds8);
+    for (int i = tid; i < p.nblks * C::BN; i += 512) ldsf[C::BIAS_OFF / 4 + i] = p.bias[i];
+    DmaTile nxt = tile_at(1);
+    const unsigned char *cur_base = tile_base(cur), *nxt_base = tile_base(nxt);
+#pragma unroll
+    for (int k = 0; k < NA; ++k) issue_a(cur, cur_base, 0, k, 0);
+#pragma unroll
+    for (int g = 0; g < D; ++g) issue_b(g, cur.nblk, cur.nblk);
+    vc_wait_vmcnt<0>();
+    __syncthreads();
+
+    // ---- per-lane LDS read offsets: pixel (2 wave, px) + the k-group's tap offset of each unit class ----
+    int a_lane[UN::NCLS];
+#pragma unroll
+    for (int c = 0; c < UN::NCLS; ++c) {
+        int dy = 0, dx = 0;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+            if (q == qq) {
+                dy = UN::dy(c, qq);
+                dx = UN::dx(c, qq);
+            }
+        a_lane[c] = ((2 * wave + dy) * C::COLS + px + dx) * C::PXB;
+    }
+    const int b_lane = C::B_OFF + lane * 16;
+
+    f32x4 acc[WM][WN];
+    f32x4 af[3][WM], bf[3][WN];
+    int gchunk = 0;                                  // chunks contracted so far: parity = buffer of the current chunk
+    for (int it = 0;; ++it) {
+        // ---- accumulators start at the bias: lane (pixel, channel quad cq = q) owns channels 16 n + 4 q .. + 3 ----
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(&ldsf[C::BIAS_OFF / 4 + cur.nblk * C::BN + 16 * n + 4 * q]);
+#pragma unroll
+            for (int t = 0; t < WM; ++t) acc[t][n] = b;
+        }
+        if (grp == 1) VC_DMA_BARRIER();              // waves 4-7 run half a phase behind waves 0-3
+#pragma unroll 1
+        for (int c = 0; c < nchunk; ++c) {
+            const int abuf = ((gchunk + c) & 1) * C::A_BYTES, nbuf = ((gchunk + c + 1) & 1);
+            const bool last_chunk = c + 1 == nchunk;
+            const int g0 = c * U;                    // tile-unit index of this chunk's first unit
+            static_for<0, U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                constexpr int cl = UN::cls(u);
+                // -- R: this unit's fragments, LDS -> registers --
+                const int bslot = b_lane + (int)((gbase + (unsigned)(g0 + u)) % RING) * C::SLOTB;
+                const int ab = a_lane[cl] + abuf;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) bf[pc][n] = *reinterpret_cast<const f32x4 *>(lds8 + bslot + (pc * WN + n) * 1024);
+#pragma unroll
+                    for (int t = 0; t < WM; ++t)
+                        af[pc][t] = *reinterpret_cast<const f32x4 *>(lds8 + ab + (((t >> 1) + UN::ky0(u)) * C::COLS + 16 * (t & 1) + UN::kx0(u)) * C::PXB + 16 * pc);
+                }
+                // -- DMA of later phases: a piece of the next chunk image, then the weights of unit g + D --
+                static_for<0, NA>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (C::piece_phase(k) == u) {
+                        if (!last_chunk) issue_a(cur, cur_base, c + 1, k, nbuf);
+                        else issue_a(nxt, nxt_base, 0, k, nbuf);
+                    }
+                });
+                issue_b(g0 + u + D, cur.nblk, nxt.nblk);
+                // -- this wave's part of the next unit's weights (and everything older) has landed --
+                // (first phase of a tile: the previous tile's epilogue stores lie between; waiting for them too costs one store
+                //  drain per tile)
+                if constexpr (!(C::KO & 2)) vc_wait_vmcnt<C::nwait(u)>();
+                VC_DMA_BARRIER();
+                // -- M: 9 x WM x WN MFMAs while the other group reads; smallest products first --
+                if constexpr (!(C::KO & 4)) {
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int sum = 4; sum >= 0; --sum)
+#pragma unroll
+                        for (int pa = 2; pa >= 0; --pa) {
+                            const int pb = sum - pa;
+                            if (pb < 0 || pb > 2) continue;
+#pragma unroll
+                            for (int t = 0; t < WM; ++t)
+#pragma unroll
+                                for (int n = 0; n < WN; ++n)
+                                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[pb][n]),
+                                                                                        __builtin_bit_cast(bf16x8, af[pa][t]), acc[t][n], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_s_setprio(0);
+                } else {
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                        for (int t = 0; t < WM; ++t) VC_DMA_KEEP(af[pc][t]);
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) VC_DMA_KEEP(bf[pc][n]);
+                    }
+                }
+                VC_DMA_BARRIER();
+            });
+        }
+        if (grp == 0) VC_DMA_BARRIER();              // (waves 4-7 finish their last phase)
+        gchunk += nchunk;
+        gbase = (gbase + (unsigned)upt) % RING;
+
+        // ---- epilogue: lane = pixel, 4 consecutive channels per accumulator: one 16-byte access per (M-tile, N-tile) ----
+        if constexpr (!(C::KO & 1)) {
+            const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+            float *const dump = reinterpret_cast<float *>(g_vc_dma_dump) + 4 * lane;
+#pragma unroll
+            for (int t = 0; t < WM; ++t) {
+                const int oy = cur.oy0 + 2 * wave + (t >> 1), ox = cur.ox0 + 16 * (t & 1) + px;
+                const bool pix_ok = oy < p.Ho && ox < p.Wo;
+#pragma unroll
+                for (int n = 0; n < WN; ++n) {
+                    const int co = cur.nblk * C::BN + 16 * n + 4 * q;
+                    const bool ok = pix_ok && co < p.Cout;
+                    f32x4 v = acc[t][n];
+                    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                    if (p.res) {
+                        const long long r_off = (long long)cur.img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + co;
+                        if (ok) r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                    }
+                    if (p.res_first) v += r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
+                    if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + min(co, p.Cout - 4));
+                    if (p.res && !p.res_first) v += r;
+                    if (p.out_sp3) {
+                        // split output for a VC_CFG_SPLIT consumer: 3 x 8 bytes (4 channels of one piece) into the pixel's 48-byte record
+                        unsigned h[4], m[4], l[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vc_split3(v[e], h[e], m[e], l[e]);
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        const u32x2 ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+                        const u32x2 pm = {(m[0] >> 16) | (m[1] & 0xffff0000u), (m[2] >> 16) | (m[3] & 0xffff0000u)};
+                        const u32x2 pl = {(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+                        unsigned char *o8 = reinterpret_cast<unsigned char *>(p.out) +
+                                            ((((long long)cur.img * (p.Cout >> 3) + (co >> 3)) * p.Ho + oy) * p.Wo + ox) * 48 + (co & 4) * 2;
+                        unsigned char *dst = ok ? o8 : reinterpret_cast<unsigned char *>(dump);
+                        *reinterpret_cast<u32x2 *>(dst) = ph;
+                        *reinterpret_cast<u32x2 *>(dst + (ok ? 16 : 0)) = pm;
+                        *reinterpret_cast<u32x2 *>(dst + (ok ? 32 : 0)) = pl;
+                    } else {
+                        const long long o_off = (long long)cur.img * p.out_sn + (long long)oy * p.out_sh + (long long)ox * p.out_sw + co;
+                        float *dst = ok ? p.out + o_off : dump;
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < WM; ++t)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) VC_DMA_KEEP(acc[t][n]);
+        }
+        if (!nxt.valid) break;
+        cur = nxt;
+        cur_base = nxt_base;
+        nxt = tile_at(it + 2);
+        nxt_base = tile_base(nxt);
+    }
+    vc_wait_vmcnt<0>();                              // no DMA may land in LDS that already belongs to another workgroup
+}
+
+template <class C> int launch_conv_split(hipStream_t st, const ConvArgs &a)
+{
+    const size_t lds_bytes = C::LDS_FIXED + (size_t)a.nblks * C::BN * sizeof(float);
+    if (lds_bytes > 160 * 1024) return VC_EINVAL;
+    auto kern = conv_split_kernel<C>;
+    static vc_lds_raised raised;
+    if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds_bytes, st, a);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
+}

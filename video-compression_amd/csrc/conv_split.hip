@@ -1,0 +1,153 @@
+// Host side of the split-operand fp32 convolution (conv_split.h, VC_CFG_SPLIT): weight packing, the fp32 -> split tensor
+// conversion, dispatch.  Layers: SPyNet's Basic blocks 7x7 32 -> 64 -> 32 (LHBDC/model/flow.py:52-62) and the mask U-Net's 5x5
+// layers (LHBDC/model/layers.py:202-209).
+#include <stdlib.h>
+#include <string.h>
+#include "conv_split.h"
+
+static inline unsigned short bf16_trunc_bits(float x)
+{
+    unsigned u;
+    memcpy(&u, &x, 4);
+    return (unsigned short)(u >> 16);
+}
+static inline float bf16_bits_to_float(unsigned short h)
+{
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// three bf16 pieces whose exact sum is x (truncation; a value whose last piece would be a bf16 subnormal the matrix pipe
+// may flush loses < 2^-126 * 2^-8 relative to the smallest normal: below any fp32 rounding of the sums it enters)
+static inline void split3_host(float x, unsigned short pc[3])
+{
+    pc[0] = bf16_trunc_bits(x);
+    const float r1 = x - bf16_bits_to_float(pc[0]);
+    pc[1] = bf16_trunc_bits(r1);
+    const float r2 = r1 - bf16_bits_to_float(pc[1]);
+    pc[2] = bf16_trunc_bits(r2);
+}
+
+template <int K> static int units_of() { return SplitUnits<K>::U; }
+static int split_units(int k) { return k == 7 ? units_of<7>() : (k == 5 ? units_of<5>() : (k == 3 ? units_of<3>() : 0)); }
+static int split_block(int cout) { return (cout % 64 == 0) ? 64 : ((cout % 32 == 0) ? 32 : 0); }
+
+extern "C" size_t vc_conv_packed_weight_bytes_split(int cout, int cin, int k)
+{
+    const int u = split_units(k), bn = split_block(cout);
+    if (!u || !bn || (cin % 8)) return 0;
+    // [n-block][chunk][unit][piece][n-tile][lane][8] bf16 + one ring slot of slack (the last DMA round of a unit over-reads)
+    return (size_t)(cout / bn) * (cin / 8) * u * 3 * (bn / 16) * 1024 + 16384;
+}
+
+template <int K> static void pack_split(const float *w, int cout, int cin, int bn, unsigned short *dst)
+{
+    typedef SplitUnits<K> UN;
+    const int ntw = bn / 16, nchunk = cin / 8;
+    for (int nb = 0; nb < cout / bn; ++nb)
+        for (int c = 0; c < nchunk; ++c)
+            for (int u = 0; u < UN::U; ++u) {
+                unsigned short *unit = dst + (((size_t)nb * nchunk + c) * UN::U + u) * (3 * ntw * 512);
+                for (int n = 0; n < ntw; ++n)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = nb * bn + 16 * n + (lane & 15), q = lane >> 4;
+                        for (int j = 0; j < 8; ++j) {
+                            unsigned short pc[3] = {0, 0, 0};
+                            if (UN::valid(u, q)) split3_host(w[(((size_t)co * cin + 8 * c + j) * K + UN::ky(u, q)) * K + UN::kx(u, q)], pc);
+                            for (int piece = 0; piece < 3; ++piece) unit[((piece * ntw + n) * 64 + lane) * 8 + j] = pc[piece];
+                        }
+                    }
+            }
+}
+
+extern "C" int vc_conv_pack_weights_split(const float *w, const float *bias, int cout, int cin, int k, void *wpk_out, float *bias_out)
+{
+    const size_t bytes = vc_conv_packed_weight_bytes_split(cout, cin, k);
+    if (!w || !wpk_out || !bias_out || !bytes) return VC_EINVAL;
+    memset(wpk_out, 0, bytes);
+    unsigned short *dst = static_cast<unsigned short *>(wpk_out);
+    const int bn = split_block(cout);
+    if (k == 7) pack_split<7>(w, cout, cin, bn, dst);
+    else if (k == 5) pack_split<5>(w, cout, cin, bn, dst);
+    else pack_split<3>(w, cout, cin, bn, dst);
+    for (int c = 0; c < cout; ++c) bias_out[c] = bias ? bias[c] : 0.0f;
+    return VC_OK;
+}
+
+// fp32 channels-last window -> split tensor [n][c/8][h][w][3][8] bf16 (48 bytes per pixel and group of 8 channels)
+__global__ void k_split3(vc_view a, unsigned char *__restrict__ out)
+{
+    const int cg = a.c >> 3;
+    const long long per_plane = (long long)a.h * a.w;
+    const long long total = (long long)a.n * cg * per_plane;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pl = i / per_plane, pos = i - pl * per_plane;     // consecutive threads: consecutive pixels of one plane
+        const int n = (int)(pl / cg), g = (int)(pl - (long long)n * cg);
+        const int y = (int)(pos / a.w), x = (int)(pos - (long long)y * a.w);
+        const float *src = a.p + view_off(a, n, y, x) + 8 * g;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vc_split3(v0[e], h[e], m[e], l[e]);
+            vc_split3(v1[e], h[4 + e], m[4 + e], l[4 + e]);
+        }
+        u32x4 ph, pm, pl4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ph[e] = (h[2 * e] >> 16) | h[2 * e + 1];
+            pm[e] = (m[2 * e] >> 16) | m[2 * e + 1];
+            pl4[e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
+        }
+        unsigned char *dst = out + i * 48;
+        *reinterpret_cast<u32x4 *>(dst) = ph;
+        *reinterpret_cast<u32x4 *>(dst + 16) = pm;
+        *reinterpret_cast<u32x4 *>(dst + 32) = pl4;
+    }
+}
+
+extern "C" int vc_split3(vc_stream s, vc_view a, void *out_split)
+{
+    if (!a.p || !out_split || (a.c % 8) || (a.sw % 4) || (a.sh % 4) || (a.sn % 4) || ((uintptr_t)a.p % 16) || ((uintptr_t)out_split % 16)) return VC_EINVAL;
+    const long long total = (long long)a.n * (a.c / 8) * a.h * a.w;
+    if (total <= 0) return VC_OK;
+    hipLaunchKernelGGL(k_split3, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, static_cast<unsigned char *>(out_split));
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
+{
+    if (stride != 1 || !a.in_sp3 || a.in_f16 || a.out_f16 || a.res_f16 || a.tail_wpk || a.epi != VC_EPI_NONE || a.in_xform != VC_IN_NONE ||
+        a.out_mode != VC_OUT_PLAIN || (a.Cin % 8) || a.act == VC_ACT_SIGMOID || a.act == VC_ACT_CLAMP01)
+        return VC_EINVAL;
+    const int bn = split_block(a.Cout);
+    if (!bn) return VC_EINVAL;
+    if (a.out_sp3 ? (a.Cout % 8 != 0) : !a.vec_out) return VC_EINVAL;
+    // per-lane source offsets are 32-bit: a tile's footprint inside one plane must stay below 2 GiB
+    if ((long long)(k + 15) * a.W * 48 + 48ll * 48 >= (1ll << 31)) return VC_EINVAL;
+    a.tiles_x = (a.Wo + 31) / 32;
+    a.tiles_y = (a.Ho + 15) / 16;
+    a.nblks = a.Cout / bn;
+    a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
+#ifdef VC_SPLIT_DIAG
+    {
+        const char *e = getenv("VC_SPLIT_VARIANT");
+        const int v = e ? atoi(e) : 0;
+        if (k == 7 && bn == 64) {
+            switch (v) {
+            case 1: return launch_conv_split<SplitCfg<7, 4, 4, 1>>(st, a);
+            case 4: return launch_conv_split<SplitCfg<7, 4, 4, 4>>(st, a);
+            case 16: return launch_conv_split<SplitCfg<7, 4, 4, 16>>(st, a);
+            case 17: return launch_conv_split<SplitCfg<7, 4, 4, 17>>(st, a);
+            case 21: return launch_conv_split<SplitCfg<7, 4, 4, 21>>(st, a);
+            }
+        }
+    }
+#endif
+    if (k == 7) return bn == 64 ? launch_conv_split<SplitCfg<7, 4>>(st, a) : launch_conv_split<SplitCfg<7, 2>>(st, a);
+    if (k == 5) return bn == 64 ? launch_conv_split<SplitCfg<5, 4>>(st, a) : launch_conv_split<SplitCfg<5, 2>>(st, a);
+    return VC_EINVAL;
+}

@@ -128,6 +128,9 @@ def lib():
     sig("vc_conv_pack_weights_f16", ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp)
     sig("vc_conv_pack_tail_f16", ci, vp, vp, ci, ci, vp, vp)
     sig("vc_conv2d_nhwc", ci, vp, ctypes.POINTER(ConvDesc))
+    sig("vc_conv_packed_weight_bytes_split", sz, ci, ci, ci)
+    sig("vc_conv_pack_weights_split", ci, vp, vp, ci, ci, ci, vp, vp)
+    sig("vc_split3", ci, vp, View, vp)
     sig("vc_nchw_to_nhwc", ci, vp, vp, View)
     sig("vc_nhwc_to_nchw", ci, vp, View, vp)
     sig("vc_u8hwc_to_f32nchw_pad", ci, vp, vp, ci, ci, vp, ci, ci)
@@ -175,7 +178,8 @@ def lib():
 EXPORTED_SYMBOLS = [
     "vc_version", "vc_abi_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
     "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
-    "vc_conv_pack_weights_f16", "vc_conv_pack_tail_f16", "vc_conv2d_nhwc", "vc_nchw_to_nhwc",
+    "vc_conv_pack_weights_f16", "vc_conv_pack_tail_f16", "vc_conv2d_nhwc", "vc_conv_packed_weight_bytes_split",
+    "vc_conv_pack_weights_split", "vc_split3", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
@@ -220,6 +224,10 @@ class T:
 
     @staticmethod
     def empty(n, h, w, c, device, dtype="f32"):
+        if dtype == "sp3":     # split tensor of the split-operand fp32 path: dense [n][c/8][h][w][3][8] bf16 (csrc/conv_split.h)
+            if c % 8:
+                raise VcError("a split tensor holds groups of 8 channels")
+            return T(torch.empty(n * h * w * c * 3, dtype=torch.int16, device=device), n, h, w, c, h * w * c, w * c, c, 0, dtype)
         buf = torch.empty(n * h * w * c, dtype=torch.float16 if dtype == "f16" else torch.float32, device=device)
         return T(buf, n, h, w, c, h * w * c, w * c, c, 0, dtype)
 
@@ -234,6 +242,8 @@ class T:
 
     @property
     def ptr(self):
+        if self.dtype == "sp3":
+            return self.buf.data_ptr()
         return self.buf.data_ptr() + (2 if self.dtype == "f16" else 4) * self.off
 
     def view(self, allow_half=False):
@@ -300,6 +310,13 @@ CFG_OUT_F16 = 0x800
 CFG_RES_FIRST = 0x1000
 CFG_RES_F16 = 0x2000        # fp16 path, VC_CFG_PWS only: `res` is a half-precision tensor (the identity path of a bottleneck chain)
 CFG_PACK128 = 0x4000        # with CFG_DMA: weights / bias packed with the 128-channel configuration (padded to blocks of 128)
+CFG_SPLIT = 10            # fp32 on the bf16 matrix pipe with split operands (csrc/conv_split.h); input: a split tensor (dtype "sp3")
+CFG_IN_SP3 = 0x8000
+CFG_OUT_SP3 = 0x10000
+# "native": v_mfma_f32_* instances everywhere (rounds 1-4).  "split": the layers the split-operand pipeline serves (5x5 / 7x7
+# stride 1, cin % 8 == 0, cout % 32 == 0) run on it -- exact bf16 x 3 pieces, nine exact products, fp32 accumulate; same precision
+# class, different summation order.  VC_FP32_MODE / set_fp32_mode().
+_FP32_MODE = os.environ.get("VC_FP32_MODE", "native")
 CFG_DMA = 8               # fp16 path: LDS-DMA pipeline, one persistent workgroup per CU (csrc/conv_dma.h); half-precision input only
 CFG_PWS = 9               # streaming 1x1 kernel with LDS-DMA activation rings (csrc/conv_pws.hip)
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
@@ -335,6 +352,27 @@ def set_conv_precision(mode):
 
 def conv_precision():
     return _PRECISION
+
+
+def set_fp32_mode(mode):
+    """"native" or "split" (see CFG_SPLIT); applies to calls made afterwards (the split packing is made on first use)."""
+    global _FP32_MODE
+    if mode not in ("native", "split"):
+        raise ValueError("fp32 mode must be 'native' or 'split'")
+    _FP32_MODE = mode
+
+
+def fp32_mode():
+    return _FP32_MODE
+
+
+def split3(x, out=None):
+    """fp32 channels-last window -> split tensor (three bf16 pieces per value, exact): the input format of CFG_SPLIT layers."""
+    if out is None:
+        out = T.empty(x.n, x.h, x.w, x.c, x.buf.device, "sp3")
+    timed_hbm(f"k_split3 c{x.c} @{x.n}x{x.h}x{x.w}", 10.0 * x.n * x.h * x.w * x.c,
+              lambda: check(lib().vc_split3(stream(), x.view(), out.ptr), "vc_split3"))
+    return out
 
 
 class PackedConv:
@@ -375,6 +413,8 @@ class PackedConv:
                 self.wpk16 = torch.from_numpy(w16).to(device)
         self.tuned = {}
         self._tail = None
+        self._wsplit = None
+        self._raw32 = (wnp, bnp) if (kh in (5, 7) and stride == 1 and cin % 8 == 0 and cout % 32 == 0 and not pixelshuffle) else None
         self._raw = (wnp, bnp) if (_PRECISION == "fp16" and kh == 1 and stride == 1 and cout == cin and cin in (64, 128) and not pixelshuffle) else None
         self._device = device
         ck = L.vc_conv_chunk(self.cfg, kh, stride, cin)
@@ -436,6 +476,26 @@ class PackedConv:
         self.tuned[key] = best | CFG_EXACT | flags
         return self.tuned[key]
 
+    @property
+    def split_ok(self):
+        """True when the split-operand fp32 pipeline (CFG_SPLIT) serves this layer."""
+        return self._raw32 is not None and self.wpk16 is None
+
+    def split_pack(self):
+        if self._wsplit is None:
+            if self._raw32 is None:
+                raise VcError("no split-operand instance for this layer")
+            wnp, bnp = self._raw32
+            nbytes = lib().vc_conv_packed_weight_bytes_split(self.cout, self.cin, self.k)
+            if not nbytes:
+                raise VcError("no split-operand instance for this layer")
+            w = np.zeros(nbytes // 2, dtype=np.int16)
+            b = np.empty(self.cout, dtype=np.float32)
+            check(lib().vc_conv_pack_weights_split(wnp.ctypes.data, None if bnp is None else bnp.ctypes.data, self.cout, self.cin, self.k,
+                                                   w.ctypes.data, b.ctypes.data), "vc_conv_pack_weights_split")
+            self._wsplit = (torch.from_numpy(w).to(self._device), torch.from_numpy(b).to(self._device))
+        return self._wsplit
+
     def tail_pack(self):
         """This 1x1 C -> C layer (C = 64 or 128) as the fused tail of a 3x3 layer (vc_conv_pack_tail_f16): (weights, bias) on the device."""
         if self._tail is None:
@@ -472,12 +532,51 @@ class PackedConv:
         bottleneck block whose identity path is kept as half (see VC_CFG_RES_F16 in include/vc_hip.h)."""
         return self.wpk16 is not None and CFG_PWS in self.candidates
 
+    def _call_split(self, x, out, act, slope, res, chscale, out_sp3, res_first):
+        """The layer on the split-operand pipeline.  ``x``: an fp32 window (converted here) or a split tensor left by the layer in
+        front; ``out_sp3``: leave the result as a split tensor for a split consumer."""
+        if not self.split_ok:
+            raise VcError("a split tensor reached a layer the split-operand pipeline does not serve")
+        xs = x if x.dtype == "sp3" else split3(x)
+        ho, wo, co = self.out_shape(x.h, x.w)
+        if out is None:
+            out = T.empty(x.n, ho, wo, co, x.buf.device, "sp3" if out_sp3 else "f32")
+        wsp, bsp = self.split_pack()
+        d = ConvDesc()
+        d.inp = View(xs.ptr, xs.n, xs.h, xs.w, xs.c, xs.sn, xs.sh, xs.sw)
+        d.out = View(out.ptr, out.n, out.h, out.w, out.c, out.sn, out.sh, out.sw)
+        d.wpk, d.bias = wsp.data_ptr(), bsp.data_ptr()
+        if res is not None:
+            if res.dtype != "f32":
+                raise VcError("the split-operand pipeline adds fp32 residuals")
+            d.res, d.res_sn, d.res_sh, d.res_sw = res.ptr, res.sn, res.sh, res.sw
+        if chscale is not None:
+            d.chscale = chscale.data_ptr()
+        d.kh = d.kw = self.k
+        d.stride = 1
+        d.act, d.slope = act, slope
+        d.out_mode = OUT_PLAIN
+        d.cfg = CFG_SPLIT | CFG_EXACT | CFG_IN_SP3 | (CFG_OUT_SP3 if out.dtype == "sp3" else 0) | (CFG_RES_FIRST if res_first else 0)
+        what = f"vc_conv2d_nhwc(split k={self.k},{self.cin}->{self.cout})"
+        if timer is None:
+            check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
+        else:
+            flops = 2.0 * x.n * ho * wo * self.cout * self.cin * self.k * self.k
+            key = f"conv k{self.k} s1 {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
+            nbytes = x.n * x.h * x.w * self.cin * 6 + x.n * ho * wo * co * (6 if out.dtype == "sp3" else 4) + self.cout * self.cin * self.k * self.k * 6
+            timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
+        return out
+
     def __call__(self, x, out=None, act=ACT_NONE, slope=0.01, res=None, epi=EPI_NONE, mul=None,
-                 in_xform=IN_NONE, chscale=None, out_f16=False, res_first=False, tail=None):
+                 in_xform=IN_NONE, chscale=None, out_f16=False, res_first=False, tail=None, out_sp3=False):
         """``out_f16``: a hint that every consumer of the result is an fp16-path convolution (``half_ok``), so the
         result may be stored as half (bit-identical downstream, half the traffic).  Honoured only when this layer
         itself runs on the fp16 path and allocates its own output; otherwise the result stays fp32."""
         ho, wo, co = self.out_shape(x.h, x.w)
+        if x.dtype == "sp3" or (_FP32_MODE == "split" and self.split_ok and epi == EPI_NONE and in_xform == IN_NONE and act < ACT_SIGMOID
+                                and mul is None and tail is None and (out is None or out.dtype != "f16")
+                                and x.dtype == "f32" and x.c % 8 == 0 and x.sw % 4 == 0 and x.sh % 4 == 0 and x.sn % 4 == 0 and x.ptr % 16 == 0):
+            return self._call_split(x, out, act, slope, res, chscale, out_sp3, res_first)
         half_in = x.dtype == "f16"
         esz = 8 if half_in else 4
         use16 = (self.wpk16 is not None and in_xform == IN_NONE and x.sw % esz == 0 and x.sh % esz == 0 and x.sn % esz == 0
