@@ -239,6 +239,9 @@ def parse_args():
                          "icip2024 = configs[4]'s model (FlowGuidedB, GOP-16, flow-resolution search, 5 quality levels)")
     ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32",
                     help="fp32 = exact path (headline); fp16 = half-precision MFMA conv path of BASELINE configs[4]")
+    ap.add_argument("--fp32-mode", choices=["native", "split"], default=os.environ.get("VC_FP32_MODE", "split"),
+                    help="fp32 path only: native = v_mfma_f32_* instances everywhere; split = the layers csrc/conv_split.h serves run on the "
+                         "bf16 matrix pipe with exact bf16 x 3 operands (nine exact products, fp32 accumulate)")
     ap.add_argument("--resolution", choices=["1080p", "2160p"], default="1080p")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="strong = BASELINE configs[3]: a fixed multi-sequence test set GOP-sharded over the ranks (LHBDC)")
@@ -313,6 +316,7 @@ def main():
     H, W = (2160, 3840) if args.resolution == "2160p" else (1080, 1920)
     hip.set_conv_precision(args.precision)
     f16 = args.precision == "fp16"
+    hip.set_fp32_mode("native" if f16 else args.fp32_mode)
     is_flex = args.model == "flex"
     is_icip = args.model == "icip2024"
     strong = args.scaling == "strong"
@@ -475,6 +479,9 @@ def main():
         "vs_baseline": None,
         "dtype": ("f16 operands / f32 accumulate (eligible convolutions; activations between them and, VC_HALF_RESIDUAL=1, the identity "
                   "path of bottleneck chains stored as half), f32 elsewhere") if f16 else "f32",
+        "fp32_mode": None if f16 else (args.fp32_mode + (" (f32 operands as exact sums of three bf16 pieces, all nine piece products -- each exact in f32 -- "
+                                                         "accumulated in f32 on v_mfma_f32_16x16x32_bf16 for the layers csrc/conv_split.h serves; "
+                                                         "native v_mfma_f32_* elsewhere)" if args.fp32_mode == "split" else " (v_mfma_f32_* everywhere)")),
         "data": f"synthetic (band-limited texture + global translation + 2% noise, {H}x{W} reflection-padded to x64); "
                 + ("seeded random weights rescaled to trained-like statistics (vcamd.seeding.calibrated_state_dict)" if checkpoint == "calibrated"
                    else "seeded random weights"),
@@ -638,6 +645,11 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
     per_launch_bytes = dom["bytes"] / dom["launches"]
     avg_ms = dom["ms"] / dom["launches"]
     peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+    dom_split = (not f16) and key in getattr(hip, "split_keys", set())
+    if dom_split:
+        # the dominant launch ran on the split-operand pipeline: an exact fp32 product costs NINE bf16 products there, so the
+        # roof of the ALGORITHMIC fp32 FLOP rate is the dense bf16 matrix peak / 9
+        peak = PEAK_F16_MFMA_TFLOPS / 9.0
     # which roofline bounds the dominant kernel: arithmetic intensity against the ridge peak_flops / peak_bandwidth
     intensity = per_launch_flop / max(per_launch_bytes, 1.0)
     if intensity >= peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
@@ -648,6 +660,13 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": key, "achieved": achieved, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                               "frac": achieved / PEAK_HBM_GBPS, "traffic": None}
+    if dom_split:
+        result["roofline"].update({
+            "pipeline": "split operands (csrc/conv_split.h): 9 x v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 fp32 block",
+            "peak_is": "dense bf16 MFMA peak (2500 TFLOP/s) / 9 products per exact fp32 product",
+            "executed_bf16_tflops": 9.0 * result["roofline"]["achieved"],
+            "native_fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS,
+            "achieved_over_native_fp32_peak": result["roofline"]["achieved"] / PEAK_F32_MFMA_TFLOPS})
     result["roofline"].update({"launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
                                "share_of_conv_time": dom["ms"] / total_ms,
                                "algorithmic_flop_per_launch": per_launch_flop,
@@ -702,6 +721,28 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
             json.dump({"what": "one B-frame launched eagerly with HIP events around every launch (python bench.py --kernel-table ...)",
                        "model": args.model, "precision": args.precision, "resolution": args.resolution,
                        "conv_ms_per_frame": total_ms, "convolutions": rows, "hbm_kernels": result["hbm_kernels"]}, f, indent=1)
+
+    if (not f16 and args.fp32_mode == "split" and not is_flex and not is_icip and args.scaling == "weak" and not args.no_graph
+            and not args.skip_extras and len(frames) % 9 == 0):
+        # ---- the same timed workload on the NATIVE fp32 instances (v_mfma_f32_* everywhere), side by side with `value` ----
+        hip.set_fp32_mode("native")
+        Gn = len(frames) // 9
+        runner = vgop.GopGraph(model, H, W, gops=Gn)
+        with torch.no_grad():
+            for _ in range(2):
+                runner.code(frames, gop_index=0, records=None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                runner.code(frames, gop_index=0, records=None)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 3
+        del runner
+        hip.set_fp32_mode(args.fp32_mode)
+        result["fp32_native"] = {"value": 7.0 * Gn / dt, "unit": "frames/s", "ms_per_step": 1000.0 * dt, "steps": 3, "warmup": 2,
+                                 "what": "the timed workload with every fp32 layer on the native v_mfma_f32_* instances (hip.set_fp32_mode('native'), "
+                                         "the round 1-4 headline path), same graphs, same frames",
+                                 "split_over_native": result["value"] / (7.0 * Gn / dt)}
 
     if not is_flex and not is_icip and args.resolution == "1080p" and args.scaling == "weak" and not args.skip_extras:
         # ---- whole GOP as testing.py codes it: 1 I-frame (mbt2018_mean q7 architecture) + 7 B-frames ----

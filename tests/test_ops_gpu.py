@@ -21,6 +21,17 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _native_fp32_instances():
+    """This module pins and compares the NATIVE fp32 / fp16 tile configurations; the split-operand pipeline (the default fp32 mode for
+    the layers it serves) has its own module, tests/test_split_gpu.py."""
+    from vcamd import hip
+    keep = hip.fp32_mode()
+    hip.set_fp32_mode("native")
+    yield
+    hip.set_fp32_mode(keep)
+
+
 def _rand(shape, seed, scale=1.0):
     g = np.random.default_rng(seed)
     return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))

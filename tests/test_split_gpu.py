@@ -1,0 +1,156 @@
+"""-m gpu: the split-operand fp32 convolution (VC_CFG_SPLIT, csrc/conv_split.h; the default fp32 mode since round 5) against an
+fp64 CPU reference and against the native fp32 MFMA instances.
+
+Bars: error against fp64 no worse than 1.5 x the native instance's; the reference-parity tests
+(test_reference_1080p_gpu.py, test_lhbdc_gpu.py, test_fullsize_gpu.py) run in the default mode, i.e. on this path.
+Reference call sites: LHBDC/model/flow.py:52-62 (7x7 Basic blocks), LHBDC/model/layers.py:202-209 (5x5 mask U-Net layers).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_mode():
+    from vcamd import hip
+    keep = hip.fp32_mode()
+    yield
+    hip.set_fp32_mode(keep)
+
+
+def _layer(cin, cout, k, seed, dev, bias=True):
+    from vcamd import hip
+    g = torch.Generator().manual_seed(seed)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1 if bias else None
+    return wt, b, hip.PackedConv(wt, b, stride=1, device=dev)
+
+
+CASES = [  # cin, cout, k, n, h, w  (>= 48 tiles of 16 x 32 per image: the sizes the split pipeline takes)
+    (32, 64, 7, 1, 112, 224),
+    (64, 32, 7, 2, 100, 250),      # ragged right / bottom tiles, two images
+    (8, 32, 7, 1, 128, 200),       # one chunk per tile
+    (96, 32, 5, 1, 120, 230),
+    (192, 64, 5, 1, 120, 200),
+    (32, 128, 7, 1, 97, 130),      # two blocks of 64 output channels
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,n,h,w", CASES)
+def test_split_conv_against_fp64_and_the_native_instance(dev, cin, cout, k, n, h, w):
+    from vcamd import hip
+    wt, b, pc = _layer(cin, cout, k, 3, dev)
+    assert pc.split_ok and pc.split_pays(n, h, w)
+    g = torch.Generator().manual_seed(4)
+    xc = torch.randn(n, cin, h, w, generator=g)
+    rc = torch.randn(n, cout, h, w, generator=g)
+    gain = torch.rand(cout, generator=g) + 0.5
+    x, res = hip.nchw_to_nhwc(xc.to(dev)), hip.nchw_to_nhwc(rc.to(dev))
+    ref = F.leaky_relu(F.conv2d(xc.double(), wt.double(), b.double(), padding=k // 2), 0.1) * gain.double().view(1, -1, 1, 1) + rc.double()
+    mag = F.conv2d(xc.double().abs(), wt.double().abs(), b.double().abs(), padding=k // 2) + rc.double().abs()
+    err = {}
+    for mode in ("native", "split"):
+        hip.set_fp32_mode(mode)
+        y = hip.nhwc_to_nchw(pc(x, act=hip.ACT_LRELU, slope=0.1, res=res, chscale=gain.to(dev))).cpu().double()
+        e = (y - ref).abs() / mag
+        err[mode] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+    print(f"k{k} {cin}->{cout} @{n}x{h}x{w}: max / rms error over sum|a b| against fp64: native {err['native'][0]:.2e} / {err['native'][1]:.2e}, "
+          f"split {err['split'][0]:.2e} / {err['split'][1]:.2e}")
+    assert err["split"][0] <= 1.5 * err["native"][0] and err["split"][1] <= 1.5 * err["native"][1], err
+    assert err["split"][0] < 6e-7
+
+
+def test_split_tensor_is_exact_and_a_split_chain_never_converts(dev):
+    """vc_split3: hi + mid + lo == x bit for bit (also for subnormal-range and huge values); the OUT_SP3 epilogue writes the same
+    records vc_split3 would make of the fp32 result, so a chain through a split intermediate equals the chain through fp32."""
+    from vcamd import hip
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 16, 40, 72, generator=g)
+    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-30, -3e38, 1.0, 2.0 ** -120, 1.0 + 2.0 ** -23, -(2.0 - 2.0 ** -23)])
+    xt = hip.nchw_to_nhwc(x.to(dev))
+    sp = hip.split3(xt)
+    rec = sp.buf.view(1, 2, 40, 72, 3, 8).to(torch.int32)          # [n][c/8][h][w][piece][8] bf16 bits
+    pieces = (rec << 16).view(torch.float32)
+    back = (pieces[..., 2, :] + pieces[..., 1, :]) + pieces[..., 0, :]          # exact: each partial sum is representable
+    back = back.permute(0, 1, 4, 2, 3).reshape(1, 16, 40, 72).cpu()
+    assert torch.equal(back, x)
+    hip.set_fp32_mode("split")
+    wt1, b1, p1 = _layer(32, 64, 7, 6, dev)
+    wt2, b2, p2 = _layer(64, 32, 7, 7, dev)
+    xin = hip.T.empty(2, 112, 224, 32, dev)
+    xin.buf.normal_()
+    mid_sp = p1(xin, act=hip.ACT_RELU, out_sp3=True)
+    assert mid_sp.dtype == "sp3"
+    a = hip.nhwc_to_nchw(p2(mid_sp, act=hip.ACT_RELU))
+    mid = p1(xin, act=hip.ACT_RELU)
+    assert mid.dtype == "f32"
+    bb = hip.nhwc_to_nchw(p2(mid, act=hip.ACT_RELU))
+    assert torch.equal(a, bb)
+
+
+def test_split_result_does_not_depend_on_the_batch(dev):
+    """A frame gets the same bits coded alone or inside a level-batched pass (the pipeline choice is per image, the accumulation
+    order per output fixed)."""
+    from vcamd import hip
+    hip.set_fp32_mode("split")
+    _, _, pc = _layer(32, 64, 7, 8, dev)
+    x = hip.T.empty(3, 112, 224, 32, dev)
+    x.buf.normal_()
+    full = hip.nhwc_to_nchw(pc(x, act=hip.ACT_RELU))
+    for i in range(3):
+        one = hip.nhwc_to_nchw(pc(x.images(i, i + 1), act=hip.ACT_RELU))
+        assert torch.equal(one, full[i:i + 1])
+    # three repetitions: no run-to-run variation (counted waits, no atomics)
+    again = hip.nhwc_to_nchw(pc(x, act=hip.ACT_RELU))
+    assert torch.equal(again, full)
+
+
+def test_split_path_refuses_what_it_does_not_serve(dev):
+    from vcamd import hip
+    hip.set_fp32_mode("split")
+    _, _, pc = _layer(32, 64, 7, 9, dev)
+    x = hip.T.empty(1, 112, 224, 32, dev)
+    x.buf.normal_()
+    sp = hip.split3(x)
+    with pytest.raises(hip.VcError):
+        pc(sp, act=hip.ACT_SIGMOID)            # sigmoid epilogue: not on the split pipeline
+    small = hip.T.empty(1, 34, 60, 32, dev)   # a coarse pyramid level: stays on the native instances
+    small.buf.normal_()
+    assert not pc.split_pays(1, 34, 60)
+    y = pc(small, act=hip.ACT_RELU)
+    hip.set_fp32_mode("native")
+    assert torch.equal(hip.nhwc_to_nchw(y), hip.nhwc_to_nchw(pc(small, act=hip.ACT_RELU)))
+
+
+def test_lhbdc_forward_split_and_native_code_the_same_integers(dev):
+    """Model level: the default (split) mode against the native mode on one fixture-sized frame triple -- same symbols, x_hat within
+    fp32 summation noise."""
+    from vcamd import hip, lhbdc
+    from vcamd.seeding import calibrated_state_dict
+    m = lhbdc.Model()
+    m.load_state_dict(calibrated_state_dict(m.state_dict(), seed=1234))
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(11)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 264, 400, generator=g), 9, 1)
+    xb, xc, xa = (base[..., :256, i:i + 384].contiguous().to(dev) for i in (0, 3, 6))
+    out = {}
+    with torch.no_grad():
+        for mode in ("native", "split"):
+            hip.set_fp32_mode(mode)
+            tr = {}
+            x_hat, tot = m.forward_device(xb, xc, xa, trace=tr)
+            out[mode] = (x_hat.cpu(), tot.cpu(), {f"{k}_{w}": tr[k][w].cpu() for k in ("mv", "res") for w in ("y_sym", "z_sym")})
+    d = float((out["native"][0] - out["split"][0]).abs().max())
+    flips = {k: int((out["native"][2][k] != out["split"][2][k]).sum()) for k in out["native"][2]}
+    print(f"LHBDC 256x384 native vs split: x_hat max|d| {d:.2e}, symbols differing {flips}")
+    assert sum(flips.values()) <= 1 and (d < 1e-4 or sum(flips.values()) == 1)

@@ -83,6 +83,7 @@ class KernelTimer:
 
 
 timer = None  # set to a KernelTimer() to collect
+split_keys = set()   # (while a KernelTimer collects) the timing keys of launches that ran on the split-operand pipeline
 
 
 def timed_hbm(key, nbytes, launch):
@@ -313,10 +314,11 @@ CFG_PACK128 = 0x4000        # with CFG_DMA: weights / bias packed with the 128-c
 CFG_SPLIT = 10            # fp32 on the bf16 matrix pipe with split operands (csrc/conv_split.h); input: a split tensor (dtype "sp3")
 CFG_IN_SP3 = 0x8000
 CFG_OUT_SP3 = 0x10000
-# "native": v_mfma_f32_* instances everywhere (rounds 1-4).  "split": the layers the split-operand pipeline serves (5x5 / 7x7
+# "native": v_mfma_f32_* instances everywhere (rounds 1-4).  "split" (default since round 5, after the reference-parity tests
+# came out equal on it: tests/test_reference_1080p_gpu.py): the layers the split-operand pipeline serves (5x5 / 7x7
 # stride 1, cin % 8 == 0, cout % 32 == 0) run on it -- exact bf16 x 3 pieces, nine exact products, fp32 accumulate; same precision
 # class, different summation order.  VC_FP32_MODE / set_fp32_mode().
-_FP32_MODE = os.environ.get("VC_FP32_MODE", "native")
+_FP32_MODE = os.environ.get("VC_FP32_MODE", "split")
 CFG_DMA = 8               # fp16 path: LDS-DMA pipeline, one persistent workgroup per CU (csrc/conv_dma.h); half-precision input only
 CFG_PWS = 9               # streaming 1x1 kernel with LDS-DMA activation rings (csrc/conv_pws.hip)
 AUTOTUNE = bool(int(os.environ.get("VC_AUTOTUNE", "1")))
@@ -481,6 +483,13 @@ class PackedConv:
         """True when the split-operand fp32 pipeline (CFG_SPLIT) serves this layer."""
         return self._raw32 is not None and self.wpk16 is None
 
+    def split_pays(self, n, h, w):
+        """The split pipeline walks 16 x 32-pixel tiles with one workgroup per CU: on coarse pyramid levels (few tiles) the native
+        instances with their 8-row tiles and several workgroups per CU are faster.  Decided per IMAGE, never by the batch: a
+        frame must get the same bits whether it is coded alone or in a level-batched pass."""
+        bn = 64 if self.cout % 64 == 0 else 32
+        return ((h + 15) // 16) * ((w + 31) // 32) * (self.cout // bn) >= 48
+
     def split_pack(self):
         if self._wsplit is None:
             if self._raw32 is None:
@@ -564,6 +573,7 @@ class PackedConv:
             flops = 2.0 * x.n * ho * wo * self.cout * self.cin * self.k * self.k
             key = f"conv k{self.k} s1 {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
             nbytes = x.n * x.h * x.w * self.cin * 6 + x.n * ho * wo * co * (6 if out.dtype == "sp3" else 4) + self.cout * self.cin * self.k * self.k * 6
+            split_keys.add(key)
             timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
         return out
 
@@ -573,7 +583,8 @@ class PackedConv:
         result may be stored as half (bit-identical downstream, half the traffic).  Honoured only when this layer
         itself runs on the fp16 path and allocates its own output; otherwise the result stays fp32."""
         ho, wo, co = self.out_shape(x.h, x.w)
-        if x.dtype == "sp3" or (_FP32_MODE == "split" and self.split_ok and epi == EPI_NONE and in_xform == IN_NONE and act < ACT_SIGMOID
+        if x.dtype == "sp3" or (_FP32_MODE == "split" and self.split_ok and self.split_pays(x.n, x.h, x.w) and epi == EPI_NONE
+                                and in_xform == IN_NONE and act < ACT_SIGMOID
                                 and mul is None and tail is None and (out is None or out.dtype != "f16")
                                 and x.dtype == "f32" and x.c % 8 == 0 and x.sw % 4 == 0 and x.sh % 4 == 0 and x.sn % 4 == 0 and x.ptr % 16 == 0):
             return self._call_split(x, out, act, slope, res, chscale, out_sp3, res_first)

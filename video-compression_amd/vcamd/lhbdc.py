@@ -116,8 +116,12 @@ class Network(_Prepared):
                                             "vc_spynet_level_input"))
             c = self._convs(lvl)
             # (each intermediate feeds exactly one convolution: on the fp16 path it is kept as half in HBM)
-            x = c[0](feat, act=hip.ACT_RELU, out_f16=c[1].half_ok)
-            x = c[1](x, act=hip.ACT_RELU, out_f16=c[2].half_ok)
+            # (fp32 mode "split", hip.set_fp32_mode: the 8 -> 32 -> 64 -> 32 layers on the split-operand pipeline; between them
+            #  the activations stay split tensors -- the producing epilogue writes the three bf16 pieces -- where the level is
+            #  large enough for that pipeline to pay)
+            sp = hip.fp32_mode() == "split" and c[1].split_ok and c[1].split_pays(f1.n, f1.h, f1.w)
+            x = c[0](feat, act=hip.ACT_RELU, out_f16=c[1].half_ok, out_sp3=sp)
+            x = c[1](x, act=hip.ACT_RELU, out_f16=c[2].half_ok, out_sp3=sp)
             x = c[2](x, act=hip.ACT_RELU, out_f16=c[3].half_ok)
             x = c[3](x, act=hip.ACT_RELU, out_f16=c[4].half_ok)
             flow = c[4](x, res=up)
