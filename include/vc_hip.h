@@ -89,8 +89,8 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
                         exact sum of three bf16 pieces, all nine piece products (each exact in fp32) are accumulated in fp32 by
                         v_mfma_f32_16x16x32_bf16 -- 9/16 of the native fp32 matrix time; same precision class as the native
                         instances (errors against fp64 measured no larger), NOT bit-identical to them (summation order).
-                        5x5 / 7x7 stride 1, cin a multiple of 8, cout a multiple of 32, plain / ReLU / LeakyReLU epilogue
-                        (+ gain, residual); `in` must be a split tensor (VC_CFG_IN_SP3), `wpk` from
+                        5x5 / 7x7 stride 1 (cin a multiple of 8, cout of 32) and 3x3 stride 1 (cin a multiple of 16, cout of 64),
+                        plain / ReLU / LeakyReLU epilogue (+ gain, residual, pixel shuffle); `in` must be a split tensor (VC_CFG_IN_SP3), `wpk` from
                         vc_conv_pack_weights_split */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
  * same packed weights and produces bit-identical results); without it the library narrows the block for
@@ -170,7 +170,8 @@ int vc_conv_pack_weights_f16(const float *w_oihw, const float *bias, int cout, i
 /* Split-operand path: packed weights = bf16 piece fragments [n-block][chunk of 8 channels][tap unit][piece][n-tile][lane][8]
  * (bytes incl. the slack the last DMA round may over-read; 0 = shape not served); bias_out: cout floats. */
 size_t vc_conv_packed_weight_bytes_split(int cout, int cin, int k);
-int vc_conv_pack_weights_split(const float *w_oihw, const float *bias, int cout, int cin, int k, void *wpk_out, float *bias_out);
+int vc_conv_pack_weights_split(const float *w_oihw, const float *bias, int cout, int cin, int k, int pixelshuffle, void *wpk_out,
+                               float *bias_out);
 /* fp32 channels-last window (c % 8 == 0, 16-byte aligned rows) -> dense split tensor, 6 bytes per element */
 int vc_split3(vc_stream s, vc_view in, void *out_split);
 int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d);

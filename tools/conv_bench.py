@@ -26,11 +26,15 @@ def main():
     ap.add_argument("--half-io", action="store_true",
                     help="fp16 path: half-precision input AND output tensors (VC_CFG_IN_F16 / OUT_F16), as inside a chain of "
                          "fp16-path layers; default is fp32 tensors either side (the first / last layer of a chain)")
+    ap.add_argument("--split", action="store_true",
+                    help="fp32 layers on the split-operand pipeline (VC_CFG_SPLIT, csrc/conv_split.h); the input is converted to a split "
+                         "tensor ONCE before the timed launches (inside a chain the producing epilogue writes it)")
     ap.add_argument("--residual", action="store_true", help="add an fp32 residual tensor in the epilogue (bottleneck blocks)")
     ap.add_argument("shapes", nargs="*", default=DEFAULT)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     hip.set_conv_precision(args.precision)
+    hip.set_fp32_mode("split" if args.split else "native")
     for spec in args.shapes:
         fields = [int(v) for v in spec.split(",")]
         cin, cout, k, s, n, h, w = fields[:7]
@@ -53,6 +57,11 @@ def main():
         if args.residual:
             res = hip.T.empty(n, ho, wo, co, dev)
             res.buf.normal_()
+        if args.split:
+            if not pc.split_ok:
+                print(f"conv k{k} s{s} {cin}->{cout}: no split-operand instance")
+                continue
+            x = hip.split3(x)
         for _ in range(2):
             pc(x, out=out, act=hip.ACT_LRELU, res=res)
         stamps = hasattr(hip.lib(), "vc_debug_dma_stamps") and os.environ.get("VC_DMA_VARIANT") == "64"

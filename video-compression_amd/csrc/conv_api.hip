@@ -36,7 +36,7 @@ extern "C" int vc_conv_select_cfg(int cout, int cin, int k, int stride)
 
 extern "C" int vc_conv_chunk(int cfg, int k, int stride, int cin)
 {
-    if (cfg == VC_CFG_SPLIT) return (stride == 1 && (k == 5 || k == 7)) ? 8 : -1;   // 8-channel chunks of a split tensor
+    if (cfg == VC_CFG_SPLIT) return stride != 1 ? -1 : ((k == 5 || k == 7) ? 8 : (k == 3 ? 16 : -1));   // planes of 8 channels of a split tensor per chunk
     if (cfg == VC_CFG_N4) {   // 64-pixel-wide tiles: smaller channel chunks keep the footprint in LDS
         if (stride != 1) return -1;
         return k == 3 ? 16 : ((k == 5 || k == 7) ? 8 : -1);

@@ -33,6 +33,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- the tap units of a K x K kernel (shared by the host packer and the kernel) ----
 template <int K> struct SplitUnits {
+    static constexpr int TPU = 4;                        // taps per unit (one 8-channel plane per k-group)
     static constexpr int Q = (K / 2) * (K / 2);          // 2 x 2 blocks over ky, kx < K - 1
     static constexpr int V = (K + 3) / 4;                // runs of <= 4 down the column kx = K - 1 (K taps)
     static constexpr int H = (K - 1 + 3) / 4;            // runs of <= 4 along the row ky = K - 1, kx < K - 1 (K - 1 taps)
@@ -83,24 +84,80 @@ template <int K> struct SplitUnits {
     static_assert(covers_all(), "every tap in exactly one unit");
 };
 
-// NTW: N-tiles of 16 output channels per workgroup (2 or 4: blocks of 32 / 64 channels)
-template <int K_, int NTW_, int RING_ = 4, int KO_ = 0> struct SplitCfg {
-    typedef SplitUnits<K_> UN;
-    static constexpr int K = K_, NTW = NTW_, RING = RING_, KO = KO_, U = UN::U, PAD = K_ / 2;
-    static constexpr int TH = 16, TW = 32, BN = 16 * NTW_;
-    static constexpr int WAVES = 8, WM = 4, WN = NTW_;           // wave w: output rows 2 w, 2 w + 1; M-tile t: row t >> 1, columns 16 (t & 1) ..
+// The same for chunks of TWO 8-channel planes (3 x 3 layers): K of an MFMA = 2 taps x 16 channels, k-group q = (tap q >> 1, plane
+// q & 1).  Units = horizontal pairs over kx < K - 1 row by row, then vertical pairs down the column kx = K - 1 (3 x 3: 3 + 2 = 5
+// units for 9 taps, 10 % padding).  Interface as SplitUnits with q = the TAP index of the k-group.
+template <int K> struct SplitPairs {
+    static constexpr int TPU = 2;
+    static constexpr int HP = (K - 1) / 2;               // horizontal pairs per kernel row
+    static constexpr int Q = HP * K;
+    static constexpr int V = (K + 1) / 2;                // vertical pairs (the last one may be a single tap)
+    static constexpr int U = Q + V;
+    static constexpr int type(int u) { return u < Q ? 2 : 1; }
+    static constexpr int ky0(int u) { return u < Q ? u / HP : 2 * (u - Q); }
+    static constexpr int kx0(int u) { return u < Q ? 2 * (u % HP) : K - 1; }
+    static constexpr int nvalid(int u) { return u < Q ? 2 : (K - 2 * (u - Q) < 2 ? 1 : 2); }
+    static constexpr int ky(int u, int q) { return type(u) == 1 ? ky0(u) + (q < nvalid(u) ? q : nvalid(u) - 1) : ky0(u); }
+    static constexpr int kx(int u, int q) { return type(u) == 2 ? kx0(u) + (q < nvalid(u) ? q : nvalid(u) - 1) : kx0(u); }
+    static constexpr bool valid(int u, int q) { return q < nvalid(u); }
+    static constexpr int cls(int u) { return type(u) * 4 + nvalid(u) - 1; }
+    static constexpr int NCLS = 12;
+    static constexpr int dy(int c, int q)
+    {
+        const int t = c / 4, nv = c % 4 + 1, qq = q < nv ? q : nv - 1;
+        return t == 1 ? qq : 0;
+    }
+    static constexpr int dx(int c, int q)
+    {
+        const int t = c / 4, nv = c % 4 + 1, qq = q < nv ? q : nv - 1;
+        return t == 2 ? qq : 0;
+    }
+    static constexpr bool covers_all()
+    {
+        int seen[K * K] = {};
+        for (int u = 0; u < U; ++u)
+            for (int q = 0; q < 2; ++q)
+                if (valid(u, q)) ++seen[ky(u, q) * K + kx(u, q)];
+        for (int i = 0; i < K * K; ++i)
+            if (seen[i] != 1) return false;
+        return true;
+    }
+    static_assert(covers_all(), "every tap in exactly one unit");
+};
+
+template <int K, int CPL> struct SplitUnitsOf { typedef SplitUnits<K> type; };
+template <int K> struct SplitUnitsOf<K, 2> { typedef SplitPairs<K> type; };
+
+// NTW: N-tiles of 16 output channels per workgroup (2 or 4: blocks of 32 / 64 channels); CPL: 8-channel planes per chunk (1: K of an
+// MFMA = 4 taps x 8 channels, 5 x 5 / 7 x 7; 2: 2 taps x 16 channels, 3 x 3); TH: rows of the 32-pixel-wide output tile (16, or 12
+// where two chunk images of 16 rows do not fit beside the weight ring)
+template <int K_, int NTW_, int CPL_ = 1, int TH_ = 16, int RING_ = 4, int KO_ = 0> struct SplitCfg {
+    typedef typename SplitUnitsOf<K_, CPL_>::type UN;
+    static_assert(UN::TPU * CPL_ == 4, "four k-groups of 8 channels per MFMA");
+    static constexpr int K = K_, NTW = NTW_, CPL = CPL_, RING = RING_, KO = KO_, U = UN::U, PAD = K_ / 2;
+    static constexpr int TH = TH_, TW = 32, BN = 16 * NTW_;
+    // wave w owns the M-tiles (16 pixels of a row) m = WM w .. WM w + WM - 1: row m >> 1, columns 16 (m & 1) ..
+    static constexpr int WAVES = 8, WM = TH_ * 2 / 8, WN = NTW_;
+    static_assert(WM * 8 == TH_ * 2, "the tile's 2 TH M-tiles split evenly over 8 waves");
     static constexpr int ROWS_IN = TH + K_ - 1, COLS = TW + K_ - 1, PIX = ROWS_IN * COLS;
-    static constexpr int PXB = 48;                               // bytes per pixel of a chunk image: 3 pieces x 8 channels x 2
-    static constexpr int NA = (PIX * 3 + 511) / 512;             // DMA instructions per wave and chunk image
+    static constexpr int PXB = 48;                               // bytes per pixel of a plane image: 3 pieces x 8 channels x 2
+    static constexpr int PLANE_B = PIX * PXB;                    // the chunk image: [plane][pixel][piece] in 16-byte slots
+    static constexpr int NA = (CPL_ * PIX * 3 + 511) / 512;      // DMA instructions per wave and chunk image
     static constexpr int A_BYTES = NA * 8192;
     static constexpr int FRAGS = 3 * NTW_;                       // weight fragments (1 KiB) per unit: [piece][n-tile]
-    static constexpr int NB = (FRAGS + 7) / 8;                   // DMA instructions per wave and unit (the tail of the last round over-reads into the next unit)
-    static constexpr int SLOTB = NB * 8192;
+    // DMA rounds per unit: every wave fetches one KiB per round.  A last round of exactly 4 fragments is fetched by waves 0-3 (= wave
+    // group 0) alone -- the counted waits then differ per group --; any other remainder is fetched by all waves (the tail over-reads
+    // into the next unit's fragments and lands in slot padding)
+    static constexpr int ROUNDS = (FRAGS + 7) / 8, LASTW = FRAGS - 8 * (ROUNDS - 1);
+    static constexpr bool EXACT = LASTW == 4;
+    static constexpr int SLOTB = EXACT ? FRAGS * 1024 : ROUNDS * 8192;
+    static constexpr int nb(int grp) { return ROUNDS - ((EXACT && grp == 1) ? 1 : 0); }
     static constexpr int B_OFF = 2 * A_BYTES, BIAS_OFF = B_OFF + RING_ * SLOTB;
     static constexpr int LDS_FIXED = BIAS_OFF;                   // + 4 * Cout at launch
     static constexpr int D = RING_ - 2;                          // weights are requested D units ahead
     // pieces of the NEXT chunk image: PPP per phase from phase 1 on; they must all be older than the weight request of phase U - D
     static constexpr int WIN = U - D - 1, PPP = (NA + WIN - 1) / WIN;
+    static_assert(WIN >= 1, "no issue window for the chunk image");
     static constexpr int piece_phase(int k) { return 1 + k / PPP; }
     static constexpr int nA(int u)
     {
@@ -109,13 +166,13 @@ template <int K_, int NTW_, int RING_ = 4, int KO_ = 0> struct SplitCfg {
         return n;
     }
     // vmcnt of phase u: the weights of unit u + 1 were the LAST requests of phase u + 1 - D; younger: everything of the phases after it
-    static constexpr int nwait(int u)
+    static constexpr int nwait(int u, int grp)
     {
         int n = 0;
-        for (int j = u + 2 - D; j <= u; ++j) n += nA(((j % U) + U) % U) + NB;
+        for (int j = u + 2 - D; j <= u; ++j) n += nA(((j % U) + U) % U) + nb(grp);
         return n;
     }
-    static_assert(D >= 1 && nwait(U - 1) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(D >= 1 && nwait(U - 1, 0) <= 63, "vmcnt is a 6-bit counter");
 };
 
 // bf16 pieces of an fp32 value by truncation: hi = top 16 bits, the remainder x - hi is exact, and so on; lo is exact (<= 8 bits left)
@@ -133,7 +190,7 @@ __device__ __forceinline__ void vc_split3(float x, unsigned &h, unsigned &m, uns
 template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(const ConvArgs p)
 {
     typedef typename C::UN UN;
-    constexpr int U = C::U, WM = C::WM, WN = C::WN, NA = C::NA, NB = C::NB, RING = C::RING, D = C::D;
+    constexpr int U = C::U, WM = C::WM, WN = C::WN, NA = C::NA, RING = C::RING, D = C::D, CPL = C::CPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];   // the kernel's only LDS object: starts at LDS address 0
 
     const int tid = threadIdx.x;
@@ -165,35 +222,36 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
     DmaTile cur = tile_at(0);
     if (!cur.valid) return;
 
-    const int nchunk = p.Cin >> 3;                                // 8-channel chunks (runtime: the chunk loop is rolled)
+    const int nchunk = p.Cin / (8 * CPL);                         // chunks of CPL 8-channel planes (runtime: the chunk loop is rolled)
     const int upt = nchunk * U;                                   // units per tile
     const unsigned char *const in_b = reinterpret_cast<const unsigned char *>(p.in);
     const unsigned char *const wpk = reinterpret_cast<const unsigned char *>(p.wpk);
     const long long plane = (long long)p.H * p.W * C::PXB;        // bytes of one 8-channel plane of one image
     const unsigned char *const zero_lane = g_vc_dma_zero + 16 * lane;
 
-    // ---- A pieces: lane (k, tid) fills slot s = 512 k + tid = 3 * pixel + piece of the chunk image, from the same position of the plane ----
+    // ---- A pieces: lane (k, tid) fills slot s = 512 k + tid = (plane, pixel, piece) of the chunk image, from the same position of that plane ----
     int a_off[NA], a_rc[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int s = k * 512 + tid;
-        const int pix = s / 3, piece = s - 3 * pix;
+        const int pl = s / (3 * C::PIX), s2 = s - pl * (3 * C::PIX);
+        const int pix = s2 / 3, piece = s2 - 3 * pix;
         const int row = pix / C::COLS, col = pix - row * C::COLS;
-        a_off[k] = (row * p.W + col) * C::PXB + piece * 16;
-        a_rc[k] = pix < C::PIX ? (row | (col << 8)) : 0x7f7f7f;
+        a_off[k] = pl * (int)plane + (row * p.W + col) * C::PXB + piece * 16;
+        a_rc[k] = pl < CPL ? (row | (col << 8)) : 0x7f7f7f;
     }
-    auto tile_base = [&](const DmaTile &t) {       // chunk 0's plane at the footprint's first pixel (may lie outside the tensor)
-        return in_b + (long long)t.img * nchunk * plane + ((long long)(t.oy0 - C::PAD) * p.W + (t.ox0 - C::PAD)) * C::PXB;
+    auto tile_base = [&](const DmaTile &t) {       // chunk 0's first plane at the footprint's first pixel (may lie outside the tensor)
+        return in_b + (long long)t.img * nchunk * CPL * plane + ((long long)(t.oy0 - C::PAD) * p.W + (t.ox0 - C::PAD)) * C::PXB;
     };
     auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {
         int rc = a_rc[k], off = a_off[k];
         asm volatile("" : "+v"(rc), "+v"(off));
         const unsigned iy = (unsigned)(t.oy0 - C::PAD + (rc & 0xff)), ix = (unsigned)(t.ox0 - C::PAD + (rc >> 8));
         const bool ok = t.valid && iy < (unsigned)p.H && ix < (unsigned)p.W;
-        const unsigned char *sp = ok ? tbase + (c * plane + off) : zero_lane;
+        const unsigned char *sp = ok ? tbase + ((long long)c * CPL * plane + off) : zero_lane;
         if constexpr (!(C::KO & 16)) vc_glds16<true>(sp, (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
     };
-    // weights of tile-unit g (>= upt: of the next tile): NB rounds of one KiB per wave, [nblk][chunk][unit][piece][n-tile] order;
+    // weights of tile-unit g (>= upt: of the next tile): one KiB per wave and round, [nblk][chunk][unit][piece][n-tile] order;
     // ring slot = (ring position of the tile's first unit + g) mod RING
     const unsigned lane16 = 16 * lane;
     unsigned gbase = 0;
@@ -203,8 +261,10 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
         const unsigned char *sbase = wpk + ((long long)nblk * upt + gg) * (C::FRAGS * 1024) + wave * 1024;
         const unsigned dst = C::B_OFF + ((gbase + (unsigned)g) % RING) * C::SLOTB + wave * 1024;
 #pragma unroll
-        for (int r = 0; r < NB; ++r)
-            if constexpr (!(C::KO & 16)) vc_glds16_sbase(sbase + r * 8192, lane16, dst + r * 8192);
+        for (int r = 0; r < C::ROUNDS; ++r)
+            if constexpr (!(C::KO & 16)) {
+                if (r + 1 < C::ROUNDS || !C::EXACT || grp == 0) vc_glds16_sbase(sbase + r * 8192, lane16, dst + r * 8192);
+            }
     };
 
     // ---- prologue: bias, first chunk image, weights of the first D units ----
@@ -219,18 +279,25 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
     vc_wait_vmcnt<0>();
     __syncthreads();
 
-    // ---- per-lane LDS read offsets: pixel (2 wave, px) + the k-group's tap offset of each unit class ----
-    int a_lane[UN::NCLS];
+    // ---- per-lane LDS read offsets: the M-tile's pixel + the tap offset (and plane) of the lane's k-group, per unit class.  With an
+    // even WM the M-tiles of a wave sit at compile-time offsets from its first one (immediates); with WM = 3 each has its own base ----
+    constexpr bool TIMM = (WM % 2 == 0);
+    const int qtap = q / CPL, qpl = q % CPL;
+    int a_lane[UN::NCLS][TIMM ? 1 : WM];
 #pragma unroll
     for (int c = 0; c < UN::NCLS; ++c) {
         int dy = 0, dx = 0;
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-            if (q == qq) {
+        for (int qq = 0; qq < UN::TPU; ++qq)
+            if (qtap == qq) {
                 dy = UN::dy(c, qq);
                 dx = UN::dx(c, qq);
             }
-        a_lane[c] = ((2 * wave + dy) * C::COLS + px + dx) * C::PXB;
+#pragma unroll
+        for (int t = 0; t < (TIMM ? 1 : WM); ++t) {
+            const int m = WM * wave + t;
+            a_lane[c][t] = (((m >> 1) + dy) * C::COLS + 16 * (m & 1) + px + dx) * C::PXB + qpl * C::PLANE_B;
+        }
     }
     const int b_lane = C::B_OFF + lane * 16;
 
@@ -256,14 +323,17 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
                 constexpr int cl = UN::cls(u);
                 // -- R: this unit's fragments, LDS -> registers --
                 const int bslot = b_lane + (int)((gbase + (unsigned)(g0 + u)) % RING) * C::SLOTB;
-                const int ab = a_lane[cl] + abuf;
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
                     for (int n = 0; n < WN; ++n) bf[pc][n] = *reinterpret_cast<const f32x4 *>(lds8 + bslot + (pc * WN + n) * 1024);
 #pragma unroll
-                    for (int t = 0; t < WM; ++t)
-                        af[pc][t] = *reinterpret_cast<const f32x4 *>(lds8 + ab + (((t >> 1) + UN::ky0(u)) * C::COLS + 16 * (t & 1) + UN::kx0(u)) * C::PXB + 16 * pc);
+                    for (int t = 0; t < WM; ++t) {
+                        const int ab = a_lane[cl][TIMM ? 0 : t] + abuf;
+                        constexpr int unit_imm = (UN::ky0(u) * C::COLS + UN::kx0(u)) * C::PXB;
+                        const int t_imm = TIMM ? ((t >> 1) * C::COLS + 16 * (t & 1)) * C::PXB : 0;
+                        af[pc][t] = *reinterpret_cast<const f32x4 *>(lds8 + ab + unit_imm + t_imm + 16 * pc);
+                    }
                 }
                 // -- DMA of later phases: a piece of the next chunk image, then the weights of unit g + D --
                 static_for<0, NA>([&](auto kc) {
@@ -277,7 +347,11 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
                 // -- this wave's part of the next unit's weights (and everything older) has landed --
                 // (first phase of a tile: the previous tile's epilogue stores lie between; waiting for them too costs one store
                 //  drain per tile)
-                if constexpr (!(C::KO & 2)) vc_wait_vmcnt<C::nwait(u)>();
+                if constexpr (!(C::KO & 2)) {
+                    if constexpr (C::nwait(u, 0) == C::nwait(u, 1)) vc_wait_vmcnt<C::nwait(u, 0)>();
+                    else if (grp == 0) vc_wait_vmcnt<C::nwait(u, 0)>();
+                    else vc_wait_vmcnt<C::nwait(u, 1)>();
+                }
                 VC_DMA_BARRIER();
                 // -- M: 9 x WM x WN MFMAs while the other group reads; smallest products first --
                 if constexpr (!(C::KO & 4)) {
@@ -318,7 +392,8 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
             float *const dump = reinterpret_cast<float *>(g_vc_dma_dump) + 4 * lane;
 #pragma unroll
             for (int t = 0; t < WM; ++t) {
-                const int oy = cur.oy0 + 2 * wave + (t >> 1), ox = cur.ox0 + 16 * (t & 1) + px;
+                const int m = WM * wave + t;
+                const int oy = cur.oy0 + (m >> 1), ox = cur.ox0 + 16 * (m & 1) + px;
                 const bool pix_ok = oy < p.Ho && ox < p.Wo;
 #pragma unroll
                 for (int n = 0; n < WN; ++n) {
@@ -326,8 +401,14 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
                     const bool ok = pix_ok && co < p.Cout;
                     f32x4 v = acc[t][n];
                     f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                    // nn.PixelShuffle(2) fused into the store (the packed output channels are permuted so that 4 consecutive ones share a position)
+                    const bool ps = p.out_mode != VC_OUT_PLAIN;
+                    const int cps = p.Cout >> 2;
+                    const int pos = ps ? co / cps : 0;
+                    const int cch = ps ? co - pos * cps : co;
+                    const int yy = ps ? 2 * oy + (pos >> 1) : oy, xx = ps ? 2 * ox + (pos & 1) : ox;
                     if (p.res) {
-                        const long long r_off = (long long)cur.img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + co;
+                        const long long r_off = (long long)cur.img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
                         if (ok) r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
                     }
                     if (p.res_first) v += r;
@@ -344,14 +425,15 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
                         const u32x2 ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
                         const u32x2 pm = {(m[0] >> 16) | (m[1] & 0xffff0000u), (m[2] >> 16) | (m[3] & 0xffff0000u)};
                         const u32x2 pl = {(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+                        const int oc = ps ? cps : p.Cout, oh = ps ? 2 * p.Ho : p.Ho, ow = ps ? 2 * p.Wo : p.Wo;
                         unsigned char *o8 = reinterpret_cast<unsigned char *>(p.out) +
-                                            ((((long long)cur.img * (p.Cout >> 3) + (co >> 3)) * p.Ho + oy) * p.Wo + ox) * 48 + (co & 4) * 2;
+                                            ((((long long)cur.img * (oc >> 3) + (cch >> 3)) * oh + yy) * ow + xx) * 48 + (cch & 4) * 2;
                         unsigned char *dst = ok ? o8 : reinterpret_cast<unsigned char *>(dump);
                         *reinterpret_cast<u32x2 *>(dst) = ph;
                         *reinterpret_cast<u32x2 *>(dst + (ok ? 16 : 0)) = pm;
                         *reinterpret_cast<u32x2 *>(dst + (ok ? 32 : 0)) = pl;
                     } else {
-                        const long long o_off = (long long)cur.img * p.out_sn + (long long)oy * p.out_sh + (long long)ox * p.out_sw + co;
+                        const long long o_off = (long long)cur.img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
                         float *dst = ok ? p.out + o_off : dump;
                         *reinterpret_cast<f32x4 *>(dst) = v;
                     }

@@ -29,49 +29,64 @@ static inline void split3_host(float x, unsigned short pc[3])
     pc[2] = bf16_trunc_bits(r2);
 }
 
-template <int K> static int units_of() { return SplitUnits<K>::U; }
-static int split_units(int k) { return k == 7 ? units_of<7>() : (k == 5 ? units_of<5>() : (k == 3 ? units_of<3>() : 0)); }
-static int split_block(int cout) { return (cout % 64 == 0) ? 64 : ((cout % 32 == 0) ? 32 : 0); }
+// (K, planes per chunk) of the instance that serves a kernel size: 5x5 / 7x7 walk one 8-channel plane per chunk, 3x3 two
+static int split_cpl(int k) { return k == 3 ? 2 : ((k == 5 || k == 7) ? 1 : 0); }
+static int split_units(int k)
+{
+    return k == 7 ? SplitUnits<7>::U : (k == 5 ? SplitUnits<5>::U : (k == 3 ? SplitPairs<3>::U : 0));
+}
+static int split_block(int cout, int k)
+{
+    if (k == 3) return (cout % 64 == 0) ? 64 : 0;
+    return (cout % 64 == 0) ? 64 : ((cout % 32 == 0) ? 32 : 0);
+}
 
 extern "C" size_t vc_conv_packed_weight_bytes_split(int cout, int cin, int k)
 {
-    const int u = split_units(k), bn = split_block(cout);
-    if (!u || !bn || (cin % 8)) return 0;
-    // [n-block][chunk][unit][piece][n-tile][lane][8] bf16 + one ring slot of slack (the last DMA round of a unit over-reads)
-    return (size_t)(cout / bn) * (cin / 8) * u * 3 * (bn / 16) * 1024 + 16384;
+    const int u = split_units(k), bn = split_block(cout, k), cpl = split_cpl(k);
+    if (!u || !bn || !cpl || (cin % (8 * cpl))) return 0;
+    // [n-block][chunk][unit][piece][n-tile][lane][8] bf16 + slack (the last DMA round of a unit may over-read)
+    return (size_t)(cout / bn) * (cin / (8 * cpl)) * u * 3 * (bn / 16) * 1024 + 16384;
 }
 
-template <int K> static void pack_split(const float *w, int cout, int cin, int bn, unsigned short *dst)
+template <class UN, int K, int CPL> static void pack_split(const float *w, int cout, int cin, int bn, int ps, unsigned short *dst)
 {
-    typedef SplitUnits<K> UN;
-    const int ntw = bn / 16, nchunk = cin / 8;
+    const int ntw = bn / 16, nchunk = cin / (8 * CPL), cps = cout / 4;
     for (int nb = 0; nb < cout / bn; ++nb)
         for (int c = 0; c < nchunk; ++c)
             for (int u = 0; u < UN::U; ++u) {
                 unsigned short *unit = dst + (((size_t)nb * nchunk + c) * UN::U + u) * (3 * ntw * 512);
                 for (int n = 0; n < ntw; ++n)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const int co = nb * bn + 16 * n + (lane & 15), q = lane >> 4;
+                        const int cop = nb * bn + 16 * n + (lane & 15), q = lane >> 4;
+                        const int co = ps ? (cop % cps) * 4 + cop / cps : cop;      // (packed -> module order, as vc_conv_pack_weights)
+                        const int tap = q / CPL, pl = q % CPL;
                         for (int j = 0; j < 8; ++j) {
                             unsigned short pc[3] = {0, 0, 0};
-                            if (UN::valid(u, q)) split3_host(w[(((size_t)co * cin + 8 * c + j) * K + UN::ky(u, q)) * K + UN::kx(u, q)], pc);
+                            if (UN::valid(u, tap))
+                                split3_host(w[(((size_t)co * cin + (c * CPL + pl) * 8 + j) * K + UN::ky(u, tap)) * K + UN::kx(u, tap)], pc);
                             for (int piece = 0; piece < 3; ++piece) unit[((piece * ntw + n) * 64 + lane) * 8 + j] = pc[piece];
                         }
                     }
             }
 }
 
-extern "C" int vc_conv_pack_weights_split(const float *w, const float *bias, int cout, int cin, int k, void *wpk_out, float *bias_out)
+extern "C" int vc_conv_pack_weights_split(const float *w, const float *bias, int cout, int cin, int k, int pixelshuffle, void *wpk_out,
+                                          float *bias_out)
 {
     const size_t bytes = vc_conv_packed_weight_bytes_split(cout, cin, k);
-    if (!w || !wpk_out || !bias_out || !bytes) return VC_EINVAL;
+    if (!w || !wpk_out || !bias_out || !bytes || (pixelshuffle && (cout % 16))) return VC_EINVAL;
     memset(wpk_out, 0, bytes);
     unsigned short *dst = static_cast<unsigned short *>(wpk_out);
-    const int bn = split_block(cout);
-    if (k == 7) pack_split<7>(w, cout, cin, bn, dst);
-    else if (k == 5) pack_split<5>(w, cout, cin, bn, dst);
-    else pack_split<3>(w, cout, cin, bn, dst);
-    for (int c = 0; c < cout; ++c) bias_out[c] = bias ? bias[c] : 0.0f;
+    const int bn = split_block(cout, k);
+    if (k == 7) pack_split<SplitUnits<7>, 7, 1>(w, cout, cin, bn, pixelshuffle, dst);
+    else if (k == 5) pack_split<SplitUnits<5>, 5, 1>(w, cout, cin, bn, pixelshuffle, dst);
+    else pack_split<SplitPairs<3>, 3, 2>(w, cout, cin, bn, pixelshuffle, dst);
+    const int cps = cout / 4;
+    for (int cop = 0; cop < cout; ++cop) {
+        const int co = pixelshuffle ? (cop % cps) * 4 + cop / cps : cop;
+        bias_out[cop] = bias ? bias[co] : 0.0f;
+    }
     return VC_OK;
 }
 
@@ -120,16 +135,20 @@ extern "C" int vc_split3(vc_stream s, vc_view a, void *out_split)
 
 int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
 {
-    if (stride != 1 || !a.in_sp3 || a.in_f16 || a.out_f16 || a.res_f16 || a.tail_wpk || a.epi != VC_EPI_NONE || a.in_xform != VC_IN_NONE ||
-        a.out_mode != VC_OUT_PLAIN || (a.Cin % 8) || a.act == VC_ACT_SIGMOID || a.act == VC_ACT_CLAMP01)
+    const int cpl = split_cpl(k);
+    if (stride != 1 || !cpl || !a.in_sp3 || a.in_f16 || a.out_f16 || a.res_f16 || a.tail_wpk || a.epi != VC_EPI_NONE || a.in_xform != VC_IN_NONE ||
+        (a.Cin % (8 * cpl)) || a.act == VC_ACT_SIGMOID || a.act == VC_ACT_CLAMP01)
         return VC_EINVAL;
-    const int bn = split_block(a.Cout);
+    const int bn = split_block(a.Cout, k);
     if (!bn) return VC_EINVAL;
-    if (a.out_sp3 ? (a.Cout % 8 != 0) : !a.vec_out) return VC_EINVAL;
-    // per-lane source offsets are 32-bit: a tile's footprint inside one plane must stay below 2 GiB
-    if ((long long)(k + 15) * a.W * 48 + 48ll * 48 >= (1ll << 31)) return VC_EINVAL;
+    const int cpp = a.out_mode == VC_OUT_PLAIN ? a.Cout : a.Cout / 4;       // channels per output pixel
+    if (a.out_mode != VC_OUT_PLAIN && (a.Cout % 16)) return VC_EINVAL;     // (4 consecutive packed channels share a shuffle position)
+    if (a.out_sp3 ? (cpp % 8 != 0) : !a.vec_out) return VC_EINVAL;
+    // per-lane source offsets are 32-bit: the planes of a chunk and a tile's footprint inside them must stay below 2 GiB
+    if ((long long)cpl * a.H * a.W * 48 + (long long)(k + 15) * a.W * 48 + 48ll * 48 >= (1ll << 31)) return VC_EINVAL;
+    const int th = k == 3 ? 12 : 16;
     a.tiles_x = (a.Wo + 31) / 32;
-    a.tiles_y = (a.Ho + 15) / 16;
+    a.tiles_y = (a.Ho + th - 1) / th;
     a.nblks = a.Cout / bn;
     a.total_blocks = a.tiles_x * a.tiles_y * a.nblks * a.N;
 #ifdef VC_SPLIT_DIAG
@@ -138,16 +157,17 @@ int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
         const int v = e ? atoi(e) : 0;
         if (k == 7 && bn == 64) {
             switch (v) {
-            case 1: return launch_conv_split<SplitCfg<7, 4, 4, 1>>(st, a);
-            case 4: return launch_conv_split<SplitCfg<7, 4, 4, 4>>(st, a);
-            case 16: return launch_conv_split<SplitCfg<7, 4, 4, 16>>(st, a);
-            case 17: return launch_conv_split<SplitCfg<7, 4, 4, 17>>(st, a);
-            case 21: return launch_conv_split<SplitCfg<7, 4, 4, 21>>(st, a);
+            case 1: return launch_conv_split<SplitCfg<7, 4, 1, 16, 4, 1>>(st, a);
+            case 4: return launch_conv_split<SplitCfg<7, 4, 1, 16, 4, 4>>(st, a);
+            case 16: return launch_conv_split<SplitCfg<7, 4, 1, 16, 4, 16>>(st, a);
+            case 17: return launch_conv_split<SplitCfg<7, 4, 1, 16, 4, 17>>(st, a);
+            case 21: return launch_conv_split<SplitCfg<7, 4, 1, 16, 4, 21>>(st, a);
             }
         }
     }
 #endif
     if (k == 7) return bn == 64 ? launch_conv_split<SplitCfg<7, 4>>(st, a) : launch_conv_split<SplitCfg<7, 2>>(st, a);
     if (k == 5) return bn == 64 ? launch_conv_split<SplitCfg<5, 4>>(st, a) : launch_conv_split<SplitCfg<5, 2>>(st, a);
+    if (k == 3) return launch_conv_split<SplitCfg<3, 4, 2, 12>>(st, a);
     return VC_EINVAL;
 }

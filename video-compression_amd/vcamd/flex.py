@@ -71,7 +71,7 @@ class UNet(_Prepared):
             raise hip.VcError("UNet input must be divisible by 2^(depth-1) (the reference pads frames to x64)")
         cats = []
         for i, (c1, c2) in enumerate(p["down"]):
-            t = c1(x, act=hip.ACT_LRELU, slope=0.1, out_f16=c2.half_ok)
+            t = c1(x, act=hip.ACT_LRELU, slope=0.1, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x))
             if i != len(p["down"]) - 1:
                 c = c2.cout
                 cat = T.empty(x.n, t.h, t.w, 2 * c, dev)           # [up(c) | skip(c)]
@@ -84,7 +84,7 @@ class UNet(_Prepared):
         for i, (cu, c1, c2) in enumerate(p["up"]):
             cat = cats[-i - 1]
             cu(hip.upsample_bilinear(x, 2), out=cat.channels(0, cu.cout))
-            x = c2(c1(cat, act=hip.ACT_LRELU, slope=0.1, out_f16=c2.half_ok), act=hip.ACT_LRELU, slope=0.1)
+            x = c2(c1(cat, act=hip.ACT_LRELU, slope=0.1, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, cat)), act=hip.ACT_LRELU, slope=0.1)
         return p["last"](x, act=final_act)
 
     def forward(self, x):

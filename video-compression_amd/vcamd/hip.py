@@ -130,7 +130,7 @@ def lib():
     sig("vc_conv_pack_tail_f16", ci, vp, vp, ci, ci, vp, vp)
     sig("vc_conv2d_nhwc", ci, vp, ctypes.POINTER(ConvDesc))
     sig("vc_conv_packed_weight_bytes_split", sz, ci, ci, ci)
-    sig("vc_conv_pack_weights_split", ci, vp, vp, ci, ci, ci, vp, vp)
+    sig("vc_conv_pack_weights_split", ci, vp, vp, ci, ci, ci, ci, vp, vp)
     sig("vc_split3", ci, vp, View, vp)
     sig("vc_nchw_to_nhwc", ci, vp, vp, View)
     sig("vc_nhwc_to_nchw", ci, vp, View, vp)
@@ -368,6 +368,13 @@ def fp32_mode():
     return _FP32_MODE
 
 
+def wants_split(pc, x, h=None, w=None):
+    """Will the layer ``pc`` run on the split-operand pipeline for an input of x's batch at h x w (default: x's own size)?  The hint
+    a producer needs to leave its result as a split tensor (``out_sp3``)."""
+    return (_FP32_MODE == "split" and pc is not None and pc.split_ok
+            and pc.split_pays(x.n, x.h if h is None else h, x.w if w is None else w))
+
+
 def split3(x, out=None):
     """fp32 channels-last window -> split tensor (three bf16 pieces per value, exact): the input format of CFG_SPLIT layers."""
     if out is None:
@@ -416,7 +423,9 @@ class PackedConv:
         self.tuned = {}
         self._tail = None
         self._wsplit = None
-        self._raw32 = (wnp, bnp) if (kh in (5, 7) and stride == 1 and cin % 8 == 0 and cout % 32 == 0 and not pixelshuffle) else None
+        split_shape = stride == 1 and ((kh in (5, 7) and cin % 8 == 0 and cout % 32 == 0 and not pixelshuffle) or
+                                       (kh == 3 and cin % 16 == 0 and cout % 64 == 0 and (not pixelshuffle or cout % 32 == 0)))
+        self._raw32 = (wnp, bnp) if split_shape else None
         self._raw = (wnp, bnp) if (_PRECISION == "fp16" and kh == 1 and stride == 1 and cout == cin and cin in (64, 128) and not pixelshuffle) else None
         self._device = device
         ck = L.vc_conv_chunk(self.cfg, kh, stride, cin)
@@ -488,7 +497,8 @@ class PackedConv:
         instances with their 8-row tiles and several workgroups per CU are faster.  Decided per IMAGE, never by the batch: a
         frame must get the same bits whether it is coded alone or in a level-batched pass."""
         bn = 64 if self.cout % 64 == 0 else 32
-        return ((h + 15) // 16) * ((w + 31) // 32) * (self.cout // bn) >= 48
+        th = 12 if self.k == 3 else 16
+        return ((h + th - 1) // th) * ((w + 31) // 32) * (self.cout // bn) >= 48
 
     def split_pack(self):
         if self._wsplit is None:
@@ -501,7 +511,7 @@ class PackedConv:
             w = np.zeros(nbytes // 2, dtype=np.int16)
             b = np.empty(self.cout, dtype=np.float32)
             check(lib().vc_conv_pack_weights_split(wnp.ctypes.data, None if bnp is None else bnp.ctypes.data, self.cout, self.cin, self.k,
-                                                   w.ctypes.data, b.ctypes.data), "vc_conv_pack_weights_split")
+                                                   int(self.ps), w.ctypes.data, b.ctypes.data), "vc_conv_pack_weights_split")
             self._wsplit = (torch.from_numpy(w).to(self._device), torch.from_numpy(b).to(self._device))
         return self._wsplit
 
@@ -564,7 +574,7 @@ class PackedConv:
         d.kh = d.kw = self.k
         d.stride = 1
         d.act, d.slope = act, slope
-        d.out_mode = OUT_PLAIN
+        d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
         d.cfg = CFG_SPLIT | CFG_EXACT | CFG_IN_SP3 | (CFG_OUT_SP3 if out.dtype == "sp3" else 0) | (CFG_RES_FIRST if res_first else 0)
         what = f"vc_conv2d_nhwc(split k={self.k},{self.cin}->{self.cout})"
         if timer is None:

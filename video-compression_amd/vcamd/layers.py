@@ -121,7 +121,7 @@ class ResidualBlockWithStride(_Prepared):
                             pack_conv(self.skip) if self.skip is not None else None)
         c1, c2, sk = self._packed
         t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok)
-        u = c2(t)
+        u = c2(t)                       # (fp32 mode "split": converts t itself -- the stride-2 layer in front is a native instance)
         identity = x if sk is None else sk(x)
         return self.gdn.run(u, res=identity)
 
@@ -140,9 +140,14 @@ class ResidualBlockUpsample(_Prepared):
             self._packed = (pack_conv(self.subpel_conv[0], pixelshuffle=True), pack_conv(self.conv),
                             pack_conv(self.upsample[0], pixelshuffle=True))
         sp, cv, up = self._packed
-        t = sp(x, act=hip.ACT_LRELU, slope=0.01, out_f16=cv.half_ok)   # LeakyReLU commutes with the pixel shuffle
+        # fp32 mode "split": both branches read ONE split copy of x; the sub-pixel layer hands its result on as a split tensor
+        xs = x
+        if x.dtype == "f32" and hip.wants_split(sp, x) and hip.wants_split(up, x):
+            xs = hip.split3(x)
+        t = sp(xs, act=hip.ACT_LRELU, slope=0.01, out_f16=cv.half_ok,   # LeakyReLU commutes with the pixel shuffle
+               out_sp3=hip.wants_split(cv, x, 2 * x.h, 2 * x.w))
         u = cv(t)
-        identity = up(x)
+        identity = up(xs)
         return self.igdn.run(u, res=identity)
 
 
@@ -159,7 +164,7 @@ class ResidualBlock(_Prepared):
             self._packed = (pack_conv(self.conv1), pack_conv(self.conv2),
                             pack_conv(self.skip) if self.skip is not None else None)
         c1, c2, sk = self._packed
-        t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok)
+        t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x))
         identity = x if sk is None else sk(x)
         return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity)
 
@@ -282,8 +287,11 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
             act = final_act
         # a result consumed by the next convolution alone (or by a bottleneck block that keeps its identity as half) may be
         # kept as half on the fp16 path
+        nxt_pk = pack_of(mods[i + 1]) if (not last and isinstance(mods[i + 1], (nn.Conv2d, nn.ConvTranspose2d, nn.Sequential))) else None
+        ho, wo, _ = pk.out_shape(x.h, x.w)
         x = pk(x, act=act, slope=slope, chscale=final_chscale if last else None, out=out if last else None,
-               out_f16=bool(not last and takes_half(mods[i + 1])))
+               out_f16=bool(not last and takes_half(mods[i + 1])),
+               out_sp3=bool(nxt_pk is not None and hip.wants_split(nxt_pk, x, ho, wo)))
         i += 1
     return x
 
