@@ -127,6 +127,12 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
  * Produced by vc_split3 or by the VC_CFG_OUT_SP3 epilogue of the layer in front (a chain of split layers never converts). */
 #define VC_CFG_IN_SP3 0x8000
 #define VC_CFG_OUT_SP3 0x10000
+/* VC_CFG_OUT_SP3 is also accepted by the classic fp32 configurations (N128 / N64 / N32 / N16 / N128B / N32T16, channels per output
+ * pixel a multiple of 8): the layer in front of a split consumer writes the three pieces itself (stride-2 / 1x1 / GDN layers).
+ * VC_CFG_RES_SP3 (VC_CFG_SPLIT only): `res` is a split tensor laid out like the output -- the identity of a residual block whose
+ * input is a split tensor; its pieces sum to the exact fp32 value.  The image strides of split tensors (in.sn / out.sn / res_sn)
+ * count BYTES, 0 = dense: a window of planes inside a wider split tensor passes its parent's image size. */
+#define VC_CFG_RES_SP3 0x20000
 typedef struct {
     vc_view in;            /* [n,h,w,cin] */
     vc_view out;           /* [n,ho,wo,cout]  (PIXELSHUFFLE2: [n,2ho,2wo,cout/4]) */
@@ -173,7 +179,7 @@ size_t vc_conv_packed_weight_bytes_split(int cout, int cin, int k);
 int vc_conv_pack_weights_split(const float *w_oihw, const float *bias, int cout, int cin, int k, int pixelshuffle, void *wpk_out,
                                float *bias_out);
 /* fp32 channels-last window (c % 8 == 0, 16-byte aligned rows) -> dense split tensor, 6 bytes per element */
-int vc_split3(vc_stream s, vc_view in, void *out_split);
+int vc_split3(vc_stream s, vc_view in, void *out_split, long long out_image_bytes /* 0 = dense */);
 int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d);
 
 /* ------------------------------------------------------------------------------------------

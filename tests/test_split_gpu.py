@@ -79,10 +79,7 @@ def test_split_tensor_is_exact_and_a_split_chain_never_converts(dev):
     x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-30, -3e38, 1.0, 2.0 ** -120, 1.0 + 2.0 ** -23, -(2.0 - 2.0 ** -23)])
     xt = hip.nchw_to_nhwc(x.to(dev))
     sp = hip.split3(xt)
-    rec = sp.buf.view(1, 2, 40, 72, 3, 8).to(torch.int32)          # [n][c/8][h][w][piece][8] bf16 bits
-    pieces = (rec << 16).view(torch.float32)
-    back = (pieces[..., 2, :] + pieces[..., 1, :]) + pieces[..., 0, :]          # exact: each partial sum is representable
-    back = back.permute(0, 1, 4, 2, 3).reshape(1, 16, 40, 72).cpu()
+    back = _unsplit(sp)
     assert torch.equal(back, x)
     hip.set_fp32_mode("split")
     wt1, b1, p1 = _layer(32, 64, 7, 6, dev)
@@ -154,3 +151,56 @@ def test_lhbdc_forward_split_and_native_code_the_same_integers(dev):
     flips = {k: int((out["native"][2][k] != out["split"][2][k]).sum()) for k in out["native"][2]}
     print(f"LHBDC 256x384 native vs split: x_hat max|d| {d:.2e}, symbols differing {flips}")
     assert sum(flips.values()) <= 1 and (d < 1e-4 or sum(flips.values()) == 1)
+
+
+def _unsplit(t):
+    """split tensor window -> NCHW fp32 (exact: (lo + mid) + hi)"""
+    full = t.buf.view(-1)[: t.buf.numel()]
+    n, h, w, c = t.n, t.h, t.w, t.c
+    per_img = t.sn * h * w * 24                     # int16 elements per image of the underlying buffer
+    out = torch.empty(n, c, h, w)
+    for i in range(n):
+        start = i * per_img + t.off * h * w * 24
+        rec = full[start:start + (c // 8) * h * w * 24].view(c // 8, h, w, 3, 8).to(torch.int32)
+        pieces = (rec << 16).view(torch.float32)
+        v = (pieces[..., 2, :] + pieces[..., 1, :]) + pieces[..., 0, :]
+        out[i] = v.permute(0, 3, 1, 2).reshape(c, h, w).cpu()
+    return out
+
+
+def test_native_layers_write_split_tensors_and_split_layers_add_split_residuals(dev):
+    """fp32 mode "split": the classic fp32 instances in front of a split consumer (stride-2 3x3, 1x1, GDN) write the three bf16
+    pieces themselves (CFG_OUT_SP3) -- exactly the fp32 values they would have stored; a split layer adds an identity that is a
+    split tensor (CFG_RES_SP3) exactly like the fp32 tensor of the same values; windows of planes inside a wider split tensor."""
+    from vcamd import hip
+    from vcamd.layers import GDN
+    hip.set_fp32_mode("split")
+    g = torch.Generator().manual_seed(21)
+    # (a) stride-2 3x3 128 -> 128, LeakyReLU: split output == fp32 output
+    wt, b, pc = _layer(128, 128, 3, 22, dev)
+    pc2 = hip.PackedConv(wt, b, stride=2, device=dev)
+    x = hip.T.empty(2, 96, 160, 128, dev)
+    x.buf.normal_()
+    y32 = hip.nhwc_to_nchw(pc2(x, act=hip.ACT_LRELU, slope=0.01)).cpu()
+    ysp = pc2(x, act=hip.ACT_LRELU, slope=0.01, out_sp3=True)
+    assert ysp.dtype == "sp3" and torch.equal(_unsplit(ysp), y32)
+    # (b) GDN on the classic 1x1 instance, split output, with a residual
+    gdn = GDN(128).to(dev)
+    r = hip.T.empty(2, 96, 160, 128, dev)
+    r.buf.normal_()
+    z32 = hip.nhwc_to_nchw(gdn.run(x, res=r)).cpu()
+    zsp = gdn.run(x, res=r, out_sp3=True)
+    assert zsp.dtype == "sp3" and torch.equal(_unsplit(zsp), z32)
+    # (c) a split layer with a split residual == the same with the fp32 residual; split input window of a wider split tensor
+    xs_wide = hip.T.empty(2, 96, 160, 256, dev, "sp3")
+    hip.split3(x, out=xs_wide.channels(128, 256))
+    hip.split3(r, out=xs_wide.channels(0, 128))
+    a = hip.nhwc_to_nchw(pc(xs_wide.channels(128, 256), act=hip.ACT_LRELU, slope=0.01, res=xs_wide.channels(0, 128)))
+    bb = hip.nhwc_to_nchw(pc(x, act=hip.ACT_LRELU, slope=0.01, res=r))
+    assert torch.equal(a, bb)
+    # (d) split OUTPUT into a window of planes
+    o_wide = hip.T.empty(2, 96, 160, 256, dev, "sp3")
+    o_wide.buf.zero_()
+    pc(x, act=hip.ACT_LRELU, slope=0.01, out=o_wide.channels(128, 256))
+    assert torch.equal(_unsplit(o_wide.channels(128, 256)), hip.nhwc_to_nchw(pc(x, act=hip.ACT_LRELU, slope=0.01)).cpu())
+    assert float(_unsplit(o_wide.channels(0, 128)).abs().max()) == 0.0

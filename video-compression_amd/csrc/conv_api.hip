@@ -217,7 +217,16 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     a.tail_bias = d->tail_bias;
     a.in_sp3 = (d->cfg & VC_CFG_IN_SP3) ? 1 : 0;
     a.out_sp3 = (d->cfg & VC_CFG_OUT_SP3) ? 1 : 0;
-    if ((a.in_sp3 || a.out_sp3) && (d->cfg & 0xff) != VC_CFG_SPLIT) return VC_EINVAL;       // split tensors are private to the split path
+    a.res_sp3 = (d->cfg & VC_CFG_RES_SP3) ? 1 : 0;
+    {
+        // split tensors: read (input, residual) by the split pipeline only; WRITTEN by it and by the classic fp32 instances (the
+        // layer in front of a split consumer: stride-2 / 1x1 / GDN layers), plain or pixel-shuffled, 16-byte epilogue accesses
+        const int c0 = d->cfg & 0xff;
+        const bool classic = c0 == VC_CFG_N128 || c0 == VC_CFG_N64 || c0 == VC_CFG_N32 || c0 == VC_CFG_N16 || c0 == VC_CFG_N128B || c0 == VC_CFG_N32T16;
+        if ((a.in_sp3 || a.res_sp3) && c0 != VC_CFG_SPLIT) return VC_EINVAL;
+        if (a.out_sp3 && c0 != VC_CFG_SPLIT && (!classic || f16 || (d->out.c % 8))) return VC_EINVAL;
+        if (a.out_sp3 && c0 != VC_CFG_SPLIT && !a.out_sn) a.out_sn = (long long)(d->out.c / 8) * d->out.h * d->out.w * 48;
+    }
     if (a.tail_wpk && (!f16 || (d->cfg & 0xff) != VC_CFG_DMA)) return VC_EINVAL;             // the fused tail lives in the LDS-DMA kernel
     // a half-precision residual: the streaming 1x1 kernel, or the LDS-DMA kernel's fused-tail epilogue
     if (a.res_f16 && (!f16 || !d->res || !((d->cfg & 0xff) == VC_CFG_PWS || ((d->cfg & 0xff) == VC_CFG_DMA && a.tail_wpk)))) return VC_EINVAL;
@@ -257,10 +266,12 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
             return !ptr || (((uintptr_t)ptr % 16) == 0 && (sn % 4) == 0 && (sh % 4) == 0 && (sw % 4) == 0);
         };
         const int cgrp = (d->out_mode == VC_OUT_PIXELSHUFFLE2) ? (a.Cout >> 2) : a.Cout;   // channels per output pixel
-        a.vec_out = (cgrp % 4) == 0 && ok(a.out, a.out_sn, a.out_sh, a.out_sw) && ok(a.res, a.res_sn, a.res_sh, a.res_sw) &&
+        a.vec_out = (cgrp % 4) == 0 && (a.out_sp3 ? ((uintptr_t)a.out % 16) == 0 : ok(a.out, a.out_sn, a.out_sh, a.out_sw)) &&
+                    (a.res_sp3 ? ((uintptr_t)a.res % 8) == 0 : ok(a.res, a.res_sn, a.res_sh, a.res_sw)) &&
                     ok(a.mul, a.mul_sn, a.mul_sh, a.mul_sw) && ok(a.chscale, 0, 0, 0);
     }
     if (a.total_blocks <= 0) return VC_EINVAL;
+    if (a.out_sp3 && !a.vec_out) return VC_EINVAL;     // the split store is a 16-byte-group epilogue
     if (f16 && !a.vec4) return VC_EINVAL;   // the fp16 staging path reads 2 x 16 bytes per item
     hipStream_t stream = as_stream(s);
     if (cfg == VC_CFG_PW) {                 // streaming 1x1 kernel: only ever chosen explicitly (autotuner)

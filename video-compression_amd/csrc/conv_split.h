@@ -175,18 +175,6 @@ template <int K_, int NTW_, int CPL_ = 1, int TH_ = 16, int RING_ = 4, int KO_ =
     static_assert(D >= 1 && nwait(U - 1, 0) <= 63, "vmcnt is a 6-bit counter");
 };
 
-// bf16 pieces of an fp32 value by truncation: hi = top 16 bits, the remainder x - hi is exact, and so on; lo is exact (<= 8 bits left)
-__device__ __forceinline__ void vc_split3(float x, unsigned &h, unsigned &m, unsigned &l)
-{
-    const unsigned ux = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
-    const float r1 = x - __builtin_bit_cast(float, ux);
-    const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-    const float r2 = r1 - __builtin_bit_cast(float, um);
-    h = ux;
-    m = um;
-    l = __builtin_bit_cast(unsigned, r2);
-}
-
 template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(const ConvArgs p)
 {
     typedef typename C::UN UN;
@@ -241,7 +229,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
         a_rc[k] = pl < CPL ? (row | (col << 8)) : 0x7f7f7f;
     }
     auto tile_base = [&](const DmaTile &t) {       // chunk 0's first plane at the footprint's first pixel (may lie outside the tensor)
-        return in_b + (long long)t.img * nchunk * CPL * plane + ((long long)(t.oy0 - C::PAD) * p.W + (t.ox0 - C::PAD)) * C::PXB;
+        return in_b + (long long)t.img * p.in_sn + ((long long)(t.oy0 - C::PAD) * p.W + (t.ox0 - C::PAD)) * C::PXB;
     };
     auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {
         int rc = a_rc[k], off = a_off[k];
@@ -389,7 +377,8 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
         // ---- epilogue: lane = pixel, 4 consecutive channels per accumulator: one 16-byte access per (M-tile, N-tile) ----
         if constexpr (!(C::KO & 1)) {
             const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
-            float *const dump = reinterpret_cast<float *>(g_vc_dma_dump) + 4 * lane;
+            // (stores of pixels / channels outside the output are simply masked: the counted waits of this kernel count DMA only --
+            //  an uncounted younger store makes a wait longer, never shorter)
 #pragma unroll
             for (int t = 0; t < WM; ++t) {
                 const int m = WM * wave + t;
@@ -407,7 +396,10 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
                     const int pos = ps ? co / cps : 0;
                     const int cch = ps ? co - pos * cps : co;
                     const int yy = ps ? 2 * oy + (pos >> 1) : oy, xx = ps ? 2 * ox + (pos & 1) : ox;
-                    if (p.res) {
+                    if (p.res_sp3) {                 // the identity kept as a split tensor: its three pieces sum to the exact fp32 value
+                        if (ok) r = vc_load_split4(reinterpret_cast<const unsigned char *>(p.res) + (long long)cur.img * p.res_sn +
+                                                       ((((long long)(cch >> 3)) * (ps ? 2 * p.Ho : p.Ho) + yy) * (ps ? 2 * p.Wo : p.Wo) + xx) * 48, (cch >> 2) & 1);
+                    } else if (p.res) {
                         const long long r_off = (long long)cur.img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
                         if (ok) r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
                     }
@@ -418,24 +410,13 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
                     if (p.res && !p.res_first) v += r;
                     if (p.out_sp3) {
                         // split output for a VC_CFG_SPLIT consumer: 3 x 8 bytes (4 channels of one piece) into the pixel's 48-byte record
-                        unsigned h[4], m[4], l[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) vc_split3(v[e], h[e], m[e], l[e]);
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        const u32x2 ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-                        const u32x2 pm = {(m[0] >> 16) | (m[1] & 0xffff0000u), (m[2] >> 16) | (m[3] & 0xffff0000u)};
-                        const u32x2 pl = {(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
-                        const int oc = ps ? cps : p.Cout, oh = ps ? 2 * p.Ho : p.Ho, ow = ps ? 2 * p.Wo : p.Wo;
-                        unsigned char *o8 = reinterpret_cast<unsigned char *>(p.out) +
-                                            ((((long long)cur.img * (oc >> 3) + (cch >> 3)) * oh + yy) * ow + xx) * 48 + (cch & 4) * 2;
-                        unsigned char *dst = ok ? o8 : reinterpret_cast<unsigned char *>(dump);
-                        *reinterpret_cast<u32x2 *>(dst) = ph;
-                        *reinterpret_cast<u32x2 *>(dst + (ok ? 16 : 0)) = pm;
-                        *reinterpret_cast<u32x2 *>(dst + (ok ? 32 : 0)) = pl;
+                        const int oh = ps ? 2 * p.Ho : p.Ho, ow = ps ? 2 * p.Wo : p.Wo;
+                        unsigned char *o8 = reinterpret_cast<unsigned char *>(p.out) + (long long)cur.img * p.out_sn +
+                                            ((((long long)(cch >> 3)) * oh + yy) * ow + xx) * 48;
+                        if (ok) vc_store_split4(o8, (cch >> 2) & 1, v);
                     } else {
                         const long long o_off = (long long)cur.img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
-                        float *dst = ok ? p.out + o_off : dump;
-                        *reinterpret_cast<f32x4 *>(dst) = v;
+                        if (ok) *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
                     }
                 }
             }

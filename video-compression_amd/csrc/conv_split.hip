@@ -90,16 +90,22 @@ extern "C" int vc_conv_pack_weights_split(const float *w, const float *bias, int
     return VC_OK;
 }
 
-// fp32 channels-last window -> split tensor [n][c/8][h][w][3][8] bf16 (48 bytes per pixel and group of 8 channels)
-__global__ void k_split3(vc_view a, unsigned char *__restrict__ out)
+// fp32 channels-last window -> split tensor [n][c/8][h][w][3][8] bf16 (48 bytes per pixel and group of 8 channels).
+// PB consecutive lanes take PB consecutive planes of ONE pixel (a 32 PB-byte contiguous read), lanes PB apart consecutive pixels (each
+// plane receives 64 / PB consecutive 48-byte records per wave): whole lines on the read side, long runs on the write side.
+template <int PB> __global__ void k_split3(vc_view a, unsigned char *__restrict__ out, long long out_img_bytes)
 {
-    const int cg = a.c >> 3;
+    const int cg = a.c >> 3, nb = cg / PB;
     const long long per_plane = (long long)a.h * a.w;
     const long long total = (long long)a.n * cg * per_plane;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long pl = i / per_plane, pos = i - pl * per_plane;     // consecutive threads: consecutive pixels of one plane
-        const int n = (int)(pl / cg), g = (int)(pl - (long long)n * cg);
+        const int gi = (int)(i % PB);
+        long long t = i / PB;
+        const long long pos = t % per_plane;
+        t /= per_plane;
+        const int b = (int)(t % nb), n = (int)(t / nb);
+        const int g = b * PB + gi;
         const int y = (int)(pos / a.w), x = (int)(pos - (long long)y * a.w);
         const float *src = a.p + view_off(a, n, y, x) + 8 * g;
         const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
@@ -116,19 +122,28 @@ __global__ void k_split3(vc_view a, unsigned char *__restrict__ out)
             pm[e] = (m[2 * e] >> 16) | m[2 * e + 1];
             pl4[e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
         }
-        unsigned char *dst = out + i * 48;
+        unsigned char *dst = out + n * out_img_bytes + ((long long)g * per_plane + pos) * 48;
         *reinterpret_cast<u32x4 *>(dst) = ph;
         *reinterpret_cast<u32x4 *>(dst + 16) = pm;
         *reinterpret_cast<u32x4 *>(dst + 32) = pl4;
     }
 }
 
-extern "C" int vc_split3(vc_stream s, vc_view a, void *out_split)
+// out_split: plane 0 of image 0; out_image_bytes: distance between images (0 = dense, c/8 planes per image) -- a window of
+// planes inside a wider split tensor (the split form of a channel slice of a concat buffer) passes the parent's image size
+extern "C" int vc_split3(vc_stream s, vc_view a, void *out_split, long long out_image_bytes)
 {
-    if (!a.p || !out_split || (a.c % 8) || (a.sw % 4) || (a.sh % 4) || (a.sn % 4) || ((uintptr_t)a.p % 16) || ((uintptr_t)out_split % 16)) return VC_EINVAL;
+    if (!a.p || !out_split || (a.c % 8) || (a.sw % 4) || (a.sh % 4) || (a.sn % 4) || ((uintptr_t)a.p % 16) || ((uintptr_t)out_split % 16) ||
+        (out_image_bytes % 16))
+        return VC_EINVAL;
     const long long total = (long long)a.n * (a.c / 8) * a.h * a.w;
     if (total <= 0) return VC_OK;
-    hipLaunchKernelGGL(k_split3, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, static_cast<unsigned char *>(out_split));
+    const long long img = out_image_bytes ? out_image_bytes : (long long)(a.c / 8) * a.h * a.w * 48;
+    unsigned char *o = static_cast<unsigned char *>(out_split);
+    const int cg = a.c / 8;
+    if (cg % 4 == 0) hipLaunchKernelGGL(k_split3<4>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
+    else if (cg % 2 == 0) hipLaunchKernelGGL(k_split3<2>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
+    else hipLaunchKernelGGL(k_split3<1>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -146,6 +161,13 @@ int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
     if (a.out_sp3 ? (cpp % 8 != 0) : !a.vec_out) return VC_EINVAL;
     // per-lane source offsets are 32-bit: the planes of a chunk and a tile's footprint inside them must stay below 2 GiB
     if ((long long)cpl * a.H * a.W * 48 + (long long)(k + 15) * a.W * 48 + 48ll * 48 >= (1ll << 31)) return VC_EINVAL;
+    if (a.res_sp3 && (!a.res || (cpp % 8))) return VC_EINVAL;
+    // image strides of split tensors are bytes; 0 = dense
+    if (!a.in_sn) a.in_sn = (long long)(a.Cin / 8) * a.H * a.W * 48;
+    const int osc = a.out_mode == VC_OUT_PLAIN ? 1 : 2;
+    if (a.out_sp3 && !a.out_sn) a.out_sn = (long long)(cpp / 8) * osc * a.Ho * osc * a.Wo * 48;
+    if (a.res_sp3 && !a.res_sn) a.res_sn = (long long)(cpp / 8) * osc * a.Ho * osc * a.Wo * 48;
+    if ((a.in_sn % 16) || (a.out_sp3 && (a.out_sn % 16)) || (a.res_sp3 && (a.res_sn % 8))) return VC_EINVAL;
     const int th = k == 3 ? 12 : 16;
     a.tiles_x = (a.Wo + 31) / 32;
     a.tiles_y = (a.Ho + th - 1) / th;

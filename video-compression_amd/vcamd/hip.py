@@ -131,7 +131,7 @@ def lib():
     sig("vc_conv2d_nhwc", ci, vp, ctypes.POINTER(ConvDesc))
     sig("vc_conv_packed_weight_bytes_split", sz, ci, ci, ci)
     sig("vc_conv_pack_weights_split", ci, vp, vp, ci, ci, ci, ci, vp, vp)
-    sig("vc_split3", ci, vp, View, vp)
+    sig("vc_split3", ci, vp, View, vp, cll)
     sig("vc_nchw_to_nhwc", ci, vp, vp, View)
     sig("vc_nhwc_to_nchw", ci, vp, View, vp)
     sig("vc_u8hwc_to_f32nchw_pad", ci, vp, vp, ci, ci, vp, ci, ci)
@@ -228,29 +228,46 @@ class T:
         if dtype == "sp3":     # split tensor of the split-operand fp32 path: dense [n][c/8][h][w][3][8] bf16 (csrc/conv_split.h)
             if c % 8:
                 raise VcError("a split tensor holds groups of 8 channels")
-            return T(torch.empty(n * h * w * c * 3, dtype=torch.int16, device=device), n, h, w, c, h * w * c, w * c, c, 0, dtype)
+            # sn = planes of 8 channels per image of the underlying buffer, off = first plane of this window
+            return T(torch.empty(n * h * w * c * 3, dtype=torch.int16, device=device), n, h, w, c, c // 8, 0, 0, 0, dtype)
         buf = torch.empty(n * h * w * c, dtype=torch.float16 if dtype == "f16" else torch.float32, device=device)
         return T(buf, n, h, w, c, h * w * c, w * c, c, 0, dtype)
 
     def channels(self, c0, c1):
+        if self.dtype == "sp3":          # a window of planes: the split form of a channel slice of a concat buffer
+            if c0 % 8 or c1 % 8:
+                raise VcError("a split tensor is sliced in groups of 8 channels")
+            return T(self.buf, self.n, self.h, self.w, c1 - c0, self.sn, 0, 0, self.off + c0 // 8, self.dtype)
         return T(self.buf, self.n, self.h, self.w, c1 - c0, self.sn, self.sh, self.sw, self.off + c0, self.dtype)
 
     def crop(self, h, w):
         return T(self.buf, self.n, h, w, self.c, self.sn, self.sh, self.sw, self.off, self.dtype)
 
     def images(self, n0, n1):
+        if self.dtype == "sp3":
+            return T(self.buf, n1 - n0, self.h, self.w, self.c, self.sn, 0, 0, self.off + n0 * self.sn, self.dtype)
         return T(self.buf, n1 - n0, self.h, self.w, self.c, self.sn, self.sh, self.sw, self.off + n0 * self.sn, self.dtype)
 
     @property
     def ptr(self):
         if self.dtype == "sp3":
-            return self.buf.data_ptr()
+            return self.buf.data_ptr() + self.off * self.h * self.w * 48
         return self.buf.data_ptr() + (2 if self.dtype == "f16" else 4) * self.off
 
     def view(self, allow_half=False):
+        if self.dtype == "sp3":
+            raise VcError("split tensors are private to the convolution engine (split_view)")
         if self.dtype != "f32" and not allow_half:
             raise VcError("half-precision activations are private to the fp16 convolution path")
         return View(self.ptr, self.n, self.h, self.w, self.c, self.sn, self.sh, self.sw)
+
+    @property
+    def image_bytes(self):
+        """split tensors: distance between images in bytes"""
+        return self.sn * self.h * self.w * 48
+
+    def split_view(self):
+        return View(self.ptr, self.n, self.h, self.w, self.c, self.image_bytes, 0, 0)
 
     def to_nchw(self):
         """Debug/inspection helper (torch indexing, not on the hot path)."""
@@ -314,6 +331,7 @@ CFG_PACK128 = 0x4000        # with CFG_DMA: weights / bias packed with the 128-c
 CFG_SPLIT = 10            # fp32 on the bf16 matrix pipe with split operands (csrc/conv_split.h); input: a split tensor (dtype "sp3")
 CFG_IN_SP3 = 0x8000
 CFG_OUT_SP3 = 0x10000
+CFG_RES_SP3 = 0x20000
 # "native": v_mfma_f32_* instances everywhere (rounds 1-4).  "split" (default since round 5, after the reference-parity tests
 # came out equal on it: tests/test_reference_1080p_gpu.py): the layers the split-operand pipeline serves (5x5 / 7x7
 # stride 1, cin % 8 == 0, cout % 32 == 0) run on it -- exact bf16 x 3 pieces, nine exact products, fp32 accumulate; same precision
@@ -368,6 +386,10 @@ def fp32_mode():
     return _FP32_MODE
 
 
+def wants_split_at(pc, n, h, w):
+    return _FP32_MODE == "split" and pc is not None and pc.split_ok and pc.split_pays(n, h, w)
+
+
 def wants_split(pc, x, h=None, w=None):
     """Will the layer ``pc`` run on the split-operand pipeline for an input of x's batch at h x w (default: x's own size)?  The hint
     a producer needs to leave its result as a split tensor (``out_sp3``)."""
@@ -380,7 +402,7 @@ def split3(x, out=None):
     if out is None:
         out = T.empty(x.n, x.h, x.w, x.c, x.buf.device, "sp3")
     timed_hbm(f"k_split3 c{x.c} @{x.n}x{x.h}x{x.w}", 10.0 * x.n * x.h * x.w * x.c,
-              lambda: check(lib().vc_split3(stream(), x.view(), out.ptr), "vc_split3"))
+              lambda: check(lib().vc_split3(stream(), x.view(), out.ptr, out.image_bytes), "vc_split3"))
     return out
 
 
@@ -468,6 +490,8 @@ class PackedConv:
             cands = [c for c in cands if c != 0]     # the 4x1 128-channel fp16 instance spills registers
         if not (flags & CFG_F16 and flags & CFG_IN_F16) and not (self.dma_f32 and not flags & CFG_F16):
             cands = [c for c in cands if c != CFG_DMA]   # the LDS-DMA pipeline copies pixels as they are: half tensors, or fp32 on its fp32 instances
+        if flags & CFG_OUT_SP3:
+            cands = [c for c in cands if c in (0, 1, 2, 3, 5, 7)]    # split output: the classic instances' epilogue
         if not AUTOTUNE or len(cands) < 2 or torch.cuda.is_current_stream_capturing():
             return (cands[0] if cands else self.cfg) | flags
         best, best_ms = self.cfg, float("inf")
@@ -562,27 +586,30 @@ class PackedConv:
             out = T.empty(x.n, ho, wo, co, x.buf.device, "sp3" if out_sp3 else "f32")
         wsp, bsp = self.split_pack()
         d = ConvDesc()
-        d.inp = View(xs.ptr, xs.n, xs.h, xs.w, xs.c, xs.sn, xs.sh, xs.sw)
-        d.out = View(out.ptr, out.n, out.h, out.w, out.c, out.sn, out.sh, out.sw)
+        d.inp = xs.split_view()
+        d.out = out.split_view() if out.dtype == "sp3" else out.view()
         d.wpk, d.bias = wsp.data_ptr(), bsp.data_ptr()
+        res_sp3 = res is not None and res.dtype == "sp3"
         if res is not None:
-            if res.dtype != "f32":
-                raise VcError("the split-operand pipeline adds fp32 residuals")
-            d.res, d.res_sn, d.res_sh, d.res_sw = res.ptr, res.sn, res.sh, res.sw
+            if res.dtype == "f16":
+                raise VcError("the split-operand pipeline adds fp32 or split residuals")
+            d.res, d.res_sn, d.res_sh, d.res_sw = (res.ptr, res.image_bytes, 0, 0) if res_sp3 else (res.ptr, res.sn, res.sh, res.sw)
         if chscale is not None:
             d.chscale = chscale.data_ptr()
         d.kh = d.kw = self.k
         d.stride = 1
         d.act, d.slope = act, slope
         d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
-        d.cfg = CFG_SPLIT | CFG_EXACT | CFG_IN_SP3 | (CFG_OUT_SP3 if out.dtype == "sp3" else 0) | (CFG_RES_FIRST if res_first else 0)
+        d.cfg = (CFG_SPLIT | CFG_EXACT | CFG_IN_SP3 | (CFG_OUT_SP3 if out.dtype == "sp3" else 0) | (CFG_RES_FIRST if res_first else 0)
+                 | (CFG_RES_SP3 if res_sp3 else 0))
         what = f"vc_conv2d_nhwc(split k={self.k},{self.cin}->{self.cout})"
         if timer is None:
             check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
         else:
             flops = 2.0 * x.n * ho * wo * self.cout * self.cin * self.k * self.k
             key = f"conv k{self.k} s1 {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
-            nbytes = x.n * x.h * x.w * self.cin * 6 + x.n * ho * wo * co * (6 if out.dtype == "sp3" else 4) + self.cout * self.cin * self.k * self.k * 6
+            nbytes = (x.n * x.h * x.w * self.cin * 6 + x.n * ho * wo * co * (6 if out.dtype == "sp3" else 4) + self.cout * self.cin * self.k * self.k * 6
+                      + (x.n * ho * wo * co * (6 if res_sp3 else 4) if res is not None else 0))
             split_keys.add(key)
             timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
         return out
@@ -604,13 +631,18 @@ class PackedConv:
                  and x.ptr % 16 == 0)
         if half_in and not use16:
             raise VcError("a half-precision activation reached a layer that is not on the fp16 path")
+        # a split consumer behind a NATIVE fp32 layer (stride-2 / 1x1 / GDN / small-cin layers): the classic instances write the three
+        # bf16 pieces themselves (CFG_OUT_SP3); the streaming / LDS-DMA configurations do not, so the tuner is held to the classic ones
+        sp_out = (out.dtype == "sp3") if out is not None else bool(out_sp3 and _FP32_MODE == "split" and not use16 and co % 8 == 0
+                                                                    and self.cfg in (0, 1, 2, 3) and (res is None or res.dtype == "f32"))
         if out is None:
-            out = T.empty(x.n, ho, wo, co, x.buf.device, "f16" if (out_f16 and HALF_ACTIVATIONS and use16 and co % 4 == 0) else "f32")
+            out = T.empty(x.n, ho, wo, co, x.buf.device, "sp3" if sp_out else
+                          ("f16" if (out_f16 and HALF_ACTIVATIONS and use16 and co % 4 == 0) else "f32"))
         half_out = out.dtype == "f16"
         if half_out and not use16:
             raise VcError("a half-precision output needs the fp16 path")
         d = ConvDesc()
-        d.inp, d.out = x.view(True), out.view(True)
+        d.inp, d.out = x.view(True), (out.split_view() if sp_out else out.view(True))
         d.wpk, d.bias = self.wpk.data_ptr(), self.bias.data_ptr()
         res_half = res is not None and res.dtype == "f16"
         if tail is not None and not (self.can_fuse_tail(tail) and use16 and half_in and epi == EPI_NONE and act < ACT_SIGMOID
@@ -630,7 +662,7 @@ class PackedConv:
         d.epi, d.in_xform = epi, in_xform
         d.out_mode = OUT_PIXELSHUFFLE2 if self.ps else OUT_PLAIN
         d.cfg = self.cfg
-        flags = CFG_RES_FIRST if res_first else 0        # out = act(conv + res) instead of act(conv) + res
+        flags = (CFG_RES_FIRST if res_first else 0) | (CFG_OUT_SP3 if sp_out else 0)      # RES_FIRST: out = act(conv + res) instead of act(conv) + res
         if use16:
             d.wpk = self.wpk16.data_ptr()
             flags |= CFG_F16 | (CFG_IN_F16 if half_in else 0) | (CFG_OUT_F16 if half_out else 0) | (CFG_RES_F16 if res_half else 0)

@@ -83,7 +83,8 @@ class GDN(_Prepared):
         self.gamma_reparam = NonNegativeParametrizer()
         self.gamma = nn.Parameter(self.gamma_reparam.init(gamma_init * torch.eye(in_channels)))
 
-    def run(self, x, res=None, out=None):
+    def run(self, x, res=None, out=None, out_sp3=False):
+        """``out_sp3``: the consumer is a split-operand block (fp32 mode "split"): the classic 1x1 instance writes the three bf16 pieces."""
         if self._packed is None:
             with torch.no_grad():
                 c = self.beta.numel()
@@ -91,7 +92,7 @@ class GDN(_Prepared):
                 gamma = self.gamma_reparam.resolve(self.gamma).reshape(c, c, 1, 1)
             self._packed = hip.PackedConv(gamma, beta, device=self.beta.device)
         return self._packed(x, out=out, epi=hip.EPI_IGDN if self.inverse else hip.EPI_GDN, mul=x,
-                            in_xform=hip.IN_SQUARE, res=res)
+                            in_xform=hip.IN_SQUARE, res=res, out_sp3=out_sp3)
 
 
 def conv3x3(in_ch, out_ch, stride=1):
@@ -115,15 +116,21 @@ class ResidualBlockWithStride(_Prepared):
         self.gdn = GDN(out_ch)
         self.skip = conv1x1(in_ch, out_ch, stride=stride) if (stride != 1 or in_ch != out_ch) else None
 
-    def run(self, x):
+    def out_hw(self, h, w):
+        s = self.conv1.stride[0]
+        return (h - 1) // s + 1, (w - 1) // s + 1
+
+    def run(self, x, out=None, out_sp3=False):
         if self._packed is None:
             self._packed = (pack_conv(self.conv1), pack_conv(self.conv2),
                             pack_conv(self.skip) if self.skip is not None else None)
         c1, c2, sk = self._packed
-        t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok)
-        u = c2(t)                       # (fp32 mode "split": converts t itself -- the stride-2 layer in front is a native instance)
+        ho, wo = self.out_hw(x.h, x.w)
+        # (fp32 mode "split": the stride-2 layer is a native instance whose epilogue writes the split tensor conv2 reads)
+        t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x, ho, wo))
+        u = c2(t)
         identity = x if sk is None else sk(x)
-        return self.gdn.run(u, res=identity)
+        return self.gdn.run(u, res=identity, out=out, out_sp3=out_sp3)
 
 
 class ResidualBlockUpsample(_Prepared):
@@ -135,20 +142,32 @@ class ResidualBlockUpsample(_Prepared):
         self.igdn = GDN(out_ch, inverse=True)
         self.upsample = subpel_conv3x3(in_ch, out_ch, upsample)
 
-    def run(self, x):
+    def _pack(self):
         if self._packed is None:
             self._packed = (pack_conv(self.subpel_conv[0], pixelshuffle=True), pack_conv(self.conv),
                             pack_conv(self.upsample[0], pixelshuffle=True))
-        sp, cv, up = self._packed
+        return self._packed
+
+    def out_hw(self, h, w):
+        return 2 * h, 2 * w
+
+    def split_in_ok(self, n, h, w):
+        """fp32 mode "split": both layers that read the block's input run on the split-operand pipeline at this size, so the
+        producer may hand the input over as a split tensor."""
+        sp, _, up = self._pack()
+        return hip.wants_split_at(sp, n, h, w) and hip.wants_split_at(up, n, h, w)
+
+    def run(self, x, out=None, out_sp3=False):
+        sp, cv, up = self._pack()
         # fp32 mode "split": both branches read ONE split copy of x; the sub-pixel layer hands its result on as a split tensor
         xs = x
-        if x.dtype == "f32" and hip.wants_split(sp, x) and hip.wants_split(up, x):
+        if x.dtype == "f32" and self.split_in_ok(x.n, x.h, x.w):
             xs = hip.split3(x)
         t = sp(xs, act=hip.ACT_LRELU, slope=0.01, out_f16=cv.half_ok,   # LeakyReLU commutes with the pixel shuffle
                out_sp3=hip.wants_split(cv, x, 2 * x.h, 2 * x.w))
         u = cv(t)
         identity = up(xs)
-        return self.igdn.run(u, res=identity)
+        return self.igdn.run(u, res=identity, out=out, out_sp3=out_sp3)
 
 
 class ResidualBlock(_Prepared):
@@ -159,14 +178,26 @@ class ResidualBlock(_Prepared):
         self.conv2 = conv3x3(out_ch, out_ch)
         self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
 
-    def run(self, x):
+    def _pack(self):
         if self._packed is None:
             self._packed = (pack_conv(self.conv1), pack_conv(self.conv2),
                             pack_conv(self.skip) if self.skip is not None else None)
-        c1, c2, sk = self._packed
+        return self._packed
+
+    def out_hw(self, h, w):
+        return h, w
+
+    def split_in_ok(self, n, h, w):
+        """fp32 mode "split": conv1 reads the input as a split tensor and conv2 adds it back from the same tensor (its three pieces
+        sum to the exact fp32 value): the producer may hand the input over as a split tensor."""
+        c1, c2, sk = self._pack()
+        return sk is None and hip.wants_split_at(c1, n, h, w) and hip.wants_split_at(c2, n, h, w)
+
+    def run(self, x, out=None, out_sp3=False):
+        c1, c2, sk = self._pack()
         t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x))
         identity = x if sk is None else sk(x)
-        return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity)
+        return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity, out=out, out_sp3=out_sp3)
 
 
 def deconv_as_subpel_weights(deconv):
@@ -259,6 +290,15 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
         pk = pack_of(m)
         return pk is not None and pk.half_ok
 
+    def takes_split(m, n, h, w):
+        """fp32 mode "split": may the member's input arrive as a split tensor (three bf16 pieces per value)?"""
+        if hasattr(m, "split_in_ok"):
+            return m.split_in_ok(n, h, w)
+        if isinstance(m, (ResidualBlockWithStride, GDN)) or getattr(m, "vc_block", False):
+            return False
+        pk = pack_of(m)
+        return pk is not None and hip.wants_split_at(pk, n, h, w)
+
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -270,6 +310,8 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
                 x = m.run(x, out=out)
             elif hasattr(m, "half_stream_ok") and not last and takes_half(mods[i + 1]):
                 x = m.run(x, out_f16=True)                # the next member reads (and, a block, adds) it as half
+            elif hasattr(m, "out_hw") and not last and takes_split(mods[i + 1], x.n, *m.out_hw(x.h, x.w)):
+                x = m.run(x, out_sp3=True)                # fp32 mode "split": the next member reads it as a split tensor
             else:
                 x = m.run(x)
             i += 1
@@ -287,11 +329,10 @@ def run_sequential(seq, x, cache, final_chscale=None, final_act=None, out=None):
             act = final_act
         # a result consumed by the next convolution alone (or by a bottleneck block that keeps its identity as half) may be
         # kept as half on the fp16 path
-        nxt_pk = pack_of(mods[i + 1]) if (not last and isinstance(mods[i + 1], (nn.Conv2d, nn.ConvTranspose2d, nn.Sequential))) else None
         ho, wo, _ = pk.out_shape(x.h, x.w)
         x = pk(x, act=act, slope=slope, chscale=final_chscale if last else None, out=out if last else None,
                out_f16=bool(not last and takes_half(mods[i + 1])),
-               out_sp3=bool(nxt_pk is not None and hip.wants_split(nxt_pk, x, ho, wo)))
+               out_sp3=bool(not last and takes_split(mods[i + 1], x.n, ho, wo)))
         i += 1
     return x
 
