@@ -210,7 +210,11 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     if (f16 && (!cfg_f16_ok(d->cfg & 0xff, a.Cin) || d->in_xform != VC_IN_NONE)) return VC_EINVAL;
     a.in_f16 = (d->cfg & VC_CFG_IN_F16) ? 1 : 0;
     a.out_f16 = (d->cfg & VC_CFG_OUT_F16) ? 1 : 0;
-    if ((a.in_f16 || a.out_f16) && !f16) return VC_EINVAL;   // half-precision tensors exist on the fp16 path only
+    // half-precision tensors exist on the fp16 path only -- one exception: the fp32 GDN / IGDN instance of the streaming 1x1 kernel
+    // may STORE its result as half (the input of a residual block that runs on the fp16 path, identity included)
+    if ((a.in_f16 || a.out_f16) && !f16 &&
+        !(a.out_f16 && !a.in_f16 && (d->cfg & 0xff) == VC_CFG_PWS && (d->epi == VC_EPI_GDN || d->epi == VC_EPI_IGDN)))
+        return VC_EINVAL;
     a.res_f16 = (d->cfg & VC_CFG_RES_F16) ? 1 : 0;
     a.pack128 = (d->cfg & VC_CFG_PACK128) ? 1 : 0;
     a.tail_wpk = d->tail_wpk;
@@ -229,7 +233,7 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
     }
     if (a.tail_wpk && (!f16 || (d->cfg & 0xff) != VC_CFG_DMA)) return VC_EINVAL;             // the fused tail lives in the LDS-DMA kernel
     // a half-precision residual: the streaming 1x1 kernel, or the LDS-DMA kernel's fused-tail epilogue
-    if (a.res_f16 && (!f16 || !d->res || !((d->cfg & 0xff) == VC_CFG_PWS || ((d->cfg & 0xff) == VC_CFG_DMA && a.tail_wpk)))) return VC_EINVAL;
+    if (a.res_f16 && (!f16 || !d->res || !((d->cfg & 0xff) == VC_CFG_PWS || (d->cfg & 0xff) == VC_CFG_DMA))) return VC_EINVAL;
     a.res_first = (d->cfg & VC_CFG_RES_FIRST) ? 1 : 0;
     if (a.res_first && (!d->res || d->epi != VC_EPI_NONE || d->act == VC_ACT_SIGMOID || d->act == VC_ACT_CLAMP01)) return VC_EINVAL;
     a.cin_pad = round_up(a.Cin, f16 ? 2 * ck : ck);

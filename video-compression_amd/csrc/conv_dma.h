@@ -221,7 +221,13 @@ __device__ __forceinline__ void dma_epilogue_mode(const ConvArgs &p, f32x16 (&ac
                 f32x4 r = {0.f, 0.f, 0.f, 0.f};
                 if (p.res) {
                     const long long r_off = (long long)img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
-                    if (ok) r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                    if (p.res_f16) {          // (VC_CFG_RES_F16: the identity of a residual block kept as half)
+                        f16x4 rh = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                        if (ok) rh = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const _Float16 *>(p.res) + r_off);
+                        r = f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                    } else if (ok) {
+                        r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
+                    }
                 }
                 if (res_first) v += r;
 #pragma unroll
@@ -298,6 +304,72 @@ __device__ __forceinline__ void dma_epilogue_fast(const ConvArgs &p, f32x16 (&ac
             const f32x4 d = *reinterpret_cast<const f32x4 *>(scratch + px * ROWB + ((rc ^ (px & (CH16 - 1))) << 4));
             *reinterpret_cast<f32x4 *>(obase + row + (long long)px * p.out_sw + 8 * rc) = d;
         }
+    });
+}
+
+// Residual-block epilogue of the fp16 path (VC_CFG_RES_F16 on a plain 3x3 instance; LHBDC/model/layers.py:48-56,82-91 through
+// compressai's ResidualBlock: out = act(conv2(t)) + identity): half-precision output AND a half-precision identity, tile inside the
+// output.  The exchange of the fused-tail epilogue: 16 pixels x 64 channels (a pair of N-tiles) at a time through an fp32 scratch,
+// read back as 8 consecutive channels per lane -- one 16-byte identity load (requested ONE step ahead) and one 16-byte store per
+// lane and pass; the sum is formed in fp32 and rounded once, exactly like dma_epilogue_mode<0> does value by value.
+template <class C>
+__device__ __forceinline__ void dma_epilogue_resh(const ConvArgs &p, f32x16 (&acc)[C::WM][C::WN], int nblk, int wm, int wn, int lane,
+                                                  int oy0, int ox0, int img, float *scratch)
+{
+    constexpr int WM = C::WM, WN = C::WN, RF = 68, STEPS = WN;          // steps per M-tile: (pair of N-tiles, 16-pixel part)
+    static_assert(WN % 2 == 0, "pairs of N-tiles (64 channels = one 128-byte line of a half-precision pixel)");
+    const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+    const int wpx = lane & 31, whalf = lane >> 5;
+    const int rp8 = lane >> 3, ro = lane & 7;
+    const int co0 = nblk * C::BN + wn * WN * 32;                        // the wave's first output channel
+    const _Float16 *const rbase = reinterpret_cast<const _Float16 *>(p.res) + (long long)img * p.res_sn + co0 + 8 * ro;
+    _Float16 *const obase = reinterpret_cast<_Float16 *>(p.out) + (long long)img * p.out_sn + co0 + 8 * ro;
+    f32x4 rnext[2] = {};
+    auto request = [&](int t, int step) {
+        const int pr = step >> 1, part = step & 1;
+        const int oy = oy0 + wm * WM + t;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = ox0 + 16 * part + 8 * j + rp8;
+            rnext[j] = *reinterpret_cast<const f32x4 *>(rbase + (long long)oy * p.res_sh + (long long)ox * p.res_sw + pr * 64);
+        }
+    };
+    request(0, 0);
+    static_for<0, WM>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int oy = oy0 + wm * WM + t;
+        static_for<0, STEPS>([&](auto sc) {
+            constexpr int step = decltype(sc)::value, pr = step >> 1, part = step & 1;
+            const f32x4 rcur[2] = {rnext[0], rnext[1]};
+            if constexpr (step + 1 < STEPS) request(t, step + 1);
+            else if constexpr (t + 1 < WM) request(t + 1, 0);
+            const int row = ((wpx >> 4) == part) ? (wpx & 15) * RF : 16 * RF;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = acc[t][2 * pr + hh][4 * g + e];
+                        v[e] = vc_max_f32(a, a * neg);
+                    }
+                    *reinterpret_cast<f32x4 *>(&scratch[row + 32 * hh + 8 * g + 4 * whalf]) = v;
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pix = 8 * j + rp8;
+                f32x4 v0 = *reinterpret_cast<const f32x4 *>(&scratch[pix * RF + 8 * ro]);
+                f32x4 v1 = *reinterpret_cast<const f32x4 *>(&scratch[pix * RF + 8 * ro + 4]);
+                const f16x8 rh = __builtin_bit_cast(f16x8, rcur[j]);
+                v0 += f32x4{(float)rh[0], (float)rh[1], (float)rh[2], (float)rh[3]};
+                v1 += f32x4{(float)rh[4], (float)rh[5], (float)rh[6], (float)rh[7]};
+                const f16x8 hv = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3],
+                                  (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+                const int ox = ox0 + 16 * part + pix;
+                *reinterpret_cast<f16x8 *>(obase + (long long)oy * p.out_sh + (long long)ox * p.out_sw + pr * 64) = hv;
+            }
+        });
     });
 }
 
@@ -735,10 +807,18 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
                               cur.oy0 + C::TH <= p.Ho && cur.ox0 + C::TW <= p.Wo && (cur.nblk + 1) * C::BN <= p.Cout &&
                               (p.out_sw & 7) == 0 && (p.out_sh & 7) == 0 &&
                               (p.out_sn & 7) == 0;
+            bool resh = false;
+            if constexpr (!C::F32 && C::WN % 2 == 0)        // half output + half identity, whole tile inside the output (VC_CFG_RES_F16)
+                resh = !(C::KO & 16384) && p.out_f16 && p.res && p.res_f16 && !p.res_first && !p.chscale && p.out_mode == VC_OUT_PLAIN &&
+                       (p.act == VC_ACT_NONE || p.act == VC_ACT_RELU || (p.act == VC_ACT_LRELU && p.slope >= 0.0f && p.slope <= 1.0f)) &&
+                       cur.oy0 + C::TH <= p.Ho && cur.ox0 + C::TW <= p.Wo && (cur.nblk + 1) * C::BN <= p.Cout &&
+                       ((p.out_sw | p.out_sh | p.out_sn | p.res_sw | p.res_sh | p.res_sn) & 7) == 0;
             if (fast)
                 dma_epilogue_fast<C>(p, acc, cur.nblk, wm, wn, lane, cur.oy0, cur.ox0, cur.img,
                                      reinterpret_cast<unsigned char *>(scratch - wave * VC_EPI_SCRATCH_FLOATS) + wave * 4096);
-            else
+            else if (resh) {
+                if constexpr (!C::F32 && C::WN % 2 == 0) dma_epilogue_resh<C>(p, acc, cur.nblk, wm, wn, lane, cur.oy0, cur.ox0, cur.img, scratch);
+            } else
                 dma_epilogue<C>(p, acc, cur.nblk, wm, wn, lane, cur.oy0, cur.ox0, cur.img, scratch);
         }
         VC_DMA_STAMP(t_e1);

@@ -92,7 +92,8 @@ int conv_dispatch_dma(hipStream_t st, ConvArgs a, int k, int stride, bool f16)
         if (a.Cout == 64) return launch_conv_dma<DmaCfg<3, 3, 2, 2, 3, 0, true>>(st, a);
         return launch_conv_dma<DmaCfg<3, 3, 4, 4, 4, 0, true>>(st, a);
     }
-    if (a.res_f16) return VC_EINVAL;                 // (a half-precision residual is read by the fused-tail epilogue only)
+    // (a half-precision residual: the fused-tail epilogue above, or the residual-block epilogue of the plain 3x3 instances)
+    if (a.res_f16 && (k != 3 || !a.res || a.res_first)) return VC_EINVAL;
     if (k == 3) {
         if (nt == 4 && nchunk == 4) {
 #ifdef VC_DMA_DIAG      // diagnostic build only (make dma_diag): knock-out / ring-depth variants of the north-star instance

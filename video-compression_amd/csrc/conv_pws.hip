@@ -186,7 +186,7 @@ template <class C, int RES, int GDN = 0> __global__ void __launch_bounds__(512, 
 
     constexpr bool has_res = RES != 0;                // a template parameter: the residual registers must not pass through a phi
     constexpr bool res_half = RES == 2;
-    const int osz = (F16 && p.out_f16) ? 2 : 4;
+    const int osz = p.out_f16 ? 2 : 4;           // (fp32 instances: the GDN / IGDN instance may store half, conv_api.hip)
     const bool half_plain = osz == 2 && !has_res && !p.chscale && (p.out_sw % 8) == 0 && (p.out_sh % 8) == 0 && (p.out_sn % 8) == 0;
     const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
     const float *const bias_l = reinterpret_cast<const float *>(lds8 + C::BIAS_OFF);
@@ -473,7 +473,7 @@ bool conv_pws_eligible(const ConvArgs &a, int k, int stride, bool f16)
     if ((long long)a.N * a.H * ((a.W + 31) / 32) >= (1ll << 31) || a.in_sw * 4 * 32 >= (1ll << 31) || a.res_sw * 4 * 32 >= (1ll << 31) ||
         a.out_sw * 4 * 32 >= (1ll << 31)) return false;
     if (f16 && a.in_f16 && ((a.in_sw % 8) || (a.in_sh % 8) || (a.in_sn % 8) || ((uintptr_t)a.in % 16))) return false;
-    if (!f16 && (a.in_f16 || a.out_f16)) return false;
+    if (!f16 && (a.in_f16 || (a.out_f16 && a.epi == VC_EPI_NONE))) return false;
     return true;
 }
 

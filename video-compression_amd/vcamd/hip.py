@@ -483,8 +483,8 @@ class PackedConv:
     def _pick_cfg(self, d, key, flags=0):
         if key in self.tuned:
             return self.tuned[key]
-        if flags & CFG_RES_F16:                       # only the streaming 1x1 kernel reads a half-precision residual
-            return CFG_PWS | CFG_EXACT | flags
+        if flags & CFG_RES_F16:                       # a half-precision residual: the streaming 1x1 kernel / the LDS-DMA 3x3 kernel
+            return (CFG_PWS if self.k == 1 else CFG_DMA) | CFG_EXACT | flags
         cands = self.candidates
         if flags & CFG_F16 and 5 in cands:
             cands = [c for c in cands if c != 0]     # the 4x1 128-channel fp16 instance spills registers
@@ -571,9 +571,10 @@ class PackedConv:
 
     @property
     def half_res_ok(self):
-        """True when this layer can add a HALF-precision residual (fp16 path, streaming 1x1 kernel): the last layer of a
-        bottleneck block whose identity path is kept as half (see VC_CFG_RES_F16 in include/vc_hip.h)."""
-        return self.wpk16 is not None and CFG_PWS in self.candidates
+        """True when this layer can add a HALF-precision residual (fp16 path; streaming 1x1 kernel, or the LDS-DMA kernel for a 3x3
+        layer with a half-precision input): the last layer of a bottleneck / residual block whose identity path is kept as half
+        (see VC_CFG_RES_F16 in include/vc_hip.h)."""
+        return self.wpk16 is not None and (CFG_PWS in self.candidates or (self.k == 3 and self.stride == 1 and CFG_DMA in self.candidates))
 
     def _call_split(self, x, out, act, slope, res, chscale, out_sp3, res_first):
         """The layer on the split-operand pipeline.  ``x``: an fp32 window (converted here) or a split tensor left by the layer in
@@ -606,7 +607,7 @@ class PackedConv:
         if timer is None:
             check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what)
         else:
-            flops = 2.0 * x.n * ho * wo * self.cout * self.cin * self.k * self.k
+            flops = 2.0 * x.n * x.h * x.w * self.cout * self.cin * self.k * self.k       # (stride 1: one output position per input pixel)
             key = f"conv k{self.k} s1 {self.cin}->{self.cout} @{x.n}x{x.h}x{x.w}"
             nbytes = (x.n * x.h * x.w * self.cin * 6 + x.n * ho * wo * co * (6 if out.dtype == "sp3" else 4) + self.cout * self.cin * self.k * self.k * 6
                       + (x.n * ho * wo * co * (6 if res_sp3 else 4) if res is not None else 0))
@@ -636,10 +637,17 @@ class PackedConv:
         sp_out = (out.dtype == "sp3") if out is not None else bool(out_sp3 and _FP32_MODE == "split" and not use16 and co % 8 == 0
                                                                     and self.cfg in (0, 1, 2, 3) and (res is None or res.dtype == "f32"))
         if out is None:
+        # fp16 mode: the fp32 GDN / IGDN instance of the streaming 1x1 kernel may STORE half (the input -- operand and identity -- of a
+        # residual block that runs on the fp16 path; part of that mode's tolerance like every VC_HALF_RESIDUAL tensor)
+        gdn_half_ok = (_PRECISION == "fp16" and HALF_ACTIVATIONS and HALF_RESIDUAL and epi != EPI_NONE and self.k == 1 and self.cin == 128
+                       and self.cout == 128 and CFG_PWS in self.candidates and mul is x and x.dtype == "f32" and not res_first and chscale is None
+                       and (res is None or res.dtype == "f32"))
+        if out is None:
             out = T.empty(x.n, ho, wo, co, x.buf.device, "sp3" if sp_out else
-                          ("f16" if (out_f16 and HALF_ACTIVATIONS and use16 and co % 4 == 0) else "f32"))
+                          ("f16" if (out_f16 and HALF_ACTIVATIONS and (use16 or gdn_half_ok) and co % 4 == 0) else "f32"))
         half_out = out.dtype == "f16"
-        if half_out and not use16:
+        gdn_half = half_out and not use16 and gdn_half_ok
+        if half_out and not use16 and not gdn_half:
             raise VcError("a half-precision output needs the fp16 path")
         d = ConvDesc()
         d.inp, d.out = x.view(True), (out.split_view() if sp_out else out.view(True))
@@ -672,7 +680,10 @@ class PackedConv:
         # (stated on every call of a layer packed with the 128-channel configuration; only the LDS-DMA kernel reads it: its
         #  blocks of 128 may run into the padding of 96 / 160 / 432 ... output channels.  Not part of the tuning key.)
         pack = CFG_PACK128 if self.cfg == 0 else 0
-        if tail is not None:          # out = tail(act(conv3x3(x))) + res in ONE launch of the LDS-DMA kernel
+        if gdn_half:                  # the fp32 GDN instance of the streaming kernel, half store
+            flags |= CFG_OUT_F16
+            d.cfg = CFG_PWS | CFG_EXACT | flags
+        elif tail is not None:        # out = tail(act(conv3x3(x))) + res in ONE launch of the LDS-DMA kernel
             tw, tb = tail.tail_pack()
             d.tail_wpk, d.tail_bias = tw.data_ptr(), tb.data_ptr()
             d.cfg = CFG_DMA | CFG_EXACT | flags | pack

@@ -83,8 +83,9 @@ class GDN(_Prepared):
         self.gamma_reparam = NonNegativeParametrizer()
         self.gamma = nn.Parameter(self.gamma_reparam.init(gamma_init * torch.eye(in_channels)))
 
-    def run(self, x, res=None, out=None, out_sp3=False):
-        """``out_sp3``: the consumer is a split-operand block (fp32 mode "split"): the classic 1x1 instance writes the three bf16 pieces."""
+    def run(self, x, res=None, out=None, out_sp3=False, out_f16=False):
+        """``out_sp3``: the consumer is a split-operand block (fp32 mode "split"): the classic 1x1 instance writes the three bf16 pieces.
+        ``out_f16``: the consumer is a residual block on the fp16 path that keeps its identity as half (hip.HALF_RESIDUAL)."""
         if self._packed is None:
             with torch.no_grad():
                 c = self.beta.numel()
@@ -92,7 +93,7 @@ class GDN(_Prepared):
                 gamma = self.gamma_reparam.resolve(self.gamma).reshape(c, c, 1, 1)
             self._packed = hip.PackedConv(gamma, beta, device=self.beta.device)
         return self._packed(x, out=out, epi=hip.EPI_IGDN if self.inverse else hip.EPI_GDN, mul=x,
-                            in_xform=hip.IN_SQUARE, res=res, out_sp3=out_sp3)
+                            in_xform=hip.IN_SQUARE, res=res, out_sp3=out_sp3, out_f16=out_f16)
 
 
 def conv3x3(in_ch, out_ch, stride=1):
@@ -120,17 +121,27 @@ class ResidualBlockWithStride(_Prepared):
         s = self.conv1.stride[0]
         return (h - 1) // s + 1, (w - 1) // s + 1
 
-    def run(self, x, out=None, out_sp3=False):
+    def _pack(self):
         if self._packed is None:
             self._packed = (pack_conv(self.conv1), pack_conv(self.conv2),
                             pack_conv(self.skip) if self.skip is not None else None)
-        c1, c2, sk = self._packed
+        return self._packed
+
+    def half_stream_ok(self):
+        """fp16 path: both layers that read the block's input (the strided 3x3 and the skip projection) take a half-precision tensor."""
+        c1, _, sk = self._pack()
+        return hip.HALF_RESIDUAL and hip.HALF_ACTIVATIONS and c1.half_ok and sk is not None and sk.half_ok
+
+    def run(self, x, out=None, out_sp3=False, out_f16=False):
+        c1, c2, sk = self._pack()
+        if x.dtype == "f16" and not self.half_stream_ok():
+            raise hip.VcError("a half-precision tensor reached a residual block that reads its input in fp32")
         ho, wo = self.out_hw(x.h, x.w)
         # (fp32 mode "split": the stride-2 layer is a native instance whose epilogue writes the split tensor conv2 reads)
         t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x, ho, wo))
         u = c2(t)
         identity = x if sk is None else sk(x)
-        return self.gdn.run(u, res=identity, out=out, out_sp3=out_sp3)
+        return self.gdn.run(u, res=identity, out=out, out_sp3=out_sp3, out_f16=out_f16)
 
 
 class ResidualBlockUpsample(_Prepared):
@@ -157,8 +168,15 @@ class ResidualBlockUpsample(_Prepared):
         sp, _, up = self._pack()
         return hip.wants_split_at(sp, n, h, w) and hip.wants_split_at(up, n, h, w)
 
-    def run(self, x, out=None, out_sp3=False):
+    def half_stream_ok(self):
+        """fp16 path: both layers that read the block's input take a half-precision tensor."""
+        sp, _, up = self._pack()
+        return hip.HALF_RESIDUAL and hip.HALF_ACTIVATIONS and sp.half_ok and up.half_ok
+
+    def run(self, x, out=None, out_sp3=False, out_f16=False):
         sp, cv, up = self._pack()
+        if x.dtype == "f16" and not self.half_stream_ok():
+            raise hip.VcError("a half-precision tensor reached a residual block that reads its input in fp32")
         # fp32 mode "split": both branches read ONE split copy of x; the sub-pixel layer hands its result on as a split tensor
         xs = x
         if x.dtype == "f32" and self.split_in_ok(x.n, x.h, x.w):
@@ -167,7 +185,7 @@ class ResidualBlockUpsample(_Prepared):
                out_sp3=hip.wants_split(cv, x, 2 * x.h, 2 * x.w))
         u = cv(t)
         identity = up(xs)
-        return self.igdn.run(u, res=identity, out=out, out_sp3=out_sp3)
+        return self.igdn.run(u, res=identity, out=out, out_sp3=out_sp3, out_f16=out_f16)
 
 
 class ResidualBlock(_Prepared):
@@ -193,11 +211,21 @@ class ResidualBlock(_Prepared):
         c1, c2, sk = self._pack()
         return sk is None and hip.wants_split_at(c1, n, h, w) and hip.wants_split_at(c2, n, h, w)
 
-    def run(self, x, out=None, out_sp3=False):
+    def half_stream_ok(self):
+        """fp16 path (LHBDC/model/layers.py:48-56,82-91; hip.HALF_RESIDUAL): the block takes its input -- conv1's operand AND the
+        identity -- as a half-precision tensor: both 3x3 layers then run on the LDS-DMA kernel, conv2 adds the half identity
+        (VC_CFG_RES_F16).  One more rounding of the identity per block: the fp16 mode's tolerance, never the fp32 path."""
         c1, c2, sk = self._pack()
+        return hip.HALF_RESIDUAL and hip.HALF_ACTIVATIONS and sk is None and c1.half_ok and c2.half_ok and c2.half_res_ok
+
+    def run(self, x, out=None, out_sp3=False, out_f16=False):
+        c1, c2, sk = self._pack()
+        if x.dtype == "f16" and not self.half_stream_ok():
+            raise hip.VcError("a half-precision tensor reached a residual block that keeps its identity path in fp32")
         t = c1(x, act=hip.ACT_LRELU, slope=0.01, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x))
         identity = x if sk is None else sk(x)
-        return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity, out=out, out_sp3=out_sp3)
+        return c2(t, act=hip.ACT_LRELU, slope=0.01, res=identity, out=out, out_sp3=out_sp3,
+                  out_f16=bool(out_f16 and out is None and self.half_stream_ok()))
 
 
 def deconv_as_subpel_weights(deconv):
