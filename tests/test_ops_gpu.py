@@ -232,21 +232,30 @@ def test_lds_dma_fp16_kernel_is_bit_identical(dev, cin, cout, k, n, h, w, cfgs):
     for cfg, ref in outs.items():
         for a, c in zip(ref, outs[hip.CFG_DMA]):
             assert torch.equal(a, c), (cfg, (a.float() - c.float()).abs().max().item())
-    # an fp32 input is not offered by this kernel (the DMA cannot convert): refused, never silently wrong
+    # an fp32 input is not offered by this kernel (the DMA cannot convert): the LIBRARY refuses the pinned configuration, and the
+    # binding falls back to the layer's general configuration -- never silently wrong, never a failed layer
     pc.tuned = {(n, h, w, fl): hip.CFG_DMA | hip.CFG_EXACT | fl}
-    with pytest.raises(hip.VcError):
-        pc(xt, act=hip.ACT_NONE)
+    y_fallback = pc(xt, act=hip.ACT_NONE).buf.clone()
+    pc.tuned = {(n, h, w, fl): pc.cfg | hip.CFG_EXACT | fl}
+    assert torch.equal(y_fallback, pc(xt, act=hip.ACT_NONE).buf)
+    d = hip.ConvDesc()
+    out_t = hip.T.empty(xt.n, *pc.out_shape(xt.h, xt.w), dev)
+    d.inp, d.out = xt.view(), out_t.view()
+    d.wpk, d.bias = pc.wpk16.data_ptr(), pc.bias.data_ptr()
+    d.kh = d.kw = pc.k
+    d.stride = 1
+    d.out_mode = hip.OUT_PIXELSHUFFLE2 if pc.ps else hip.OUT_PLAIN
+    d.cfg = hip.CFG_DMA | hip.CFG_EXACT | fl | (hip.CFG_PACK128 if pc.cfg == 0 else 0)
+    assert hip.lib().vc_conv2d_nhwc(hip.stream(), ctypes.byref(d)) == -1
     if cout > 64 and cout % 128:
         # a partly padded last block reads weights / bias padded to 128s: a caller that does not state that packing
         # (VC_CFG_PACK128) is refused instead of reading past a narrower one
         fi = fl | hip.CFG_IN_F16
-        pc.tuned = {(n, h, w, fi): hip.CFG_DMA | hip.CFG_EXACT | fi}
-        keep, pc.cfg = pc.cfg, 1
-        try:
-            with pytest.raises(hip.VcError):
-                pc(xh, act=hip.ACT_NONE)
-        finally:
-            pc.cfg = keep
+        d.inp = xh.view(True)
+        d.cfg = hip.CFG_DMA | hip.CFG_EXACT | fi | hip.CFG_PACK128
+        assert hip.lib().vc_conv2d_nhwc(hip.stream(), ctypes.byref(d)) == 0
+        d.cfg = hip.CFG_DMA | hip.CFG_EXACT | fi
+        assert hip.lib().vc_conv2d_nhwc(hip.stream(), ctypes.byref(d)) == -1
 
 
 def test_conv_residual_and_channel_slices(dev):
@@ -970,3 +979,32 @@ def test_gdn_on_the_streaming_kernel_is_bit_identical(dev, h, w, n, inverse):
     norm = F.conv2d(xc * xc, gamma.view(128, 128, 1, 1), beta)
     ref = xc * torch.sqrt(norm) if inverse else xc * torch.rsqrt(norm)
     _close(hip.nhwc_to_nchw(_as_t(base[0], n, h, w, 128, dev)).cpu(), ref, 2e-5, "GDN vs torch")
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(128, 128, 48, 96, 2), (128, 128, 37, 75, 1), (64, 64, 33, 70, 1), (128, 256, 32, 64, 1)])
+def test_lds_dma_3x3_half_precision_residual(dev, cin, cout, h, w, n):
+    """VC_CFG_RES_F16 on the LDS-DMA 3x3 kernel (round 5; the residual blocks of LHBDC/model/layers.py:48-56,82-91 on the fp16 path): a
+    half-precision identity gives exactly what the fp32 identity holding the same values gives on the classic fp16 instance -- the sum is
+    formed in fp32 and rounded once; whole tiles through the 16-byte exchange epilogue, ragged edges through the general one; half and
+    fp32 output."""
+    from vcamd import hip
+    hip.set_conv_precision("fp16")
+    try:
+        pc = hip.PackedConv(_rand((cout, cin, 3, 3), 71, 1.0 / np.sqrt(9 * cin)), _rand((cout,), 72, 0.1), device=dev)
+    finally:
+        hip.set_conv_precision("fp32")
+    assert pc.half_res_ok and hip.CFG_DMA in pc.candidates
+    x16 = hip.T.empty(n, h, w, cin, dev, "f16")
+    x16.buf.copy_(hip.nchw_to_nhwc(_rand((n, cin, h, w), 73).to(dev)).buf.half())
+    r16 = hip.T.empty(n, h, w, cout, dev, "f16")
+    r16.buf.copy_(hip.nchw_to_nhwc(_rand((n, cout, h, w), 74).to(dev)).buf.half())
+    r32 = hip.T.empty(n, h, w, cout, dev)
+    r32.buf.copy_(r16.buf.float())
+    for out_f16 in (True, False):
+        fl = hip.CFG_F16 | hip.CFG_IN_F16 | (hip.CFG_OUT_F16 if out_f16 else 0)
+        pc.tuned = {(n, h, w, fl): pc.cfg | hip.CFG_EXACT | fl}                     # classic instance, fp32 identity
+        ref = pc(x16, act=hip.ACT_LRELU, slope=0.01, res=r32, out_f16=out_f16).buf.clone()
+        for rep in range(3):                                                        # the LDS-DMA kernel, half identity (picked by the flag)
+            o = pc(x16, act=hip.ACT_LRELU, slope=0.01, res=r16, out_f16=out_f16)
+            assert o.dtype == ("f16" if out_f16 else "f32")
+            assert torch.equal(o.buf, ref), (out_f16, rep, (o.buf.float() - ref.float()).abs().max().item())

@@ -636,7 +636,6 @@ class PackedConv:
         # bf16 pieces themselves (CFG_OUT_SP3); the streaming / LDS-DMA configurations do not, so the tuner is held to the classic ones
         sp_out = (out.dtype == "sp3") if out is not None else bool(out_sp3 and _FP32_MODE == "split" and not use16 and co % 8 == 0
                                                                     and self.cfg in (0, 1, 2, 3) and (res is None or res.dtype == "f32"))
-        if out is None:
         # fp16 mode: the fp32 GDN / IGDN instance of the streaming 1x1 kernel may STORE half (the input -- operand and identity -- of a
         # residual block that runs on the fp16 path; part of that mode's tolerance like every VC_HALF_RESIDUAL tensor)
         gdn_half_ok = (_PRECISION == "fp16" and HALF_ACTIVATIONS and HALF_RESIDUAL and epi != EPI_NONE and self.k == 1 and self.cin == 128
