@@ -317,6 +317,14 @@ int vc_gc_forward(vc_stream s, vc_view y, vc_view scales, vc_view means, const f
                   int n_scales, float *likelihoods);
 /* decoder side: indexes from scales; y_hat = (sym + mu) * out_gain */
 int vc_gc_indexes(vc_stream s, vc_view scales, const float *scale_table, int n_scales, int32_t *indexes);
+/* Scale refinement: for the elements of `scales` (the first N output channels of the hyper-synthesis transform's last layer,
+ * conv3x3(cin -> 2N, stride 1, padding 1; LHBDC/model/layers.py:82-91) whose fp32 value lies within rel_eps (relative) of an
+ * entry of the scale table, recompute that layer's output from its input `in` and its ORIGINAL weights [2N][cin][3][3] / bias in
+ * fp64 and store the correctly rounded fp32 value -- the scale-table index then no longer depends on this platform's summation
+ * order (the CompressAI format carries no indexes: INTEGRATION.md, cross-platform limits).  counter (optional, device): +1 per
+ * refined element. */
+int vc_refine_scales(vc_stream s, vc_view scales, vc_view in, const float *w_oihw, const float *bias, const float *scale_table,
+                     int n_scales, float rel_eps, int *counter);
 int vc_gc_dequant(vc_stream s, const int32_t *symbols, vc_view means, const float *out_gain, vc_view y_hat);
 /* Deterministic two-stage reduction of the per-workgroup partial sums written by the kernels above:
  * out[i] = sum_j partial[i*slots + j], i < count. */

@@ -73,8 +73,26 @@ def test_end_to_end_containers_against_the_cpu_path(dev, h, w):
     triples = [triple(s, h, w) for s in SEEDS]
     refs = pool.run_jobs(triples, pool.lhbdc_encode_job(ora.state_dict()))
     identical, report = 0, []
+    from vcamd import hip
+    flips = {False: 0, True: 0}          # scale-table indexes differing from the CPU path's, without / with vc_refine_scales
+    unaided = {False: 0, True: 0}        # CPU-path containers this decoder reads WITHOUT being handed the encoder's indexes
     with torch.no_grad():
         for seed, (xb, xc, xa), ref in zip(SEEDS, triples, refs):
+            # ---- round 5: the scales near a table entry recomputed in fp64 (hip.SCALE_REFINE) against plain fp32 scales ----
+            for refine in (False, True):
+                hip.SCALE_REFINE = refine
+                tr = {}
+                lhbdc.encode_B(prod, xa.to(dev), xc.to(dev), xb.to(dev), trace=tr)
+                flips[refine] += sum(int((torch.from_numpy(tr[c]["y_idx"]).reshape(-1) != ref[c]["y_idx"].reshape(-1)).sum()) for c in ("mv", "res"))
+                _, s_mv, s_res, sh_mv, sh_res = lhbdc.read_container(ref["container"])
+                try:
+                    td = {}
+                    lhbdc.decode_B(xb.to(dev), xa.to(dev), prod, s_mv, s_res, sh_mv, sh_res, trace=td)
+                    ok = all(int((torch.from_numpy(td[c]["y_sym"]).reshape(-1) != ref[c]["y_sym"].reshape(-1)).sum()) == 0 for c in ("mv", "res"))
+                except hip.VcError:
+                    ok = False
+                unaided[refine] += ok
+            hip.SCALE_REFINE = True
             trace = {}
             mv_bits, res_bits = lhbdc.encode_B(prod, xa.to(dev), xc.to(dev), xb.to(dev), trace=trace)
             blob = lhbdc.write_container(None, 1626, mv_bits, res_bits)
@@ -96,6 +114,8 @@ def test_end_to_end_containers_against_the_cpu_path(dev, h, w):
                 check_teacher_forced(f"triple {seed}: residual_compressor", teacher_forced(prod.residual_compressor, ref["res"], dev))
             assert abs(len(blob) - len(ref["container"])) <= max(64, 0.001 * len(blob)), (seed, len(blob), len(ref["container"]))
     print(f"end-to-end encode_B containers byte-identical to the CPU path: {identical} of {len(SEEDS)} ({h}x{w}, calibrated checkpoint)")
+    print(f"scale-table indexes differing from the CPU path's over the {len(SEEDS)} frames: {flips[False]} with plain fp32 scales, {flips[True]} with "
+          f"vc_refine_scales; CPU-path containers the HIP decoder reads unaided (no index override): {unaided[False]} / {unaided[True]} of {len(SEEDS)}")
     for seed, same, n, m, sym, idx in report:
         print(f"  triple {seed}: {'identical' if same else 'DIFFERENT'} ({n} vs {m} bytes); symbols differing {sym}; indexes differing {idx}")
     if h * w <= 192 * 256:

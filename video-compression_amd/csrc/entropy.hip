@@ -382,3 +382,77 @@ extern "C" int vc_psnr_uint8(vc_stream s, const float *a_chw, const float *b_chw
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Scale refinement (round 5; DESIGN section 8 (5) of round 4): the scale-table index of a latent is the fragile integer of the
+// CompressAI format -- a scale within fp32 summation noise of one of the 64 table entries lands in the neighbouring bin on another
+// platform.  For exactly those elements (relative distance to a table entry <= rel_eps) the last hyper-synthesis layer
+// (LHBDC/model/layers.py:82-91: conv3x3(3N/2 -> 2N), first N output channels = the scales) is recomputed in fp64 -- 9 * cin exact
+// products, double accumulation, ONE rounding to fp32: this side's value is then the correctly rounded one, independent of any
+// summation order.  ~1e-4 of the elements: a few hundred dot products per frame.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_refine_scales(vc_view sc, vc_view in, const float *__restrict__ w, const float *__restrict__ bias,
+                                                       const float *__restrict__ table, int n_scales, float rel_eps, int *__restrict__ counter)
+{
+    const long long total = (long long)sc.n * sc.h * sc.w * sc.c;
+    const int lane = threadIdx.x & 63;
+    const int cin = in.c, kk = 9 * cin;
+    const float lt0 = logf(table[0]), step = (logf(table[n_scales - 1]) - lt0) / (float)(n_scales - 1);
+    const long long nwave = (long long)gridDim.x * (blockDim.x >> 6), wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (long long base = wave0 * 64; base < total; base += nwave * 64) {
+        const long long i = base + lane;
+        bool near = false;
+        if (i < total) {
+            const int c = (int)(i % sc.c);
+            long long t = i / sc.c;
+            const int x = (int)(t % sc.w); t /= sc.w;
+            const int y = (int)(t % sc.h);
+            const int n = (int)(t / sc.h);
+            const float s = sc.p[view_off(sc, n, y, x) + c];
+            if (s > table[0] * (1.0f - rel_eps)) {
+                int k = (int)floorf((logf(s) - lt0) / step + 0.5f);
+                k = min(max(k, 0), n_scales - 1);
+                // (the table is log-spaced only up to fp32 rounding of exp(): test the neighbours too)
+                for (int j = max(k - 1, 0); j <= min(k + 1, n_scales - 1); ++j) near = near || fabsf(s - table[j]) <= rel_eps * table[j];
+            }
+        }
+        unsigned long long mask = __ballot(near);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const long long e = base + src;                    // wave-uniform
+            const int c = (int)(e % sc.c);
+            long long t = e / sc.c;
+            const int x = (int)(t % sc.w); t /= sc.w;
+            const int y = (int)(t % sc.h);
+            const int n = (int)(t / sc.h);
+            double acc = 0.0;
+            for (int idx = lane; idx < kk; idx += 64) {
+                const int tap = idx / cin, ci = idx - tap * cin;
+                const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                if (iy >= 0 && iy < in.h && ix >= 0 && ix < in.w)
+                    acc = fma((double)in.p[view_off(in, n, iy, ix) + ci], (double)w[((long long)c * cin + ci) * 9 + tap], acc);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) {
+                sc.p[view_off(sc, n, y, x) + c] = (float)(acc + (double)(bias ? bias[c] : 0.0f));
+                if (counter) atomicAdd(counter, 1);
+            }
+        }
+    }
+}
+
+extern "C" int vc_refine_scales(vc_stream s, vc_view scales, vc_view in, const float *w_oihw, const float *bias, const float *scale_table,
+                                int n_scales, float rel_eps, int *counter)
+{
+    if (!scales.p || !in.p || !w_oihw || !scale_table || n_scales < 2 || scales.n != in.n || scales.h != in.h || scales.w != in.w ||
+        !(rel_eps > 0.0f) || rel_eps > 1e-2f)
+        return VC_EINVAL;
+    const long long total = (long long)scales.n * scales.h * scales.w * scales.c;
+    if (total <= 0) return VC_OK;
+    hipLaunchKernelGGL(k_refine_scales, dim3(ew_grid((total + 63) / 64 * 64, 256)), dim3(256), 0, as_stream(s), scales, in, w_oihw, bias, scale_table,
+                       n_scales, rel_eps, counter);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}

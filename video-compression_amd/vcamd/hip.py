@@ -161,6 +161,7 @@ def lib():
     sig("vc_eb_dequant", ci, vp, vp, vp, vp, View)
     sig("vc_gc_forward", ci, vp, View, View, View, vp, vp, View, vp, ci, vp, vp, vp, vp, ci, vp)
     sig("vc_gc_indexes", ci, vp, View, vp, ci, vp)
+    sig("vc_refine_scales", ci, vp, View, View, vp, vp, vp, ci, cf, vp)
     sig("vc_gc_dequant", ci, vp, vp, View, vp, View)
     sig("vc_bits_reduce", ci, vp, vp, ci, ci, vp)
     sig("vc_bits_slots", ci)
@@ -184,7 +185,7 @@ EXPORTED_SYMBOLS = [
     "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
-    "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes",
+    "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes", "vc_refine_scales",
     "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_psnr_uint8", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes", "vc_rans_decode_stream",
     # the operator spellings of SURVEY.md 8(b), thin forwards (csrc/abi_aliases.cpp)
@@ -359,6 +360,11 @@ FUSE_TAIL = bool(int(os.environ.get("VC_FUSE_TAIL", "1")))
 # group: one 16-byte gather per corner instead of two; the kernel is bound by its gathers).  Offsets, modulation, bilinear
 # weights and accumulation stay fp32.  VC_HALF_DEFORM=0 gathers fp32 features (A/B, tests).
 HALF_DEFORM = bool(int(os.environ.get("VC_HALF_DEFORM", "1")))
+# Bitstream paths (compress / decompress): scales within SCALE_REFINE_EPS (relative) of a scale-table entry are recomputed in fp64
+# from the last hyper-synthesis layer's input (vc_refine_scales): this side's table indexes stop depending on its summation order.
+# VC_SCALE_REFINE=0 keeps the plain fp32 scales (A/B, tests).
+SCALE_REFINE = bool(int(os.environ.get("VC_SCALE_REFINE", "1")))
+SCALE_REFINE_EPS = 2e-5
 
 
 def set_conv_precision(mode):

@@ -596,6 +596,34 @@ class MeanScaleHyperprior(_Prepared):
         """(gain, inv_gain, hyper_gain, hyper_inv_gain) device vectors or Nones (Flex overrides)."""
         return None, None, None, None
 
+    def _hs_for_bitstream(self, z_hat):
+        """Hyper-synthesis for the BITSTREAM paths (compress / decompress): the scales whose table index could go either way -- within
+        hip.SCALE_REFINE_EPS of a table entry -- are recomputed in fp64 from the last layer's input (vc_refine_scales), so this
+        side's indexes do not depend on its fp32 summation order.  Encoder and decoder call the same function: identical indexes."""
+        mods = list(self.h_s)
+        last = mods[-1]
+        if not (hip.SCALE_REFINE and isinstance(last, nn.Conv2d) and tuple(last.kernel_size) == (3, 3) and tuple(last.stride) == (1, 1)
+                and last.out_channels == 2 * self.M):
+            return run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        head = self._cache["h_s"].get("head")
+        if head is None:
+            head = self._cache["h_s"]["head"] = nn.Sequential(*mods[:-1])
+        t = run_sequential(head, z_hat, self._cache["h_s"])
+        if t.dtype != "f32":
+            raise hip.VcError("scale refinement reads the last hyper-synthesis layer's input in fp32")
+        tail = self._cache["h_s"].get("tail")
+        if tail is None:
+            tail = self._cache["h_s"]["tail"] = nn.Sequential(last)
+        gp = run_sequential(tail, t, self._cache["h_s"])
+        table = self._scale_table_dev()
+        w = last.weight.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        hip.check(hip.lib().vc_refine_scales(hip.stream(), gp.channels(0, self.M).view(), t.view(), w.data_ptr(),
+                                             None if last.bias is None else last.bias.detach().data_ptr(), table.data_ptr(), table.numel(),
+                                             hip.SCALE_REFINE_EPS, None), "vc_refine_scales")
+        return gp
+
     def forward_t(self, x, bits, gains=(None, None, None, None), likelihoods=None, trace=None):
         """x: T [n,h,w,c_in] -> x_hat T; appends two rows (y then z) PER IMAGE to the BitCounter.
         ``likelihoods``: a dict that receives the per-element likelihood tensors "y" [n,M,h/16,w/16] and "z"
@@ -671,7 +699,7 @@ class MeanScaleHyperprior(_Prepared):
         hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
                                   None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
                                   z_hat.view(), z_sym.data_ptr(), None, 0, None), "vc_eb_forward")
-        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        gp = self._hs_for_bitstream(z_hat)
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
         y_sym = torch.empty(y.n * y.c * y.h * y.w, dtype=torch.int32, device=dev)
@@ -715,7 +743,7 @@ class MeanScaleHyperprior(_Prepared):
         hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
                                   None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
                                   z_hat.view(), z_sym.data_ptr(), None, 0, None), "vc_eb_forward")
-        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        gp = self._hs_for_bitstream(z_hat)
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
         y_hat = T.empty(y.n, y.h, y.w, y.c, dev)
@@ -738,7 +766,7 @@ class MeanScaleHyperprior(_Prepared):
         z_hat = T.empty(n, hz, wz, self.N, device)
         hip.check(L.vc_eb_dequant(hip.stream(), z_sym_d.data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
                                   None if hig is None else hig.data_ptr(), z_hat.view()), "vc_eb_dequant")
-        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        gp = self._hs_for_bitstream(z_hat)
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
         idx_d = torch.empty((n, m * gp.h * gp.w), dtype=torch.int32, device=device)
@@ -775,7 +803,7 @@ class MeanScaleHyperprior(_Prepared):
         z_hat = T.empty(n, hz, wz, c, device)
         hip.check(L.vc_eb_dequant(hip.stream(), z_sym_d.data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
                                   None if hig is None else hig.data_ptr(), z_hat.view()), "vc_eb_dequant")
-        gp = run_sequential(self.h_s, z_hat, self._cache["h_s"])
+        gp = self._hs_for_bitstream(z_hat)
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
         idx_d = torch.empty(n * m * gp.h * gp.w, dtype=torch.int32, device=device)
