@@ -203,9 +203,15 @@ int vc_f32nchw_to_u8hwc(vc_stream s, const float *src_nchw, int hp, int wp, uint
 int vc_avgpool_reflectpad(vc_stream s, vc_view in, vc_view out, int k, float scale);
 /* nn.MaxPool2d(2,2) (layers.py:200) */
 int vc_maxpool2(vc_stream s, vc_view in, vc_view out);
+/* The same on a split tensor ([n][c/8][h][w][3][8] bf16, see VC_CFG_SPLIT; image strides in bytes, 0 = dense), split result:
+ * between the split-operand encoder layers of the mask U-Net. */
+int vc_maxpool2_sp3(vc_stream s, const void *in_split, long long in_image_bytes, int n, int h, int w, int c, void *out_split,
+                    long long out_image_bytes);
 /* F.interpolate / nn.Upsample bilinear by an integer factor (layers.py:232,238,244; m.py:30;
  * unet.py:63), out = scale * bilinear(in); out.h/out.w = factor * in.h/in.w. */
 int vc_upsample_bilinear(vc_stream s, vc_view in, vc_view out, int factor, int align_corners, float scale);
+/* The same with a split tensor as the result (the up-sampled part of a concat buffer a split-operand convolution reads). */
+int vc_upsample_bilinear_sp3(vc_stream s, vc_view in, void *out_split, long long out_image_bytes, int factor, int align_corners, float scale);
 /* out = alpha*a + beta*b (b may be NULL-pointer view with p==0) -- m.py:52,56-59,71 */
 int vc_axpby(vc_stream s, vc_view a, vc_view b, vc_view out, float alpha, float beta);
 /* out = clamp(a, 0, 1) on views: a decoded frame before it serves as a reference (ICIP2024/src/test.py:94, src/utils.py:194) */

@@ -204,3 +204,42 @@ def test_native_layers_write_split_tensors_and_split_layers_add_split_residuals(
     pc(x, act=hip.ACT_LRELU, slope=0.01, out=o_wide.channels(128, 256))
     assert torch.equal(_unsplit(o_wide.channels(128, 256)), hip.nhwc_to_nchw(pc(x, act=hip.ACT_LRELU, slope=0.01)).cpu())
     assert float(_unsplit(o_wide.channels(0, 128)).abs().max()) == 0.0
+
+
+def test_pooling_and_upsampling_on_split_tensors(dev):
+    """vc_maxpool2_sp3 / vc_upsample_bilinear_sp3 (the mask U-Net between split-operand layers, LHBDC/model/layers.py:200-246): exactly the
+    fp32 kernels followed by vc_split3, also into a window of planes of a wider split tensor."""
+    from vcamd import hip
+    g = torch.Generator().manual_seed(31)
+    x = hip.nchw_to_nhwc(torch.randn(2, 64, 48, 80, generator=g).to(dev))
+    xs = hip.split3(x)
+    assert torch.equal(_unsplit(hip.maxpool2(xs)), hip.nhwc_to_nchw(hip.maxpool2(x)).cpu())
+    wide = hip.T.empty(2, 96, 160, 96, dev, "sp3")
+    wide.buf.zero_()
+    hip.upsample_bilinear(x, 2, out=wide.channels(32, 96))
+    assert torch.equal(_unsplit(wide.channels(32, 96)), hip.nhwc_to_nchw(hip.upsample_bilinear(x, 2)).cpu())
+    assert float(_unsplit(wide.channels(0, 32)).abs().max()) == 0.0
+    pooled = hip.maxpool2(wide.channels(32, 96))            # a window as the input
+    assert torch.equal(_unsplit(pooled), hip.nhwc_to_nchw(hip.maxpool2(hip.upsample_bilinear(x, 2))).cpu())
+
+
+def test_masknet_through_split_tensors_equals_the_conversion_path(dev):
+    """Mask.run at a size where every layer takes the split pipeline: concat buffers as split tensors written by the producers == the
+    same layers with fp32 concat buffers converted by vc_split3 (bit for bit: split tensors are exact)."""
+    from vcamd import hip, lhbdc
+    hip.set_fp32_mode("split")
+    torch.manual_seed(5)
+    m = lhbdc.Mask().to(dev).eval()
+    x = hip.nchw_to_nhwc(torch.rand(1, 6, 544, 960, generator=torch.Generator().manual_seed(6)).to(dev))
+    with torch.no_grad():
+        a = hip.nhwc_to_nchw(m.run(x)).cpu()
+        keep = hip.wants_split_at
+        try:
+            hip.wants_split_at = lambda pc, n, h, w: False if (pc is m._packed["deconv3"]) else keep(pc, n, h, w)   # forces the fp32-buffer path
+            b = hip.nhwc_to_nchw(m.run(x)).cpu()
+        finally:
+            hip.wants_split_at = keep
+        hip.set_fp32_mode("native")
+        c = hip.nhwc_to_nchw(m.run(x)).cpu()
+    print(f"mask net 544x960: split-streaming vs conversion path max|d| {float((a - b).abs().max()):.2e}; vs native {float((a - c).abs().max()):.2e}")
+    assert float((a - c).abs().max()) < 1e-4

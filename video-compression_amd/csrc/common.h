@@ -46,6 +46,53 @@ static inline int ew_grid(long long work_items, int block)
     return (int)g;
 }
 
+// ---- split tensors ([n][c/8][h][w][3 pieces][8 channels] bf16; csrc/conv_split.h) ----
+// bf16 pieces of an fp32 value by truncation: hi = top 16 bits, the remainder x - hi is exact, and so on; lo is exact (<= 8 bits left)
+__device__ __forceinline__ void vc_split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    const unsigned ux = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, ux);
+    const unsigned um = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, um);
+    h = ux;
+    m = um;
+    l = __builtin_bit_cast(unsigned, r2);
+}
+// 4 consecutive channels (c % 4 == 0) of one pixel into its split record: 3 x 8 bytes.  `rec`: the 48-byte record of the pixel's
+// group of 8 channels; `half`: 0 / 1 = channels 0-3 / 4-7 of the group
+__device__ __forceinline__ void vc_store_split4(unsigned char *rec, int half, const f32x4 &v)
+{
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vc_split3(v[e], h[e], m[e], l[e]);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+    const u32x2 pm = {(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+    const u32x2 pl = {(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+    unsigned char *d = rec + 8 * half;
+    *reinterpret_cast<u32x2 *>(d) = ph;
+    *reinterpret_cast<u32x2 *>(d + 16) = pm;
+    *reinterpret_cast<u32x2 *>(d + 32) = pl;
+}
+// the exact fp32 values back out of a split record (hi + mid + lo with lo + mid first: both partial sums are representable)
+__device__ __forceinline__ f32x4 vc_load_split4(const unsigned char *rec, int half)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned char *s = rec + 8 * half;
+    const u32x2 ph = *reinterpret_cast<const u32x2 *>(s), pm = *reinterpret_cast<const u32x2 *>(s + 16), pl = *reinterpret_cast<const u32x2 *>(s + 32);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // (element 2 i sits in the low half of word i, element 2 i + 1 in the high half)
+        const unsigned wh = ph[e >> 1], wm = pm[e >> 1], wl = pl[e >> 1];
+        const float hi = __builtin_bit_cast(float, (e & 1) ? (wh & 0xffff0000u) : (wh << 16));
+        const float mi = __builtin_bit_cast(float, (e & 1) ? (wm & 0xffff0000u) : (wm << 16));
+        const float lo = __builtin_bit_cast(float, (e & 1) ? (wl & 0xffff0000u) : (wl << 16));
+        r[e] = (lo + mi) + hi;
+    }
+    return r;
+}
+
 __device__ __forceinline__ long long view_off(const vc_view &v, int n, int y, int x)
 {
     return (long long)n * v.sn + (long long)y * v.sh + (long long)x * v.sw;

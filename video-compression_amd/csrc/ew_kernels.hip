@@ -149,6 +149,46 @@ __global__ void k_maxpool2(vc_view in, vc_view out)
     }
 }
 
+// nn.MaxPool2d(2, 2) on a SPLIT tensor, split result (between the split-operand encoder layers of the mask U-Net, LHBDC/model/
+// layers.py:200,224-230): the pieces of a record sum to the exact fp32 value, the maximum is split again -- bit for bit what the fp32
+// kernel followed by vc_split3 gives.
+__global__ void k_maxpool2_sp3(const unsigned char *__restrict__ in, long long in_img_bytes, int n_img, int h, int w, int cg,
+                               unsigned char *__restrict__ out, long long out_img_bytes)
+{
+    const int oh = h >> 1, ow = w >> 1;
+    const long long total = (long long)n_img * cg * oh * ow * 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int half = (int)(i & 1);
+        long long t = i >> 1;
+        const int x = (int)(t % ow); t /= ow;
+        const int y = (int)(t % oh); t /= oh;
+        const int g = (int)(t % cg);
+        const int n = (int)(t / cg);
+        const unsigned char *b = in + n * in_img_bytes + (((long long)g * h + 2 * y) * w + 2 * x) * 48;
+        const f32x4 a0 = vc_load_split4(b, half), a1 = vc_load_split4(b + 48, half);
+        const f32x4 a2 = vc_load_split4(b + (long long)w * 48, half), a3 = vc_load_split4(b + (long long)w * 48 + 48, half);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaxf(a0[e], a1[e]), fmaxf(a2[e], a3[e]));
+        vc_store_split4(out + n * out_img_bytes + (((long long)g * oh + y) * ow + x) * 48, half, v);
+    }
+}
+
+extern "C" int vc_maxpool2_sp3(vc_stream s, const void *in_split, long long in_image_bytes, int n, int h, int w, int c, void *out_split,
+                               long long out_image_bytes)
+{
+    if (!in_split || !out_split || n < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || (c % 8) || ((uintptr_t)in_split % 8) || ((uintptr_t)out_split % 8) ||
+        (in_image_bytes % 8) || (out_image_bytes % 8))
+        return VC_EINVAL;
+    const long long ii = in_image_bytes ? in_image_bytes : (long long)(c / 8) * h * w * 48;
+    const long long oi = out_image_bytes ? out_image_bytes : (long long)(c / 8) * (h / 2) * (w / 2) * 48;
+    const long long total = (long long)n * (c / 8) * (h / 2) * (w / 2) * 2;
+    hipLaunchKernelGGL(k_maxpool2_sp3, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), static_cast<const unsigned char *>(in_split), ii,
+                       n, h, w, c / 8, static_cast<unsigned char *>(out_split), oi);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
 __global__ void k_maxpool2_v4(vc_view in, vc_view out)
 {
     const int c4n = out.c >> 2;
@@ -254,9 +294,66 @@ __global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int 
     }
 }
 
+// The same into a SPLIT tensor (the up-sampled half of a concat buffer a split-operand convolution reads: LHBDC/model/layers.py:
+// 232-246): one lane per 48-byte record (8 channels of a pixel), consecutive lanes consecutive pixels: three 16-byte stores per lane
+// that together cover a contiguous run.
+__global__ void k_upsample_bilinear_sp3(vc_view in, unsigned char *__restrict__ out, long long out_img_bytes, int factor, int align_corners, float scale)
+{
+    const int cg = in.c >> 3, oh = in.h * factor, ow = in.w * factor;
+    const long long total = (long long)in.n * cg * oh * ow;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        long long t = i;
+        const int x = (int)(t % ow); t /= ow;
+        const int y = (int)(t % oh); t /= oh;
+        const int g = (int)(t % cg);
+        const int n = (int)(t / cg);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        bilinear_src(y, in.h, oh, factor, align_corners, y0, y1, ly0, ly1);
+        bilinear_src(x, in.w, ow, factor, align_corners, x0, x1, lx0, lx1);
+        const float *b = in.p + (long long)n * in.sn + 8 * g;
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const f32x4 v00 = *reinterpret_cast<const f32x4 *>(b + (long long)y0 * in.sh + (long long)x0 * in.sw + 4 * hf);
+            const f32x4 v01 = *reinterpret_cast<const f32x4 *>(b + (long long)y0 * in.sh + (long long)x1 * in.sw + 4 * hf);
+            const f32x4 v10 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x0 * in.sw + 4 * hf);
+            const f32x4 v11 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x1 * in.sw + 4 * hf);
+            const f32x4 v = (ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11)) * scale;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vc_split3(v[e], h[e], m[e], l[e]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                ph[2 * hf + e] = (h[2 * e] >> 16) | h[2 * e + 1];
+                pm[2 * hf + e] = (m[2 * e] >> 16) | m[2 * e + 1];
+                pl[2 * hf + e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
+            }
+        }
+        unsigned char *dst = out + n * out_img_bytes + (((long long)g * oh + y) * ow + x) * 48;
+        *reinterpret_cast<u32x4 *>(dst) = ph;
+        *reinterpret_cast<u32x4 *>(dst + 16) = pm;
+        *reinterpret_cast<u32x4 *>(dst + 32) = pl;
+    }
+}
+
 static inline bool view_vec4(const vc_view &v)
 {
     return (v.c % 4) == 0 && (v.sw % 4) == 0 && (v.sh % 4) == 0 && (v.sn % 4) == 0 && ((uintptr_t)v.p % 16) == 0;
+}
+
+extern "C" int vc_upsample_bilinear_sp3(vc_stream s, vc_view in, void *out_split, long long out_image_bytes, int factor, int align_corners,
+                                        float scale)
+{
+    if (!in.p || !out_split || factor < 1 || (in.c % 8) || !view_vec4(in) || ((uintptr_t)out_split % 16) || (out_image_bytes % 16)) return VC_EINVAL;
+    const long long img = out_image_bytes ? out_image_bytes : (long long)(in.c / 8) * in.h * factor * in.w * factor * 48;
+    const long long total = (long long)in.n * (in.c / 8) * in.h * factor * in.w * factor;
+    if (total <= 0) return VC_OK;
+    hipLaunchKernelGGL(k_upsample_bilinear_sp3, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in,
+                       static_cast<unsigned char *>(out_split), img, factor, align_corners, scale);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
 }
 
 extern "C" int vc_upsample_bilinear(vc_stream s, vc_view in, vc_view out, int factor, int align_corners, float scale)

@@ -138,6 +138,8 @@ def lib():
     sig("vc_f32nchw_to_u8hwc", ci, vp, vp, ci, ci, vp, ci, ci)
     sig("vc_avgpool_reflectpad", ci, vp, View, View, ci, cf)
     sig("vc_maxpool2", ci, vp, View, View)
+    sig("vc_maxpool2_sp3", ci, vp, vp, cll, ci, ci, ci, ci, vp, cll)
+    sig("vc_upsample_bilinear_sp3", ci, vp, View, vp, cll, ci, ci, cf)
     sig("vc_upsample_bilinear", ci, vp, View, View, ci, ci, cf)
     sig("vc_axpby", ci, vp, View, View, View, cf, cf)
     sig("vc_clamp01", ci, vp, View, View)
@@ -182,7 +184,7 @@ EXPORTED_SYMBOLS = [
     "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
     "vc_conv_pack_weights_f16", "vc_conv_pack_tail_f16", "vc_conv2d_nhwc", "vc_conv_packed_weight_bytes_split",
     "vc_conv_pack_weights_split", "vc_split3", "vc_nchw_to_nhwc",
-    "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_upsample_bilinear", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
+    "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_maxpool2_sp3", "vc_upsample_bilinear", "vc_upsample_bilinear_sp3", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes", "vc_refine_scales",
@@ -729,6 +731,11 @@ def avgpool_reflectpad(x, k, scale=1.0, out_h=None, out_w=None):
 
 
 def maxpool2(x):
+    if x.dtype == "sp3":          # between split-operand layers: split in, split out (exactly maxpool + vc_split3)
+        out = T.empty(x.n, x.h // 2, x.w // 2, x.c, x.buf.device, "sp3")
+        timed_hbm(f"k_maxpool2_sp3 c{x.c} @{x.n}x{x.h}x{x.w}", 6.0 * x.n * x.c * (x.h * x.w + out.h * out.w),
+                  lambda: check(lib().vc_maxpool2_sp3(stream(), x.ptr, x.image_bytes, x.n, x.h, x.w, x.c, out.ptr, out.image_bytes), "vc_maxpool2_sp3"))
+        return out
     out = T.empty(x.n, x.h // 2, x.w // 2, x.c, x.buf.device)
     check(lib().vc_maxpool2(stream(), x.view(), out.view()), "vc_maxpool2")
     return out
@@ -737,6 +744,11 @@ def maxpool2(x):
 def upsample_bilinear(x, factor, align_corners=False, scale=1.0, out=None):
     if out is None:
         out = T.empty(x.n, x.h * factor, x.w * factor, x.c, x.buf.device)
+    if out.dtype == "sp3":        # the up-sampled part of a concat buffer a split-operand convolution reads
+        timed_hbm(f"k_upsample_bilinear_sp3 x{factor} c{x.c} @{x.n}x{x.h}x{x.w}", x.n * x.c * (4.0 * x.h * x.w + 6.0 * out.h * out.w),
+                  lambda: check(lib().vc_upsample_bilinear_sp3(stream(), x.view(), out.ptr, out.image_bytes, factor, int(align_corners), scale),
+                                "vc_upsample_bilinear_sp3"))
+        return out
     timed_hbm(f"k_upsample_bilinear x{factor} c{x.c} @{x.n}x{x.h}x{x.w}", 4.0 * x.n * x.c * (x.h * x.w + out.h * out.w),
               lambda: check(lib().vc_upsample_bilinear(stream(), x.view(), out.view(), factor, int(align_corners), scale),
                             "vc_upsample_bilinear"))

@@ -233,6 +233,25 @@ class Mask(_Prepared):
                             ("conv1", "conv2", "conv3", "bottleneck", "deconv1", "deconv2", "deconv3", "conv4")}
         p, ch, dev = self._packed, self.ch, x.buf.device
         n, h, w = x.n, x.h, x.w
+        # fp32 mode "split" (frames large enough for every layer below to run on the split-operand pipeline): the concat buffers and
+        # everything between the encoder layers are SPLIT tensors -- conv1's classic epilogue, the split layers' epilogues, the
+        # pooling and the up-sampling kernels write the three bf16 pieces directly; no conversion pass
+        if all(hip.wants_split_at(p[k], n, h >> s, w >> s) for k, s in (("conv2", 1), ("conv3", 2), ("bottleneck", 3), ("deconv1", 2),
+                                                                           ("deconv2", 1), ("deconv3", 0))) and x.dtype == "f32":
+            cat3 = T.empty(n, h, w, ch * 3, dev, "sp3")              # [up(64) | conv1(32)]
+            cat2 = T.empty(n, h // 2, w // 2, ch * 6, dev, "sp3")    # [up(128) | conv2(64)]
+            cat1 = T.empty(n, h // 4, w // 4, ch * 8, dev, "sp3")    # [up(128) | conv3(128)]
+            s1 = p["conv1"](x, out=cat3.channels(ch * 2, ch * 3), act=hip.ACT_RELU)
+            s2 = p["conv2"](hip.maxpool2(s1), out=cat2.channels(ch * 4, ch * 6), act=hip.ACT_RELU)
+            s3 = p["conv3"](hip.maxpool2(s2), out=cat1.channels(ch * 4, ch * 8), act=hip.ACT_RELU)
+            b = p["bottleneck"](hip.maxpool2(s3), act=hip.ACT_RELU)
+            hip.upsample_bilinear(b, 2, out=cat1.channels(0, ch * 4))
+            d1 = p["deconv1"](cat1, act=hip.ACT_RELU)
+            hip.upsample_bilinear(d1, 2, out=cat2.channels(0, ch * 4))
+            d2 = p["deconv2"](cat2, act=hip.ACT_RELU)
+            hip.upsample_bilinear(d2, 2, out=cat3.channels(0, ch * 2))
+            d3 = p["deconv3"](cat3, act=hip.ACT_RELU)
+            return p["conv4"](d3, act=hip.ACT_SIGMOID)
         cat3 = T.empty(n, h, w, ch * 2 + ch, dev)              # [up(64) | conv1(32)]
         cat2 = T.empty(n, h // 2, w // 2, ch * 4 + ch * 2, dev)  # [up(128) | conv2(64)]
         cat1 = T.empty(n, h // 4, w // 4, ch * 8, dev)           # [up(128) | conv3(128)]
