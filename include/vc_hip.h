@@ -235,6 +235,9 @@ int vc_spynet_preprocess(vc_stream s, const float *src_nchw, vc_view dst);
  * warp_W1(second, up), up] (8 ch), and `up` alone (2 ch) for the residual add after the last conv. */
 int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second, vc_view flow_coarse,
                           vc_view feat8, vc_view up2);
+/* The same with the 8-channel level input written as a dense split tensor (one 48-byte record per pixel, see VC_CFG_SPLIT): the
+ * first 7x7 layer then reads it as it lies. */
+int vc_spynet_level_input_sp3(vc_stream s, vc_view first, vc_view second, vc_view flow_coarse, void *feat_split, vc_view up);
 
 /* LHBDC mask blend + residual (m.py:63-67): pred = m*fw + (1-m)*bw ; resid = cur - pred.
  * fwbw holds fw in channels 0..2 and bw in 3..5; mask has 1 channel. resid.p may be NULL. */

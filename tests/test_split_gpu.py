@@ -243,3 +243,29 @@ def test_masknet_through_split_tensors_equals_the_conversion_path(dev):
         c = hip.nhwc_to_nchw(m.run(x)).cpu()
     print(f"mask net 544x960: split-streaming vs conversion path max|d| {float((a - b).abs().max()):.2e}; vs native {float((a - c).abs().max()):.2e}")
     assert float((a - c).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(128, 128, 96, 160, 2), (64, 64, 50, 75, 1), (128, 64, 33, 170, 1)])
+def test_streaming_1x1_kernel_writes_split_tensors(dev, cin, cout, h, w, n):
+    """VC_CFG_OUT_SP3 on the streaming 1x1 kernel (csrc/conv_pws.hip, its own instances with the store counts the counted waits need):
+    plain / residual / residual-first epilogues -- the split tensor holds exactly the fp32 values the same configuration stores; three
+    repetitions (a wrong wait count shows as run-to-run differences)."""
+    from vcamd import hip
+    hip.set_fp32_mode("split")
+    g = torch.Generator().manual_seed(41)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    pc = hip.PackedConv(wt, torch.randn(cout, generator=g) * 0.1, device=dev)
+    assert hip.CFG_PWS in pc.candidates
+    x = hip.T.empty(n, h, w, cin, dev)
+    x.buf.normal_()
+    r = hip.T.empty(n, h, w, cout, dev)
+    r.buf.normal_()
+    for kw in (dict(act=hip.ACT_RELU), dict(act=hip.ACT_LRELU, slope=0.1, res=r), dict(act=hip.ACT_RELU, res=r, res_first=True)):
+        pc.tuned = {}
+        fl = hip.CFG_RES_FIRST if kw.get("res_first") else 0
+        pc.tuned[(n, h, w, fl)] = hip.CFG_PWS | hip.CFG_EXACT | fl
+        pc.tuned[(n, h, w, fl | hip.CFG_OUT_SP3)] = hip.CFG_PWS | hip.CFG_EXACT | fl | hip.CFG_OUT_SP3
+        ref = hip.nhwc_to_nchw(pc(x, **kw)).cpu()
+        for rep in range(3):
+            o = pc(x, out_sp3=True, **kw)
+            assert o.dtype == "sp3" and torch.equal(_unsplit(o), ref), (kw.keys(), rep)

@@ -228,7 +228,7 @@ extern "C" int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d)
         const int c0 = d->cfg & 0xff;
         const bool classic = c0 == VC_CFG_N128 || c0 == VC_CFG_N64 || c0 == VC_CFG_N32 || c0 == VC_CFG_N16 || c0 == VC_CFG_N128B || c0 == VC_CFG_N32T16;
         if ((a.in_sp3 || a.res_sp3) && c0 != VC_CFG_SPLIT) return VC_EINVAL;
-        if (a.out_sp3 && c0 != VC_CFG_SPLIT && (!classic || f16 || (d->out.c % 8))) return VC_EINVAL;
+        if (a.out_sp3 && c0 != VC_CFG_SPLIT && ((!classic && c0 != VC_CFG_PWS) || f16 || (d->out.c % 8))) return VC_EINVAL;
         if (a.out_sp3 && c0 != VC_CFG_SPLIT && !a.out_sn) a.out_sn = (long long)(d->out.c / 8) * d->out.h * d->out.w * 48;
     }
     if (a.tail_wpk && (!f16 || (d->cfg & 0xff) != VC_CFG_DMA)) return VC_EINVAL;             // the fused tail lives in the LDS-DMA kernel

@@ -50,12 +50,18 @@ template <int KQ_, int NT_, int PREC_> struct PwsCfg {      // PREC: 0 fp32, 1 f
     // profiles/r03/o_pw_check_residual_at_tile_start_variant.log).
     // Stores per tile: units of 16 pixels x 128 bytes, 2 per unit.
     static constexpr int NG32 = 2 * NT_, NG16 = 2 * ((NT_ + 1) / 2);
-    static constexpr int eops(bool half_plain) { return half_plain ? NG16 * 2 : NG32 * 2; }
+    // (a SPLIT output -- VC_CFG_OUT_SP3, fp32 instances -- stores three 8-byte pieces instead of one 16-byte group: 6 per unit)
+    static constexpr int eops(bool half_plain, bool osp = false) { return half_plain ? NG16 * 2 : NG32 * (osp ? 6 : 2); }
     static constexpr int nb(int s) { return (D - 1 - s >= 0) ? (D - 1 - s) / NSUB + 1 : 0; }
     static constexpr int clamp63(int n) { return n > 63 ? 63 : n; }
     // `young`: the wave's first steps, where the oldest of those epilogues is the one before the first tile -- there is none
-    static constexpr int wait_a(int s, bool half_plain, bool young) { return clamp63((D - 1) * NI + (nb(s) - (young ? 1 : 0)) * eops(half_plain)); }
+    static constexpr int wait_a(int s, bool half_plain, bool young, bool osp = false)
+    {
+        return clamp63((D - 1) * NI + (nb(s) - (young ? 1 : 0)) * eops(half_plain, osp));
+    }
     static constexpr int WAIT_RES = clamp63(2 * (NG32 - 1));
+    // split output: behind unit g's residual loads lie the loads of the units after it and the 6 g stores of the units before it
+    static constexpr int wait_res_sp(int g) { return clamp63(2 * (NG32 - 1 - g) + 6 * g); }
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -78,7 +84,7 @@ __device__ __forceinline__ f32x4 pws_load16(const void *uniform_base, unsigned l
 // accumulator 4 g + e of N-tile t), so the tile's x stays in 64 registers (squared on the way into the MFMA) and no second read
 // of the input exists.  The residual (the block's skip path) is then requested 16 pixels ahead of its use instead of a tile at
 // once: 64 registers fewer.
-template <class C, int RES, int GDN = 0> __global__ void __launch_bounds__(512, 2) conv_pws_kernel(const ConvArgs p)      // RES: 0 none, 1 fp32, 2 half
+template <class C, int RES, int GDN = 0, bool OSP = false> __global__ void __launch_bounds__(512, 2) conv_pws_kernel(const ConvArgs p)      // RES: 0 none, 1 fp32, 2 half
 {
     static_assert(GDN == 0 || (!C::F16 && C::KQ == 16 && C::NT == 4 && RES != 2), "GDN / IGDN: the fp32 128 -> 128 instance");
     constexpr int KQ = C::KQ, NT = C::NT, NSUB = C::NSUB, D = C::D, NI = C::NI, QPS = C::QPS, RPQ = C::RPQ, S = C::S;
@@ -187,6 +193,10 @@ template <class C, int RES, int GDN = 0> __global__ void __launch_bounds__(512, 
     constexpr bool has_res = RES != 0;                // a template parameter: the residual registers must not pass through a phi
     constexpr bool res_half = RES == 2;
     const int osz = p.out_f16 ? 2 : 4;           // (fp32 instances: the GDN / IGDN instance may store half, conv_api.hip)
+    // split output ([n][c/8][h][w][3][8] bf16, image stride out_sn in BYTES; fp32 instances): a TEMPLATE parameter -- the counted waits
+    // differ with it, and a run-time branch around a wait is what tools/check_inflight_regs.py rightly refuses
+    constexpr bool osp = OSP;
+    static_assert(!OSP || !F16, "split output: fp32 instances");
     const bool half_plain = osz == 2 && !has_res && !p.chscale && (p.out_sw % 8) == 0 && (p.out_sh % 8) == 0 && (p.out_sn % 8) == 0;
     const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
     const float *const bias_l = reinterpret_cast<const float *>(lds8 + C::BIAS_OFF);
@@ -240,6 +250,9 @@ template <class C, int RES, int GDN = 0> __global__ void __launch_bounds__(512, 
                 if (C::NG16 != C::NG32 && half_plain) {
                     if (young) vc_wait_vmcnt<C::wait_a(s, true, true)>();
                     else vc_wait_vmcnt<C::wait_a(s, true, false)>();
+                } else if constexpr (osp) {
+                    if (young) vc_wait_vmcnt<C::wait_a(s, false, true, true)>();
+                    else vc_wait_vmcnt<C::wait_a(s, false, false, true)>();
                 } else {
                     if (young) vc_wait_vmcnt<C::wait_a(s, false, true)>();
                     else vc_wait_vmcnt<C::wait_a(s, false, false)>();
@@ -359,10 +372,10 @@ template <class C, int RES, int GDN = 0> __global__ void __launch_bounds__(512, 
                     // unit g + 1 is requested before unit g is waited for: younger than unit g's loads are then the two stores
                     // of unit g - 1 and the two loads of unit g + 1
                     if constexpr (g + 1 < C::NG32) issue_res(std::integral_constant<int, g + 1>{});
-                    vc_wait_vmcnt<(g + 1 < C::NG32 ? 2 : 0) + (g > 0 ? 2 : 0)>();
+                    vc_wait_vmcnt<(g + 1 < C::NG32 ? 2 : 0) + (g > 0 ? (osp ? 6 : 2) : 0)>();
                     asm volatile("" : "+v"(rv[g & 1][0]), "+v"(rv[g & 1][1]));
                 } else if constexpr (has_res) {
-                    vc_wait_vmcnt<C::WAIT_RES>();
+                    vc_wait_vmcnt<osp ? C::wait_res_sp(g) : C::WAIT_RES>();
                     if constexpr (res_half) asm volatile("" : "+v"(rvh[g][0]), "+v"(rvh[g][1]));
                     else asm volatile("" : "+v"(rv[g][0]), "+v"(rv[g][1]));
                 }
@@ -393,7 +406,11 @@ template <class C, int RES, int GDN = 0> __global__ void __launch_bounds__(512, 
                     if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(lds8 + C::GAIN_OFF + (t * 32 + 4 * rq) * 4);
                     if constexpr (has_res) { if (!p.res_first) v += r; }
                     unsigned char *dst = obase + (pxc[part][j] * out_pix_bytes + (t * 32 + 4 * rq) * osz);
-                    if (osz == 2) {
+                    if constexpr (osp) {
+                        // the three bf16 pieces of the 4 channels into the pixel's record of group (4 t + rq / 2), half rq & 1
+                        vc_store_split4(out_b + (long long)tl.img * p.out_sn +
+                                            (((long long)(4 * t + (rq >> 1)) * p.H + tl.y) * p.W + tl.x0 + pxc[part][j]) * 48, rq & 1, v);
+                    } else if (osz == 2) {
                         const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                         *reinterpret_cast<f16x4 *>(dst) = hv;
                     } else {
@@ -406,9 +423,12 @@ template <class C, int RES, int GDN = 0> __global__ void __launch_bounds__(512, 
     vc_wait_vmcnt<0>();
 }
 
-template <class C, int RES, int GDN = 0> int launch_pws_res(hipStream_t st, const ConvArgs &a)
+template <class C, int RES, int GDN = 0, bool OSP = false> int launch_pws_res(hipStream_t st, const ConvArgs &a)
 {
-    auto kern = conv_pws_kernel<C, RES, GDN>;
+    if constexpr (!OSP && !C::F16 && RES != 2) {
+        if (a.out_sp3) return launch_pws_res<C, RES, GDN, true>(st, a);
+    }
+    auto kern = conv_pws_kernel<C, RES, GDN, OSP>;
     static vc_lds_raised raised;
     if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), C::LDS_BYTES, raised)) return VC_ELAUNCH;
     const long long ntiles = (long long)a.N * a.H * ((a.W + 31) / 32);
@@ -474,6 +494,7 @@ bool conv_pws_eligible(const ConvArgs &a, int k, int stride, bool f16)
         a.out_sw * 4 * 32 >= (1ll << 31)) return false;
     if (f16 && a.in_f16 && ((a.in_sw % 8) || (a.in_sh % 8) || (a.in_sn % 8) || ((uintptr_t)a.in % 16))) return false;
     if (!f16 && (a.in_f16 || (a.out_f16 && a.epi == VC_EPI_NONE))) return false;
+    if (a.out_sp3 && (f16 || a.out_f16 || (a.Cout % 8))) return false;      // split output: the fp32 instances
     return true;
 }
 

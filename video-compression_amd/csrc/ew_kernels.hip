@@ -268,6 +268,17 @@ __global__ void k_upsample_bilinear(vc_view in, vc_view out, int factor, int ali
     }
 }
 
+// one bilinear sample of 4 channels: ONE definition (contraction pinned off) shared by the fp32 and the split-tensor kernel, so that
+// the two give the same bits whatever the compiler makes of the code around it
+__device__ __forceinline__ f32x4 bilinear4(const f32x4 &v00, const f32x4 &v01, const f32x4 &v10, const f32x4 &v11, float lx0, float lx1,
+                                           float ly0, float ly1, float scale)
+{
+#pragma clang fp contract(off)
+    const f32x4 top = lx0 * v00 + lx1 * v01, bot = lx0 * v10 + lx1 * v11;
+    const f32x4 v = ly0 * top + ly1 * bot;
+    return v * scale;
+}
+
 // 4 channels per lane (16-byte loads/stores) when the views allow it: the U-Net up-sampling layers move
 // hundreds of MB per call and are purely HBM-bound
 __global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int align_corners, float scale)
@@ -289,8 +300,7 @@ __global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int 
         const f32x4 v01 = *reinterpret_cast<const f32x4 *>(b + (long long)y0 * in.sh + (long long)x1 * in.sw);
         const f32x4 v10 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x0 * in.sw);
         const f32x4 v11 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x1 * in.sw);
-        const f32x4 v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-        *reinterpret_cast<f32x4 *>(out.p + view_off(out, n, y, x) + c) = v * scale;
+        *reinterpret_cast<f32x4 *>(out.p + view_off(out, n, y, x) + c) = bilinear4(v00, v01, v10, v11, lx0, lx1, ly0, ly1, scale);
     }
 }
 
@@ -320,7 +330,7 @@ __global__ void k_upsample_bilinear_sp3(vc_view in, unsigned char *__restrict__ 
             const f32x4 v01 = *reinterpret_cast<const f32x4 *>(b + (long long)y0 * in.sh + (long long)x1 * in.sw + 4 * hf);
             const f32x4 v10 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x0 * in.sw + 4 * hf);
             const f32x4 v11 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x1 * in.sw + 4 * hf);
-            const f32x4 v = (ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11)) * scale;
+            const f32x4 v = bilinear4(v00, v01, v10, v11, lx0, lx1, ly0, ly1, scale);
             unsigned h[4], m[4], l[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) vc_split3(v[e], h[e], m[e], l[e]);
@@ -722,7 +732,9 @@ extern "C" int vc_spynet_preprocess(vc_stream s, const float *src, vc_view dst)
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <bool VEC> __global__ void k_spynet_level_input(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
+// SP3: the 8-channel level input as ONE split record per pixel (`feat.p` = the dense split tensor [n][1][h][w][3][8] bf16): the
+// first Basic-block layer runs on the split-operand pipeline and reads it as it lies (no fp32 copy, no conversion pass)
+template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
 {
     const long long total = (long long)feat.n * feat.h * feat.w;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -755,7 +767,30 @@ template <bool VEC> __global__ void k_spynet_level_input(vc_view first, vc_view 
         const float w1 = sample_bilinear(s2 + 1, second.sh, second.sw, second.h, second.w, gx, gy, true);
         const float w2 = sample_bilinear(s2 + 2, second.sh, second.sw, second.h, second.w, gx, gy, true);
         float *q = up.p + view_off(up, n, y, x);
-        if (VEC) {      // the 8 channels of a pixel as two 16-byte stores (eight 4-byte stores touched every line eight times)
+        if (SP3) {
+            const f32x4 lo = {f1[0], f1[1], f1[2], w0}, hi = {w1, w2, u, v};
+            unsigned char *rec = reinterpret_cast<unsigned char *>(feat.p) + (((long long)n * feat.h + y) * feat.w + x) * 48;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 ph, pm, pl;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const f32x4 vv = hf ? hi : lo;
+                unsigned h4[4], m4[4], l4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vc_split3(vv[e], h4[e], m4[e], l4[e]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    ph[2 * hf + e] = (h4[2 * e] >> 16) | h4[2 * e + 1];
+                    pm[2 * hf + e] = (m4[2 * e] >> 16) | m4[2 * e + 1];
+                    pl[2 * hf + e] = (l4[2 * e] >> 16) | (l4[2 * e + 1] & 0xffff0000u);
+                }
+            }
+            *reinterpret_cast<u32x4 *>(rec) = ph;
+            *reinterpret_cast<u32x4 *>(rec + 16) = pm;
+            *reinterpret_cast<u32x4 *>(rec + 32) = pl;
+            const f32x2 uv = {u, v};
+            *reinterpret_cast<f32x2 *>(q) = uv;
+        } else if (VEC) {      // the 8 channels of a pixel as two 16-byte stores (eight 4-byte stores touched every line eight times)
             const f32x4 lo = {f1[0], f1[1], f1[2], w0}, hi = {w1, w2, u, v};
             *reinterpret_cast<f32x4 *>(o) = lo;
             *reinterpret_cast<f32x4 *>(o + 4) = hi;
@@ -786,6 +821,23 @@ extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second,
     else
         hipLaunchKernelGGL(k_spynet_level_input<false>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
                            fc, feat, up);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+extern "C" int vc_spynet_level_input_sp3(vc_stream s, vc_view first, vc_view second, vc_view fc, void *feat_split, vc_view up)
+{
+    if (!first.p || !second.p || !feat_split || !up.p || ((uintptr_t)feat_split % 16)) return VC_EINVAL;
+    if (first.c != 3 || second.c != 3 || up.c != 2) return VC_EINVAL;
+    if (second.h != first.h || second.w != first.w || up.h != first.h || up.w != first.w || up.n != first.n) return VC_EINVAL;
+    if (fc.p && (fc.c != 2 || (2 * fc.h != first.h && 2 * fc.h + 1 != first.h) || (2 * fc.w != first.w && 2 * fc.w + 1 != first.w)))
+        return VC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(up.p) % 8 || up.sn % 2 || up.sh % 2 || up.sw % 2) return VC_EINVAL;
+    vc_view feat = first;                     // (shape only; p = the split tensor)
+    feat.p = static_cast<float *>(feat_split);
+    feat.c = 8;
+    const long long total = (long long)feat.n * feat.h * feat.w;
+    hipLaunchKernelGGL((k_spynet_level_input<true, true>), dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }

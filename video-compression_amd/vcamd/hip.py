@@ -147,6 +147,7 @@ def lib():
     sig("vc_warp", ci, vp, ci, View, View, View)
     sig("vc_spynet_preprocess", ci, vp, vp, View)
     sig("vc_spynet_level_input", ci, vp, View, View, View, View, View)
+    sig("vc_spynet_level_input_sp3", ci, vp, View, View, View, vp, View)
     sig("vc_lhbdc_blend", ci, vp, View, View, View, View, View)
     sig("vc_flex_blend", ci, vp, View, View, View, View, View, View)
     sig("vc_flex_motion_split", ci, vp, View, View, View, cf)
@@ -185,7 +186,7 @@ EXPORTED_SYMBOLS = [
     "vc_conv_pack_weights_f16", "vc_conv_pack_tail_f16", "vc_conv2d_nhwc", "vc_conv_packed_weight_bytes_split",
     "vc_conv_pack_weights_split", "vc_split3", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_maxpool2_sp3", "vc_upsample_bilinear", "vc_upsample_bilinear_sp3", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
-    "vc_spynet_preprocess", "vc_spynet_level_input", "vc_lhbdc_blend", "vc_flex_blend",
+    "vc_spynet_preprocess", "vc_spynet_level_input", "vc_spynet_level_input_sp3", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes", "vc_refine_scales",
     "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_psnr_uint8", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
@@ -499,7 +500,7 @@ class PackedConv:
         if not (flags & CFG_F16 and flags & CFG_IN_F16) and not (self.dma_f32 and not flags & CFG_F16):
             cands = [c for c in cands if c != CFG_DMA]   # the LDS-DMA pipeline copies pixels as they are: half tensors, or fp32 on its fp32 instances
         if flags & CFG_OUT_SP3:
-            cands = [c for c in cands if c in (0, 1, 2, 3, 5, 7)]    # split output: the classic instances' epilogue
+            cands = [c for c in cands if c in (0, 1, 2, 3, 5, 7, CFG_PWS)]    # split output: the classic instances' and the streaming 1x1 kernel's epilogue
         if not AUTOTUNE or len(cands) < 2 or torch.cuda.is_current_stream_capturing():
             return (cands[0] if cands else self.cfg) | flags
         best, best_ms = self.cfg, float("inf")

@@ -66,7 +66,7 @@ class ResidualBottleneckBlock(_Prepared):
         c1, c2, c3 = self._pack()
         if x.dtype == "f16" and not self.half_stream_ok():
             raise hip.VcError("a half-precision tensor reached a bottleneck block that keeps its identity path in fp32")
-        t = c1(x, act=hip.ACT_RELU, out_f16=c2.half_ok)        # both intermediates feed one convolution each:
+        t = c1(x, act=hip.ACT_RELU, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x))        # both intermediates feed one convolution each:
         if t.dtype == "f16" and c2.can_fuse_tail(c3) and (x.dtype == "f32" or self.half_stream_ok()):
             # fp16 path, 128 channels: the trailing 1x1 + identity in the 3x3 layer's epilogue (hip.FUSE_TAIL) -- the 3x3
             # layer's output (rounded to half exactly as it would be stored) never leaves the CU
@@ -466,7 +466,7 @@ class _ResidualUnit(_Prepared):
         if self._packed is None:
             self._packed = (pack_conv(self.conv[0]), pack_conv(self.conv[2]), pack_conv(self.conv[4]))
         c1, c2, c3 = self._packed
-        t = c1(x, act=hip.ACT_RELU, out_f16=c2.half_ok)
+        t = c1(x, act=hip.ACT_RELU, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x))
         t = c2(t, act=hip.ACT_RELU, out_f16=c3.half_ok)
         return c3(t, act=hip.ACT_RELU, res=x, res_first=True)        # the ReLU comes AFTER the skip addition
 

@@ -106,20 +106,25 @@ class Network(_Prepared):
         for lvl in range(len(pyr_first)):
             f1, f2 = pyr_first[lvl], pyr_second[lvl]
             dev = f1.buf.device
-            feat = T.empty(f1.n, f1.h, f1.w, 8, dev)
+            c = self._convs(lvl)
+            # (fp32 mode "split", hip.set_fp32_mode: the 8 -> 32 -> 64 -> 32 layers on the split-operand pipeline; the level input and
+            #  the activations between them are split tensors -- every producer writes the three bf16 pieces itself -- where the level
+            #  is large enough for that pipeline to pay)
+            sp = hip.fp32_mode() == "split" and c[0].split_ok and c[1].split_ok and c[1].split_pays(f1.n, f1.h, f1.w)
+            feat = T.empty(f1.n, f1.h, f1.w, 8, dev, "sp3" if sp else "f32")
             up = T.empty(f1.n, f1.h, f1.w, 2, dev)
             fv = flow.view() if flow is not None else _zero_flow_view(f1)
             # algorithmic traffic: both frames read (3 ch each) + coarse flow read (2 ch at 1/4 of the pixels) + 8-ch level input
             # and 2-ch upsampled flow written
-            hip.timed_hbm(f"k_spynet_level_input @{f1.n}x{f1.h}x{f1.w}", 4.0 * f1.n * f1.h * f1.w * (3 + 3 + 0.5 + 8 + 2),
-                          lambda: hip.check(L.vc_spynet_level_input(hip.stream(), f1.view(), f2.view(), fv, feat.view(), up.view()),
-                                            "vc_spynet_level_input"))
-            c = self._convs(lvl)
+            if sp:
+                hip.timed_hbm(f"k_spynet_level_input @{f1.n}x{f1.h}x{f1.w}", f1.n * f1.h * f1.w * (4.0 * (3 + 3 + 0.5 + 2) + 48.0),
+                              lambda: hip.check(L.vc_spynet_level_input_sp3(hip.stream(), f1.view(), f2.view(), fv, feat.ptr, up.view()),
+                                                "vc_spynet_level_input_sp3"))
+            else:
+                hip.timed_hbm(f"k_spynet_level_input @{f1.n}x{f1.h}x{f1.w}", 4.0 * f1.n * f1.h * f1.w * (3 + 3 + 0.5 + 8 + 2),
+                              lambda: hip.check(L.vc_spynet_level_input(hip.stream(), f1.view(), f2.view(), fv, feat.view(), up.view()),
+                                                "vc_spynet_level_input"))
             # (each intermediate feeds exactly one convolution: on the fp16 path it is kept as half in HBM)
-            # (fp32 mode "split", hip.set_fp32_mode: the 8 -> 32 -> 64 -> 32 layers on the split-operand pipeline; between them
-            #  the activations stay split tensors -- the producing epilogue writes the three bf16 pieces -- where the level is
-            #  large enough for that pipeline to pay)
-            sp = hip.fp32_mode() == "split" and c[1].split_ok and c[1].split_pays(f1.n, f1.h, f1.w)
             x = c[0](feat, act=hip.ACT_RELU, out_f16=c[1].half_ok, out_sp3=sp)
             x = c[1](x, act=hip.ACT_RELU, out_f16=c[2].half_ok, out_sp3=sp)
             x = c[2](x, act=hip.ACT_RELU, out_f16=c[3].half_ok)
