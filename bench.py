@@ -667,6 +667,10 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
             "executed_bf16_tflops": 9.0 * result["roofline"]["achieved"],
             "native_fp32_mfma_peak": PEAK_F32_MFMA_TFLOPS,
             "achieved_over_native_fp32_peak": result["roofline"]["achieved"] / PEAK_F32_MFMA_TFLOPS})
+    # which kernel instance the dominant launch ran, as a rocprofv3 trace names it: the committed trace of this command is matched on it
+    # (tests/test_profiles_cpu.py); the instrumented frames are the last thing launched under --skip-extras, and within a frame the
+    # dominant shape (finest pyramid level) is the LAST dispatch of its instance
+    result["roofline"]["kernel_symbol"] = getattr(hip, "kernel_symbols", {}).get(key)
     result["roofline"].update({"launches_per_frame": dom["launches"], "avg_launch_ms": avg_ms,
                                "share_of_conv_time": dom["ms"] / total_ms,
                                "algorithmic_flop_per_launch": per_launch_flop,

@@ -84,6 +84,7 @@ class KernelTimer:
 
 timer = None  # set to a KernelTimer() to collect
 split_keys = set()   # (while a KernelTimer collects) the timing keys of launches that ran on the split-operand pipeline
+kernel_symbols = {}  # timing key -> a prefix of the kernel symbol the launch ran (what a rocprofv3 trace names it)
 
 
 def timed_hbm(key, nbytes, launch):
@@ -621,6 +622,8 @@ class PackedConv:
             nbytes = (x.n * x.h * x.w * self.cin * 6 + x.n * ho * wo * co * (6 if out.dtype == "sp3" else 4) + self.cout * self.cin * self.k * self.k * 6
                       + (x.n * ho * wo * co * (6 if res_sp3 else 4) if res is not None else 0))
             split_keys.add(key)
+            cpl, th = (2, 12) if self.k == 3 else (1, 16)
+            kernel_symbols[key] = f"conv_split_kernel<SplitCfg<{self.k}, {4 if self.cout % 64 == 0 else 2}, {cpl}, {th},"
             timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
         return out
 
@@ -717,6 +720,15 @@ class PackedConv:
             nbytes = (x.n * x.h * x.w * self.cin * (2 if half_in else 4) + x.n * ho * wo * co * (2 if half_out else 4)
                       + self.cout * self.cin * self.k * self.k * (2 if use16 else 4)
                       + (x.n * ho * wo * co * (2 if res_half else 4) if res is not None else 0) + (x.n * ho * wo * co * 4 if mul is not None else 0))
+            c0 = d.cfg & 0xff
+            if c0 == CFG_DMA:
+                kernel_symbols[key] = f"conv_dma_kernel<DmaCfg<{self.k}, {self.k}, {self.cin // (32 if use16 else 16)},"
+            elif c0 == CFG_PWS:
+                kernel_symbols[key] = "conv_pws_kernel<"
+            elif c0 == 7:
+                kernel_symbols[key] = f"conv_mfma_kernel<{self.k}, {self.k}, 1, 16, TileCfg<32, 16"
+            else:
+                kernel_symbols[key] = f"conv_mfma_kernel<{self.k}, {self.k}, {self.stride},"
             timer.bracket(key, flops, lambda: check(launch_once(), what), nbytes)
         return out
 
