@@ -89,7 +89,7 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
                         exact sum of three bf16 pieces, all nine piece products (each exact in fp32) are accumulated in fp32 by
                         v_mfma_f32_16x16x32_bf16 -- 9/16 of the native fp32 matrix time; same precision class as the native
                         instances (errors against fp64 measured no larger), NOT bit-identical to them (summation order).
-                        5x5 / 7x7 stride 1 (cin a multiple of 8, cout of 32) and 3x3 stride 1 (cin a multiple of 16, cout of 64),
+                        5x5 / 7x7 stride 1 (cin a multiple of 8, cout of 32) and 3x3 stride 1 (cin a multiple of 16, cout of 32),
                         plain / ReLU / LeakyReLU epilogue (+ gain, residual, pixel shuffle); `in` must be a split tensor (VC_CFG_IN_SP3), `wpk` from
                         vc_conv_pack_weights_split */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the
@@ -205,6 +205,10 @@ int vc_avgpool_reflectpad(vc_stream s, vc_view in, vc_view out, int k, float sca
 int vc_maxpool2(vc_stream s, vc_view in, vc_view out);
 /* The same on a split tensor ([n][c/8][h][w][3][8] bf16, see VC_CFG_SPLIT; image strides in bytes, 0 = dense), split result:
  * between the split-operand encoder layers of the mask U-Net. */
+/* F.avg_pool2d(x * scale, 2) of a split tensor (no padding: even h, w), result a split tensor (out_split) or an fp32 view (out_f32):
+ * exactly one of the two. */
+int vc_avgpool2_sp3(vc_stream s, const void *in_split, long long in_image_bytes, int n, int h, int w, int c, float scale, void *out_split,
+                    long long out_image_bytes, vc_view out_f32);
 int vc_maxpool2_sp3(vc_stream s, const void *in_split, long long in_image_bytes, int n, int h, int w, int c, void *out_split,
                     long long out_image_bytes);
 /* F.interpolate / nn.Upsample bilinear by an integer factor (layers.py:232,238,244; m.py:30;

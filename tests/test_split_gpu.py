@@ -37,6 +37,9 @@ def _layer(cin, cout, k, seed, dev, bias=True):
 
 
 CASES = [  # cin, cout, k, n, h, w  (>= 48 tiles of 16 x 32 per image: the sizes the split pipeline takes)
+    (128, 128, 3, 2, 100, 170),    # 3x3: two planes per chunk, 12-row tiles, ragged edges
+    (64, 32, 3, 1, 150, 260),      # 3x3, one block of 32 output channels
+    (256, 128, 3, 1, 61, 130),
     (32, 64, 7, 1, 112, 224),
     (64, 32, 7, 2, 100, 250),      # ragged right / bottom tiles, two images
     (8, 32, 7, 1, 128, 200),       # one chunk per tile
@@ -219,6 +222,8 @@ def test_pooling_and_upsampling_on_split_tensors(dev):
     hip.upsample_bilinear(x, 2, out=wide.channels(32, 96))
     assert torch.equal(_unsplit(wide.channels(32, 96)), hip.nhwc_to_nchw(hip.upsample_bilinear(x, 2)).cpu())
     assert float(_unsplit(wide.channels(0, 32)).abs().max()) == 0.0
+    assert torch.equal(_unsplit(hip.avgpool2_split(xs, True)), hip.nhwc_to_nchw(hip.avgpool_reflectpad(x, 2)).cpu())
+    assert torch.equal(hip.nhwc_to_nchw(hip.avgpool2_split(xs, False)), hip.nhwc_to_nchw(hip.avgpool_reflectpad(x, 2)))
     pooled = hip.maxpool2(wide.channels(32, 96))            # a window as the input
     assert torch.equal(_unsplit(pooled), hip.nhwc_to_nchw(hip.maxpool2(hip.upsample_bilinear(x, 2))).cpu())
 

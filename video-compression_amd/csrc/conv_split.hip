@@ -37,7 +37,7 @@ static int split_units(int k)
 }
 static int split_block(int cout, int k)
 {
-    if (k == 3) return (cout % 64 == 0) ? 64 : 0;
+    if (k == 3) return (cout % 64 == 0) ? 64 : ((cout % 32 == 0) ? 32 : 0);
     return (cout % 64 == 0) ? 64 : ((cout % 32 == 0) ? 32 : 0);
 }
 
@@ -141,7 +141,8 @@ extern "C" int vc_split3(vc_stream s, vc_view a, void *out_split, long long out_
     const long long img = out_image_bytes ? out_image_bytes : (long long)(a.c / 8) * a.h * a.w * 48;
     unsigned char *o = static_cast<unsigned char *>(out_split);
     const int cg = a.c / 8;
-    if (cg % 4 == 0) hipLaunchKernelGGL(k_split3<4>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
+    if (cg % 8 == 0) hipLaunchKernelGGL(k_split3<8>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
+    else if (cg % 4 == 0) hipLaunchKernelGGL(k_split3<4>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
     else if (cg % 2 == 0) hipLaunchKernelGGL(k_split3<2>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
     else hipLaunchKernelGGL(k_split3<1>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
     VC_LAUNCH_CHECK();
@@ -190,6 +191,6 @@ int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
 #endif
     if (k == 7) return bn == 64 ? launch_conv_split<SplitCfg<7, 4>>(st, a) : launch_conv_split<SplitCfg<7, 2>>(st, a);
     if (k == 5) return bn == 64 ? launch_conv_split<SplitCfg<5, 4>>(st, a) : launch_conv_split<SplitCfg<5, 2>>(st, a);
-    if (k == 3) return launch_conv_split<SplitCfg<3, 4, 2, 12>>(st, a);
+    if (k == 3) return bn == 64 ? launch_conv_split<SplitCfg<3, 4, 2, 12>>(st, a) : launch_conv_split<SplitCfg<3, 2, 2, 12>>(st, a);
     return VC_EINVAL;
 }

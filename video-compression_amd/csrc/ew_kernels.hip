@@ -174,6 +174,58 @@ __global__ void k_maxpool2_sp3(const unsigned char *__restrict__ in, long long i
     }
 }
 
+// F.avg_pool2d(x, 2) on a SPLIT tensor (the skip tensor of a Flex-Rate U-Net level lives inside a split concat buffer and is pooled
+// from there: Flex.../b_model/unet.py:62-68), result split or fp32.  Same sum order and scaling as k_avgpool_reflectpad (k = 2).
+template <bool OSP> __global__ void k_avgpool2_sp3(const unsigned char *__restrict__ in, long long in_img_bytes, int n_img, int h, int w, int cg,
+                                                   float scale, unsigned char *__restrict__ out, long long out_img_bytes, vc_view of)
+{
+    const int oh = h >> 1, ow = w >> 1;
+    const long long total = (long long)n_img * cg * oh * ow * 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int half = (int)(i & 1);
+        long long t = i >> 1;
+        const int x = (int)(t % ow); t /= ow;
+        const int y = (int)(t % oh); t /= oh;
+        const int g = (int)(t % cg);
+        const int n = (int)(t / cg);
+        const unsigned char *b = in + n * in_img_bytes + (((long long)g * h + 2 * y) * w + 2 * x) * 48;
+        const f32x4 a0 = vc_load_split4(b, half), a1 = vc_load_split4(b + 48, half);
+        const f32x4 a2 = vc_load_split4(b + (long long)w * 48, half), a3 = vc_load_split4(b + (long long)w * 48 + 48, half);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sum = 0.0f;
+            sum += a0[e]; sum += a1[e]; sum += a2[e]; sum += a3[e];
+            v[e] = sum * 0.25f * scale;
+        }
+        if (OSP) vc_store_split4(out + n * out_img_bytes + (((long long)g * oh + y) * ow + x) * 48, half, v);
+        else *reinterpret_cast<f32x4 *>(of.p + view_off(of, n, y, x) + 8 * g + 4 * half) = v;
+    }
+}
+
+extern "C" int vc_avgpool2_sp3(vc_stream s, const void *in_split, long long in_image_bytes, int n, int h, int w, int c, float scale,
+                               void *out_split, long long out_image_bytes, vc_view out_f32)
+{
+    if (!in_split || n < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || (c % 8) || ((uintptr_t)in_split % 8) || (in_image_bytes % 8)) return VC_EINVAL;
+    if ((out_split != nullptr) == (out_f32.p != nullptr)) return VC_EINVAL;            // exactly one result
+    const long long ii = in_image_bytes ? in_image_bytes : (long long)(c / 8) * h * w * 48;
+    const long long total = (long long)n * (c / 8) * (h / 2) * (w / 2) * 2;
+    if (out_split) {
+        if (((uintptr_t)out_split % 8) || (out_image_bytes % 8)) return VC_EINVAL;
+        const long long oi = out_image_bytes ? out_image_bytes : (long long)(c / 8) * (h / 2) * (w / 2) * 48;
+        hipLaunchKernelGGL(k_avgpool2_sp3<true>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s),
+                           static_cast<const unsigned char *>(in_split), ii, n, h, w, c / 8, scale, static_cast<unsigned char *>(out_split), oi, out_f32);
+    } else {
+        if (out_f32.n != n || out_f32.h != h / 2 || out_f32.w != w / 2 || out_f32.c != c || (out_f32.sw % 4) || (out_f32.sh % 4) || (out_f32.sn % 4) ||
+            ((uintptr_t)out_f32.p % 16))
+            return VC_EINVAL;
+        hipLaunchKernelGGL(k_avgpool2_sp3<false>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s),
+                           static_cast<const unsigned char *>(in_split), ii, n, h, w, c / 8, scale, nullptr, 0, out_f32);
+    }
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
 extern "C" int vc_maxpool2_sp3(vc_stream s, const void *in_split, long long in_image_bytes, int n, int h, int w, int c, void *out_split,
                                long long out_image_bytes)
 {
@@ -307,17 +359,21 @@ __global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int 
 // The same into a SPLIT tensor (the up-sampled half of a concat buffer a split-operand convolution reads: LHBDC/model/layers.py:
 // 232-246): one lane per 48-byte record (8 channels of a pixel), consecutive lanes consecutive pixels: three 16-byte stores per lane
 // that together cover a contiguous run.
+// (PB consecutive lanes take PB consecutive planes of ONE output pixel: their source reads are one contiguous 32 PB-byte run per corner;
+//  lanes PB apart take consecutive pixels: each plane receives 64 / PB consecutive records per wave)
+template <int PB>
 __global__ void k_upsample_bilinear_sp3(vc_view in, unsigned char *__restrict__ out, long long out_img_bytes, int factor, int align_corners, float scale)
 {
-    const int cg = in.c >> 3, oh = in.h * factor, ow = in.w * factor;
+    const int cg = in.c >> 3, nb = cg / PB, oh = in.h * factor, ow = in.w * factor;
     const long long total = (long long)in.n * cg * oh * ow;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        long long t = i;
+        const int gi = (int)(i % PB);
+        long long t = i / PB;
         const int x = (int)(t % ow); t /= ow;
         const int y = (int)(t % oh); t /= oh;
-        const int g = (int)(t % cg);
-        const int n = (int)(t / cg);
+        const int g = (int)(t % nb) * PB + gi;
+        const int n = (int)(t / nb);
         int y0, y1, x0, x1;
         float ly0, ly1, lx0, lx1;
         bilinear_src(y, in.h, oh, factor, align_corners, y0, y1, ly0, ly1);
@@ -360,8 +416,14 @@ extern "C" int vc_upsample_bilinear_sp3(vc_stream s, vc_view in, void *out_split
     const long long img = out_image_bytes ? out_image_bytes : (long long)(in.c / 8) * in.h * factor * in.w * factor * 48;
     const long long total = (long long)in.n * (in.c / 8) * in.h * factor * in.w * factor;
     if (total <= 0) return VC_OK;
-    hipLaunchKernelGGL(k_upsample_bilinear_sp3, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in,
-                       static_cast<unsigned char *>(out_split), img, factor, align_corners, scale);
+    unsigned char *o = static_cast<unsigned char *>(out_split);
+    const int cg = in.c / 8;
+    if (cg % 8 == 0)
+        hipLaunchKernelGGL(k_upsample_bilinear_sp3<8>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
+    else if (cg % 4 == 0)
+        hipLaunchKernelGGL(k_upsample_bilinear_sp3<4>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
+    else
+        hipLaunchKernelGGL(k_upsample_bilinear_sp3<1>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }

@@ -69,21 +69,35 @@ class UNet(_Prepared):
         p, dev = self._packed, x.buf.device
         if x.h % (1 << (self.depth - 1)) or x.w % (1 << (self.depth - 1)):
             raise hip.VcError("UNet input must be divisible by 2^(depth-1) (the reference pads frames to x64)")
+        # fp32 mode "split" (hip.set_fp32_mode): a level whose up-block convolution runs on the split-operand pipeline keeps its concat
+        # buffer -- and everything the split layers hand each other -- as SPLIT tensors: the skip convolution, the up-path convolution
+        # and the up-sampling kernel write the three bf16 pieces directly, the skip tensor is pooled from its window of the buffer
         cats = []
+        nd = len(p["down"])
         for i, (c1, c2) in enumerate(p["down"]):
             t = c1(x, act=hip.ACT_LRELU, slope=0.1, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, x))
-            if i != len(p["down"]) - 1:
+            if i != nd - 1:
                 c = c2.cout
-                cat = T.empty(x.n, t.h, t.w, 2 * c, dev)           # [up(c) | skip(c)]
+                up_c1 = p["up"][nd - 2 - i][1]                       # the convolution that reads this level's concat buffer
+                sp_cat = hip.wants_split_at(up_c1, x.n, t.h, t.w) and c % 8 == 0
+                cat = T.empty(x.n, t.h, t.w, 2 * c, dev, "sp3" if sp_cat else "f32")     # [up(c) | skip(c)]
                 skip = c2(t, out=cat.channels(c, 2 * c), act=hip.ACT_LRELU, slope=0.1)
                 cats.append(cat)
-                x = hip.avgpool_reflectpad(skip, 2)
+                nxt_c1 = p["down"][i + 1][0]
+                if sp_cat:
+                    x = hip.avgpool2_split(skip, out_sp3=hip.wants_split_at(nxt_c1, x.n, t.h // 2, t.w // 2))
+                else:
+                    x = hip.avgpool_reflectpad(skip, 2)
             else:
-                x = c2(t, act=hip.ACT_LRELU, slope=0.1)
+                x = c2(t, act=hip.ACT_LRELU, slope=0.1, out_sp3=hip.wants_split(p["mid"], t))
         x = p["mid"](x, act=hip.ACT_LRELU, slope=0.1)
         for i, (cu, c1, c2) in enumerate(p["up"]):
             cat = cats[-i - 1]
-            cu(hip.upsample_bilinear(x, 2), out=cat.channels(0, cu.cout))
+            if hip.wants_split_at(cu, x.n, cat.h, cat.w) and x.c % 8 == 0 and x.dtype == "f32":
+                ups = hip.upsample_bilinear(x, 2, out=T.empty(x.n, cat.h, cat.w, x.c, dev, "sp3"))
+            else:
+                ups = hip.upsample_bilinear(x, 2)
+            cu(ups, out=cat.channels(0, cu.cout))
             x = c2(c1(cat, act=hip.ACT_LRELU, slope=0.1, out_f16=c2.half_ok, out_sp3=hip.wants_split(c2, cat)), act=hip.ACT_LRELU, slope=0.1)
         return p["last"](x, act=final_act)
 

@@ -140,6 +140,7 @@ def lib():
     sig("vc_avgpool_reflectpad", ci, vp, View, View, ci, cf)
     sig("vc_maxpool2", ci, vp, View, View)
     sig("vc_maxpool2_sp3", ci, vp, vp, cll, ci, ci, ci, ci, vp, cll)
+    sig("vc_avgpool2_sp3", ci, vp, vp, cll, ci, ci, ci, ci, cf, vp, cll, View)
     sig("vc_upsample_bilinear_sp3", ci, vp, View, vp, cll, ci, ci, cf)
     sig("vc_upsample_bilinear", ci, vp, View, View, ci, ci, cf)
     sig("vc_axpby", ci, vp, View, View, View, cf, cf)
@@ -186,7 +187,7 @@ EXPORTED_SYMBOLS = [
     "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
     "vc_conv_pack_weights_f16", "vc_conv_pack_tail_f16", "vc_conv2d_nhwc", "vc_conv_packed_weight_bytes_split",
     "vc_conv_pack_weights_split", "vc_split3", "vc_nchw_to_nhwc",
-    "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_maxpool2_sp3", "vc_upsample_bilinear", "vc_upsample_bilinear_sp3", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
+    "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_maxpool2_sp3", "vc_avgpool2_sp3", "vc_upsample_bilinear", "vc_upsample_bilinear_sp3", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_spynet_level_input_sp3", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes", "vc_refine_scales",
@@ -456,7 +457,7 @@ class PackedConv:
         self._tail = None
         self._wsplit = None
         split_shape = stride == 1 and ((kh in (5, 7) and cin % 8 == 0 and cout % 32 == 0 and not pixelshuffle) or
-                                       (kh == 3 and cin % 16 == 0 and cout % 64 == 0 and (not pixelshuffle or cout % 32 == 0)))
+                                       (kh == 3 and cin % 16 == 0 and cout % 32 == 0))
         self._raw32 = (wnp, bnp) if split_shape else None
         self._raw = (wnp, bnp) if (_PRECISION == "fp16" and kh == 1 and stride == 1 and cout == cin and cin in (64, 128) and not pixelshuffle) else None
         self._device = device
@@ -740,6 +741,15 @@ def avgpool_reflectpad(x, k, scale=1.0, out_h=None, out_w=None):
     hp, wp = x.h // k, x.w // k
     out = T.empty(x.n, out_h or hp, out_w or wp, x.c, x.buf.device)
     check(lib().vc_avgpool_reflectpad(stream(), x.view(), out.view(), k, scale), "vc_avgpool_reflectpad")
+    return out
+
+
+def avgpool2_split(x, out_sp3):
+    """F.avg_pool2d(x, 2) of a split tensor (window): split or fp32 result."""
+    out = T.empty(x.n, x.h // 2, x.w // 2, x.c, x.buf.device, "sp3" if out_sp3 else "f32")
+    timed_hbm(f"k_avgpool2_sp3 c{x.c} @{x.n}x{x.h}x{x.w}", x.n * x.c * (6.0 * x.h * x.w + (6.0 if out_sp3 else 4.0) * out.h * out.w),
+              lambda: check(lib().vc_avgpool2_sp3(stream(), x.ptr, x.image_bytes, x.n, x.h, x.w, x.c, 1.0, out.ptr if out_sp3 else None,
+                                                  out.image_bytes if out_sp3 else 0, NULL_VIEW if out_sp3 else out.view()), "vc_avgpool2_sp3"))
     return out
 
 
