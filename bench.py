@@ -38,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # BF16/FP16 matrix peak, dense
 PEAK_HBM_GBPS = 8000.0           # HBM3E peak (same guide)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04", "traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05", "traffic.json")
 
 
 def kernel_source_stamp():

@@ -30,6 +30,8 @@ def main():
                     help="fp32 layers on the split-operand pipeline (VC_CFG_SPLIT, csrc/conv_split.h); the input is converted to a split "
                          "tensor ONCE before the timed launches (inside a chain the producing epilogue writes it)")
     ap.add_argument("--residual", action="store_true", help="add an fp32 residual tensor in the epilogue (bottleneck blocks)")
+    ap.add_argument("--residual-half", action="store_true",
+                    help="fp16 path with --half-io: add a HALF-precision residual (VC_CFG_RES_F16: the identity of a residual block)")
     ap.add_argument("shapes", nargs="*", default=DEFAULT)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -56,6 +58,9 @@ def main():
         res = None
         if args.residual:
             res = hip.T.empty(n, ho, wo, co, dev)
+            res.buf.normal_()
+        if args.residual_half:
+            res = hip.T.empty(n, ho, wo, co, dev, "f16")
             res.buf.normal_()
         if args.split:
             if not pc.split_ok:
