@@ -949,8 +949,25 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
             refs = pool.run_jobs([tuple(frames[i].cpu() for i in pk) for pk in picks], pool.lhbdc_encode_job(sd))
             t_oracle = time.perf_counter() - t1
             same, per = 0, []
+            flips, unaided = {False: 0, True: 0}, {False: 0, True: 0}
             with torch.no_grad():
                 for pk, ref in zip(picks, refs):
+                    # scale-table indexes against the CPU path's, and the CPU path's container through THIS decoder without handing
+                    # it the encoder's indexes -- with plain fp32 scales and with vc_refine_scales (hip.SCALE_REFINE)
+                    for refine in (False, True):
+                        hip.SCALE_REFINE = refine
+                        t2 = {}
+                        vlhbdc.encode_B(model, frames[pk[2]], frames[pk[1]], frames[pk[0]], trace=t2)
+                        flips[refine] += sum(int((torch.from_numpy(t2[c]["y_idx"]).reshape(-1) != ref[c]["y_idx"].reshape(-1)).sum()) for c in ("mv", "res"))
+                        _, s_mv, s_res, sh_mv, sh_res = vlhbdc.read_container(ref["container"])
+                        try:
+                            td = {}
+                            vlhbdc.decode_B(frames[pk[0]], frames[pk[2]], model, s_mv, s_res, sh_mv, sh_res, trace=td)
+                            ok = all(int((torch.from_numpy(td[c]["y_sym"]).reshape(-1) != ref[c]["y_sym"].reshape(-1)).sum()) == 0 for c in ("mv", "res"))
+                        except hip.VcError:
+                            ok = False
+                        unaided[refine] += bool(ok)
+                    hip.SCALE_REFINE = True
                     tr = {}
                     mv_b, res_b = vlhbdc.encode_B(model, frames[pk[2]], frames[pk[1]], frames[pk[0]], trace=tr)
                     blob = vlhbdc.write_container(None, 1626, mv_b, res_b)
@@ -960,6 +977,8 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                     per.append({"frames": list(pk), "identical": blob == ref["container"], "bytes": len(blob),
                                 "symbols_differing": nd["y_sym"] + nd["z_sym"], "scale_indexes_differing": nd["y_idx"]})
             result["byte_equality"] = {"containers_identical": same, "of": len(picks), "triples": per, "oracle_s": round(t_oracle, 1),
+                                       "scale_indexes_differing_plain_fp32_scales": flips[False], "scale_indexes_differing_with_vc_refine_scales": flips[True],
+                                       "cpu_containers_decoded_unaided_plain": unaided[False], "cpu_containers_decoded_unaided_refined": unaided[True],
                                        "oracle_workers_x_threads": list(pool.plan(len(picks))),
                                        "what": "end-to-end encode_B (frames -> bits_B container) against the CPU oracle's container, byte for "
                                                "byte; calibrated checkpoint, 1088x1920, ~1.2 M coded integers per frame.  A scale within fp32 "

@@ -89,7 +89,7 @@ enum { VC_CFG_N128 = 0, VC_CFG_N64 = 1, VC_CFG_N32 = 2, VC_CFG_N16 = 3, VC_CFG_N
                         exact sum of three bf16 pieces, all nine piece products (each exact in fp32) are accumulated in fp32 by
                         v_mfma_f32_16x16x32_bf16 -- 9/16 of the native fp32 matrix time; same precision class as the native
                         instances (errors against fp64 measured no larger), NOT bit-identical to them (summation order).
-                        5x5 / 7x7 stride 1 (cin a multiple of 8, cout of 32) and 3x3 stride 1 (cin a multiple of 16, cout of 32),
+                        5x5 / 7x7 stride 1 (cin a multiple of 8, cout of 32; 7x7 also of 16) and 3x3 stride 1 (cin a multiple of 16, cout of 32),
                         plain / ReLU / LeakyReLU epilogue (+ gain, residual, pixel shuffle); `in` must be a split tensor (VC_CFG_IN_SP3), `wpk` from
                         vc_conv_pack_weights_split */ };
 /* OR into vc_conv_desc.cfg to launch exactly that configuration (a narrower 32-wide configuration reads the

@@ -43,6 +43,7 @@ CASES = [  # cin, cout, k, n, h, w  (>= 48 tiles of 16 x 32 per image: the sizes
     (32, 64, 7, 1, 112, 224),
     (64, 32, 7, 2, 100, 250),      # ragged right / bottom tiles, two images
     (8, 32, 7, 1, 128, 200),       # one chunk per tile
+    (32, 16, 7, 2, 250, 330),      # one N-tile of 16 channels per workgroup, 24-row tiles
     (96, 32, 5, 1, 120, 230),
     (192, 64, 5, 1, 120, 200),
     (32, 128, 7, 1, 97, 130),      # two blocks of 64 output channels

@@ -17,7 +17,7 @@ from vcamd import hip  # noqa: E402
 
 SMALL = ["32,64,7,1,48,80", "64,32,7,2,37,53", "8,32,7,1,40,72", "96,32,5,1,48,80", "192,64,5,1,33,47",
          "128,128,3,1,60,96", "64,128,3,2,50,70", "128,512,3,1,48,64,1", "16,64,3,1,24,33"]
-BIG = ["32,64,7,4,1088,1920", "64,32,7,4,1088,1920", "128,128,3,1,544,960", "128,128,3,4,544,960", "128,512,3,1,272,480,1",
+BIG = ["32,16,7,4,1088,1920", "32,64,7,4,1088,1920", "64,32,7,4,1088,1920", "128,128,3,1,544,960", "128,128,3,4,544,960", "128,512,3,1,272,480,1",
        "128,128,3,1,272,480", "256,128,3,1,272,480", "128,128,3,1,136,240", "96,32,5,1,1088,1920"]
 
 

@@ -38,7 +38,8 @@ static int split_units(int k)
 static int split_block(int cout, int k)
 {
     if (k == 3) return (cout % 64 == 0) ? 64 : ((cout % 32 == 0) ? 32 : 0);
-    return (cout % 64 == 0) ? 64 : ((cout % 32 == 0) ? 32 : 0);
+    // (7x7 only: one N-tile of 16 channels per workgroup on 24-row tiles -- SPyNet's 32 -> 16 layer, LHBDC/model/flow.py:58)
+    return (cout % 64 == 0) ? 64 : ((cout % 32 == 0) ? 32 : ((k == 7 && cout % 16 == 0) ? 16 : 0));
 }
 
 extern "C" size_t vc_conv_packed_weight_bytes_split(int cout, int cin, int k)
@@ -169,7 +170,7 @@ int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
     if (a.out_sp3 && !a.out_sn) a.out_sn = (long long)(cpp / 8) * osc * a.Ho * osc * a.Wo * 48;
     if (a.res_sp3 && !a.res_sn) a.res_sn = (long long)(cpp / 8) * osc * a.Ho * osc * a.Wo * 48;
     if ((a.in_sn % 16) || (a.out_sp3 && (a.out_sn % 16)) || (a.res_sp3 && (a.res_sn % 8))) return VC_EINVAL;
-    const int th = k == 3 ? 12 : 16;
+    const int th = k == 3 ? 12 : (bn == 16 ? 24 : 16);
     a.tiles_x = (a.Wo + 31) / 32;
     a.tiles_y = (a.Ho + th - 1) / th;
     a.nblks = a.Cout / bn;
@@ -189,6 +190,7 @@ int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
         }
     }
 #endif
+    if (k == 7 && bn == 16) return launch_conv_split<SplitCfg<7, 1, 1, 24>>(st, a);
     if (k == 7) return bn == 64 ? launch_conv_split<SplitCfg<7, 4>>(st, a) : launch_conv_split<SplitCfg<7, 2>>(st, a);
     if (k == 5) return bn == 64 ? launch_conv_split<SplitCfg<5, 4>>(st, a) : launch_conv_split<SplitCfg<5, 2>>(st, a);
     if (k == 3) return bn == 64 ? launch_conv_split<SplitCfg<3, 4, 2, 12>>(st, a) : launch_conv_split<SplitCfg<3, 2, 2, 12>>(st, a);

@@ -456,7 +456,7 @@ class PackedConv:
         self.tuned = {}
         self._tail = None
         self._wsplit = None
-        split_shape = stride == 1 and ((kh in (5, 7) and cin % 8 == 0 and cout % 32 == 0 and not pixelshuffle) or
+        split_shape = stride == 1 and ((kh in (5, 7) and cin % 8 == 0 and (cout % 32 == 0 or (kh == 7 and cout % 16 == 0)) and not pixelshuffle) or
                                        (kh == 3 and cin % 16 == 0 and cout % 32 == 0))
         self._raw32 = (wnp, bnp) if split_shape else None
         self._raw = (wnp, bnp) if (_PRECISION == "fp16" and kh == 1 and stride == 1 and cout == cin and cin in (64, 128) and not pixelshuffle) else None
@@ -531,8 +531,8 @@ class PackedConv:
         """The split pipeline walks 16 x 32-pixel tiles with one workgroup per CU: on coarse pyramid levels (few tiles) the native
         instances with their 8-row tiles and several workgroups per CU are faster.  Decided per IMAGE, never by the batch: a
         frame must get the same bits whether it is coded alone or in a level-batched pass."""
-        bn = 64 if self.cout % 64 == 0 else 32
-        th = 12 if self.k == 3 else 16
+        bn = 64 if self.cout % 64 == 0 else (32 if self.cout % 32 == 0 else 16)
+        th = 12 if self.k == 3 else (24 if bn == 16 else 16)
         return ((h + th - 1) // th) * ((w + 31) // 32) * (self.cout // bn) >= 48
 
     def split_pack(self):
@@ -623,8 +623,9 @@ class PackedConv:
             nbytes = (x.n * x.h * x.w * self.cin * 6 + x.n * ho * wo * co * (6 if out.dtype == "sp3" else 4) + self.cout * self.cin * self.k * self.k * 6
                       + (x.n * ho * wo * co * (6 if res_sp3 else 4) if res is not None else 0))
             split_keys.add(key)
-            cpl, th = (2, 12) if self.k == 3 else (1, 16)
-            kernel_symbols[key] = f"conv_split_kernel<SplitCfg<{self.k}, {4 if self.cout % 64 == 0 else 2}, {cpl}, {th},"
+            ntw = 4 if self.cout % 64 == 0 else (2 if self.cout % 32 == 0 else 1)
+            cpl, th = (2, 12) if self.k == 3 else (1, 24 if ntw == 1 else 16)
+            kernel_symbols[key] = f"conv_split_kernel<SplitCfg<{self.k}, {ntw}, {cpl}, {th},"
             timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
         return out
 

@@ -127,7 +127,7 @@ class Network(_Prepared):
             # (each intermediate feeds exactly one convolution: on the fp16 path it is kept as half in HBM)
             x = c[0](feat, act=hip.ACT_RELU, out_f16=c[1].half_ok, out_sp3=sp)
             x = c[1](x, act=hip.ACT_RELU, out_f16=c[2].half_ok, out_sp3=sp)
-            x = c[2](x, act=hip.ACT_RELU, out_f16=c[3].half_ok)
+            x = c[2](x, act=hip.ACT_RELU, out_f16=c[3].half_ok, out_sp3=sp and hip.wants_split(c[3], f1))
             x = c[3](x, act=hip.ACT_RELU, out_f16=c[4].half_ok)
             flow = c[4](x, res=up)
         return flow
