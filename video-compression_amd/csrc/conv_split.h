@@ -175,6 +175,57 @@ template <int K_, int NTW_, int CPL_ = 1, int TH_ = 16, int RING_ = 4, int KO_ =
     static_assert(D >= 1 && nwait(U - 1, 0) <= 63, "vmcnt is a 6-bit counter");
 };
 
+// Epilogue of the split kernels: lane = pixel (px of M-tile m = WM wave + t: row m >> 1, columns 16 (m & 1) ..), k-group q = channel quad:
+// 4 consecutive channels per accumulator -> one 16-byte access (or the 3 x 8 bytes of a split record) per (M-tile, N-tile).  Stores of
+// pixels / channels outside the output are simply masked: the counted waits of these kernels count DMA only -- an uncounted younger
+// store makes a wait longer, never shorter.
+template <class C>
+__device__ __forceinline__ void split_epilogue(const ConvArgs &p, f32x4 (&acc)[C::WM][C::WN], const DmaTile &cur, int wave, int px, int q)
+{
+    constexpr int WM = C::WM, WN = C::WN;
+    const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+#pragma unroll
+    for (int t = 0; t < WM; ++t) {
+        const int m = WM * wave + t;
+        const int oy = cur.oy0 + (m >> 1), ox = cur.ox0 + 16 * (m & 1) + px;
+        const bool pix_ok = oy < p.Ho && ox < p.Wo;
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const int co = cur.nblk * C::BN + 16 * n + 4 * q;
+            const bool ok = pix_ok && co < p.Cout;
+            f32x4 v = acc[t][n];
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            // nn.PixelShuffle(2) fused into the store (the packed output channels are permuted so that 4 consecutive ones share a position)
+            const bool ps = p.out_mode != VC_OUT_PLAIN;
+            const int cps = p.Cout >> 2;
+            const int pos = ps ? co / cps : 0;
+            const int cch = ps ? co - pos * cps : co;
+            const int yy = ps ? 2 * oy + (pos >> 1) : oy, xx = ps ? 2 * ox + (pos & 1) : ox;
+            const int oh = ps ? 2 * p.Ho : p.Ho, ow = ps ? 2 * p.Wo : p.Wo;
+            if (p.res_sp3) {                 // the identity kept as a split tensor: its three pieces sum to the exact fp32 value
+                if (ok) r = vc_load_split4(reinterpret_cast<const unsigned char *>(p.res) + (long long)cur.img * p.res_sn +
+                                               ((((long long)(cch >> 3)) * oh + yy) * ow + xx) * 48, (cch >> 2) & 1);
+            } else if (p.res) {
+                const long long r_off = (long long)cur.img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
+                if (ok) r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
+            }
+            if (p.res_first) v += r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
+            if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + min(co, p.Cout - 4));
+            if (p.res && !p.res_first) v += r;
+            if (p.out_sp3) {
+                // split output for a VC_CFG_SPLIT consumer: 3 x 8 bytes (4 channels of one piece) into the pixel's 48-byte record
+                unsigned char *o8 = reinterpret_cast<unsigned char *>(p.out) + (long long)cur.img * p.out_sn + ((((long long)(cch >> 3)) * oh + yy) * ow + xx) * 48;
+                if (ok) vc_store_split4(o8, (cch >> 2) & 1, v);
+            } else {
+                const long long o_off = (long long)cur.img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
+                if (ok) *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
+            }
+        }
+    }
+}
+
 template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(const ConvArgs p)
 {
     typedef typename C::UN UN;
@@ -374,52 +425,9 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
         gchunk += nchunk;
         gbase = (gbase + (unsigned)upt) % RING;
 
-        // ---- epilogue: lane = pixel, 4 consecutive channels per accumulator: one 16-byte access per (M-tile, N-tile) ----
+        // ---- epilogue ----
         if constexpr (!(C::KO & 1)) {
-            const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
-            // (stores of pixels / channels outside the output are simply masked: the counted waits of this kernel count DMA only --
-            //  an uncounted younger store makes a wait longer, never shorter)
-#pragma unroll
-            for (int t = 0; t < WM; ++t) {
-                const int m = WM * wave + t;
-                const int oy = cur.oy0 + (m >> 1), ox = cur.ox0 + 16 * (m & 1) + px;
-                const bool pix_ok = oy < p.Ho && ox < p.Wo;
-#pragma unroll
-                for (int n = 0; n < WN; ++n) {
-                    const int co = cur.nblk * C::BN + 16 * n + 4 * q;
-                    const bool ok = pix_ok && co < p.Cout;
-                    f32x4 v = acc[t][n];
-                    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-                    // nn.PixelShuffle(2) fused into the store (the packed output channels are permuted so that 4 consecutive ones share a position)
-                    const bool ps = p.out_mode != VC_OUT_PLAIN;
-                    const int cps = p.Cout >> 2;
-                    const int pos = ps ? co / cps : 0;
-                    const int cch = ps ? co - pos * cps : co;
-                    const int yy = ps ? 2 * oy + (pos >> 1) : oy, xx = ps ? 2 * ox + (pos & 1) : ox;
-                    if (p.res_sp3) {                 // the identity kept as a split tensor: its three pieces sum to the exact fp32 value
-                        if (ok) r = vc_load_split4(reinterpret_cast<const unsigned char *>(p.res) + (long long)cur.img * p.res_sn +
-                                                       ((((long long)(cch >> 3)) * (ps ? 2 * p.Ho : p.Ho) + yy) * (ps ? 2 * p.Wo : p.Wo) + xx) * 48, (cch >> 2) & 1);
-                    } else if (p.res) {
-                        const long long r_off = (long long)cur.img * p.res_sn + (long long)yy * p.res_sh + (long long)xx * p.res_sw + cch;
-                        if (ok) r = *reinterpret_cast<const f32x4 *>(p.res + r_off);
-                    }
-                    if (p.res_first) v += r;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
-                    if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + min(co, p.Cout - 4));
-                    if (p.res && !p.res_first) v += r;
-                    if (p.out_sp3) {
-                        // split output for a VC_CFG_SPLIT consumer: 3 x 8 bytes (4 channels of one piece) into the pixel's 48-byte record
-                        const int oh = ps ? 2 * p.Ho : p.Ho, ow = ps ? 2 * p.Wo : p.Wo;
-                        unsigned char *o8 = reinterpret_cast<unsigned char *>(p.out) + (long long)cur.img * p.out_sn +
-                                            ((((long long)(cch >> 3)) * oh + yy) * ow + xx) * 48;
-                        if (ok) vc_store_split4(o8, (cch >> 2) & 1, v);
-                    } else {
-                        const long long o_off = (long long)cur.img * p.out_sn + (long long)yy * p.out_sh + (long long)xx * p.out_sw + cch;
-                        if (ok) *reinterpret_cast<f32x4 *>(p.out + o_off) = v;
-                    }
-                }
-            }
+            split_epilogue<C>(p, acc, cur, wave, px, q);
         } else {
 #pragma unroll
             for (int t = 0; t < WM; ++t)
@@ -433,6 +441,251 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
         nxt_base = tile_base(nxt);
     }
     vc_wait_vmcnt<0>();                              // no DMA may land in LDS that already belongs to another workgroup
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 3 x 3 WITHOUT tap padding (input channels a multiple of 32).  K of an MFMA = four (tap, 8-channel plane) k-groups; a 16-channel chunk
+// has 9 x 2 = 18 of them = 4.5 units, which SplitPairs<3> pads to 5.  Here the k-groups of TWO consecutive chunks are walked as one
+// PERIOD of 36 = 9 full units: k-group q of unit u is number g = 4 u + q -> chunk g / 18 of the period, tap (g % 18) / 2, plane g % 2;
+// unit 4 straddles the two chunks (taps 8 of the first, tap 0 of the second).  The first chunk of a period lives in image buffer X,
+// the second in Y, always: the per-lane read offset of a unit (buffer, plane, tap offset of the lane's k-group) is a loop-invariant
+// register.  DMA schedule of a period: Y (this period's second chunk) in phases 1-2 -- Y was last read in phase 8 of the period before,
+// is first read in phase 4 --, X (the next period's / tile's first chunk) in phases 6-7 -- last read in phase 4, first read in the next
+// phase 0.  10 % fewer MFMAs than the padded instance, same results up to the order of the k-groups inside a chunk pair.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int NTW_, int RING_ = 4, int KO_ = 0> struct Split3Cfg {
+    static constexpr int K = 3, NTW = NTW_, CPL = 2, RING = RING_, KO = KO_, U = 9, PAD = 1;
+    static constexpr int TH = 12, TW = 32, BN = 16 * NTW_;
+    static constexpr int WAVES = 8, WM = 3, WN = NTW_;
+    static constexpr int ROWS_IN = TH + 2, COLS = TW + 2, PIX = ROWS_IN * COLS, PXB = 48, PLANE_B = PIX * PXB;
+    static constexpr int NA = (2 * PIX * 3 + 511) / 512, A_BYTES = NA * 8192;
+    static constexpr int FRAGS = 3 * NTW_, ROUNDS = (FRAGS + 7) / 8, LASTW = FRAGS - 8 * (ROUNDS - 1);
+    static constexpr bool EXACT = LASTW == 4;
+    static constexpr int SLOTB = EXACT ? FRAGS * 1024 : ROUNDS * 8192;
+    static constexpr int nb(int grp) { return ROUNDS - ((EXACT && grp == 1) ? 1 : 0); }
+    static constexpr int B_OFF = 2 * A_BYTES, BIAS_OFF = B_OFF + RING_ * SLOTB, LDS_FIXED = BIAS_OFF;
+    static constexpr int D = RING_ - 2;
+    static_assert(D == 2, "the issue windows below are laid out for weights requested two units ahead");
+    static constexpr int kg_chunk(int u, int q) { return (4 * u + q) / 18; }
+    static constexpr int kg_tap(int u, int q) { return ((4 * u + q) % 18) / 2; }
+    static constexpr int kg_plane(int u, int q) { return (4 * u + q) % 2; }
+    static constexpr int PPP = (NA + 1) / 2;                                       // pieces per phase of a two-phase window
+    // phase in which piece k of buffer Y (which = 1) / X (which = 0) is requested
+    static constexpr int piece_phase(int which, int k) { return (which ? 1 : 6) + k / PPP; }
+    static constexpr int nA(int u)
+    {
+        int n = 0;
+        for (int w = 0; w < 2; ++w)
+            for (int k = 0; k < NA; ++k) n += piece_phase(w, k) == u;
+        return n;
+    }
+    static constexpr int nwait(int u, int grp)
+    {
+        int n = 0;
+        for (int j = u + 2 - D; j <= u; ++j) n += nA(((j % U) + U) % U) + nb(grp);
+        return n;
+    }
+    static_assert(nwait(7, 0) <= 63, "vmcnt is a 6-bit counter");
+};
+
+template <class C> __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvArgs p)
+{
+    constexpr int U = C::U, WM = C::WM, WN = C::WN, NA = C::NA, RING = C::RING, D = C::D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];   // the kernel's only LDS object: starts at LDS address 0
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int px = lane & 15, q = lane >> 4;
+
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int total = per_img * p.N * p.nblks;
+    const int xcd = blockIdx.x & 7, xl = blockIdx.x >> 3;
+    const int tq = total >> 3, tr = total & 7;
+    const int x_start = xcd * tq + min(xcd, tr), x_count = tq + (xcd < tr ? 1 : 0);
+    auto tile_at = [&](int it) {
+        DmaTile t;
+        const int k = it * 32 + xl;
+        t.valid = k < x_count;
+        const int idx = x_start + (t.valid ? k : 0);
+        t.nblk = idx % p.nblks;
+        const int t1 = idx / p.nblks;
+        t.img = t1 / per_img;
+        int tx, ty;
+        vc_tile_xy(t1 - t.img * per_img, p.tiles_x, p.tiles_y, p.tile_band, tx, ty);
+        t.oy0 = ty * C::TH;
+        t.ox0 = tx * C::TW;
+        return t;
+    };
+    DmaTile cur = tile_at(0);
+    if (!cur.valid) return;
+
+    const int nper = p.Cin >> 5;                                  // periods of two 16-channel chunks
+    const int upt = nper * U;
+    const unsigned char *const in_b = reinterpret_cast<const unsigned char *>(p.in);
+    const unsigned char *const wpk = reinterpret_cast<const unsigned char *>(p.wpk);
+    const long long plane = (long long)p.H * p.W * C::PXB;
+    const unsigned char *const zero_lane = g_vc_dma_zero + 16 * lane;
+
+    int a_off[NA], a_rc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int s = k * 512 + tid;
+        const int pl = s / (3 * C::PIX), s2 = s - pl * (3 * C::PIX);
+        const int pix = s2 / 3, piece = s2 - 3 * pix;
+        const int row = pix / C::COLS, col = pix - row * C::COLS;
+        a_off[k] = pl * (int)plane + (row * p.W + col) * C::PXB + piece * 16;
+        a_rc[k] = pl < 2 ? (row | (col << 8)) : 0x7f7f7f;
+    }
+    auto tile_base = [&](const DmaTile &t) {
+        return in_b + (long long)t.img * p.in_sn + ((long long)(t.oy0 - 1) * p.W + (t.ox0 - 1)) * C::PXB;
+    };
+    auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {      // c: 16-channel chunk of the layer
+        int rc = a_rc[k], off = a_off[k];
+        asm volatile("" : "+v"(rc), "+v"(off));
+        const unsigned iy = (unsigned)(t.oy0 - 1 + (rc & 0xff)), ix = (unsigned)(t.ox0 - 1 + (rc >> 8));
+        const bool ok = t.valid && iy < (unsigned)p.H && ix < (unsigned)p.W;
+        const unsigned char *sp = ok ? tbase + ((long long)c * 2 * plane + off) : zero_lane;
+        if constexpr (!(C::KO & 16)) vc_glds16<true>(sp, (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
+    };
+    const unsigned lane16 = 16 * lane;
+    unsigned gbase = 0;
+    auto issue_b = [&](int g, int nblk_cur, int nblk_next) {
+        const int gg = g >= upt ? g - upt : g;
+        const int nblk = g >= upt ? nblk_next : nblk_cur;
+        const unsigned char *sbase = wpk + ((long long)nblk * upt + gg) * (C::FRAGS * 1024) + wave * 1024;
+        const unsigned dst = C::B_OFF + ((gbase + (unsigned)g) % RING) * C::SLOTB + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < C::ROUNDS; ++r)
+            if constexpr (!(C::KO & 16)) {
+                if (r + 1 < C::ROUNDS || !C::EXACT || grp == 0) vc_glds16_sbase(sbase + r * 8192, lane16, dst + r * 8192);
+            }
+    };
+
+    float *const ldsf = reinterpret_cast<float *>(lds8);
+    for (int i = tid; i < p.nblks * C::BN; i += 512) ldsf[C::BIAS_OFF / 4 + i] = p.bias[i];
+    DmaTile nxt = tile_at(1);
+    const unsigned char *cur_base = tile_base(cur), *nxt_base = tile_base(nxt);
+#pragma unroll
+    for (int k = 0; k < NA; ++k) issue_a(cur, cur_base, 0, k, 0);
+#pragma unroll
+    for (int g = 0; g < D; ++g) issue_b(g, cur.nblk, cur.nblk);
+    vc_wait_vmcnt<0>();
+    __syncthreads();
+
+    // per-lane read offsets: M-tile base + (buffer, plane, tap) of the lane's k-group in each of the 9 units
+    int a_t[WM], a_unit[U];
+#pragma unroll
+    for (int t = 0; t < WM; ++t) {
+        const int m = WM * wave + t;
+        a_t[t] = ((m >> 1) * C::COLS + 16 * (m & 1) + px) * C::PXB;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int off = 0;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+            if (q == qq)
+                off = C::kg_chunk(u, qq) * C::A_BYTES + C::kg_plane(u, qq) * C::PLANE_B + ((C::kg_tap(u, qq) / 3) * C::COLS + C::kg_tap(u, qq) % 3) * C::PXB;
+        a_unit[u] = off;
+    }
+    const int b_lane = C::B_OFF + lane * 16;
+
+    f32x4 acc[WM][WN];
+    f32x4 af[3][WM], bf[3][WN];
+    for (int it = 0;; ++it) {
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(&ldsf[C::BIAS_OFF / 4 + cur.nblk * C::BN + 16 * n + 4 * q]);
+#pragma unroll
+            for (int t = 0; t < WM; ++t) acc[t][n] = b;
+        }
+        if (grp == 1) VC_DMA_BARRIER();
+#pragma unroll 1
+        for (int pr = 0; pr < nper; ++pr) {
+            const bool last_per = pr + 1 == nper;
+            const int g0 = pr * U;
+            static_for<0, U>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int bslot = b_lane + (int)((gbase + (unsigned)(g0 + u)) % RING) * C::SLOTB;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                    for (int n = 0; n < WN; ++n) bf[pc][n] = *reinterpret_cast<const f32x4 *>(lds8 + bslot + (pc * WN + n) * 1024);
+#pragma unroll
+                    for (int t = 0; t < WM; ++t) af[pc][t] = *reinterpret_cast<const f32x4 *>(lds8 + (a_t[t] + a_unit[u]) + 16 * pc);
+                }
+                static_for<0, NA>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (C::piece_phase(1, k) == u) issue_a(cur, cur_base, 2 * pr + 1, k, 1);          // this period's second chunk -> Y
+                    if constexpr (C::piece_phase(0, k) == u) {                                                   // the next first chunk -> X
+                        if (!last_per) issue_a(cur, cur_base, 2 * pr + 2, k, 0);
+                        else issue_a(nxt, nxt_base, 0, k, 0);
+                    }
+                });
+                issue_b(g0 + u + D, cur.nblk, nxt.nblk);
+                if constexpr (!(C::KO & 2)) {
+                    if constexpr (C::nwait(u, 0) == C::nwait(u, 1)) vc_wait_vmcnt<C::nwait(u, 0)>();
+                    else if (grp == 0) vc_wait_vmcnt<C::nwait(u, 0)>();
+                    else vc_wait_vmcnt<C::nwait(u, 1)>();
+                }
+                VC_DMA_BARRIER();
+                if constexpr (!(C::KO & 4)) {
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int sum = 4; sum >= 0; --sum)
+#pragma unroll
+                        for (int pa = 2; pa >= 0; --pa) {
+                            const int pb = sum - pa;
+                            if (pb < 0 || pb > 2) continue;
+#pragma unroll
+                            for (int t = 0; t < WM; ++t)
+#pragma unroll
+                                for (int n = 0; n < WN; ++n)
+                                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[pb][n]),
+                                                                                        __builtin_bit_cast(bf16x8, af[pa][t]), acc[t][n], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_s_setprio(0);
+                } else {
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                        for (int t = 0; t < WM; ++t) VC_DMA_KEEP(af[pc][t]);
+#pragma unroll
+                        for (int n = 0; n < WN; ++n) VC_DMA_KEEP(bf[pc][n]);
+                    }
+                }
+                VC_DMA_BARRIER();
+            });
+        }
+        if (grp == 0) VC_DMA_BARRIER();
+        gbase = (gbase + (unsigned)upt) % RING;
+        if constexpr (!(C::KO & 1)) {
+            split_epilogue<C>(p, acc, cur, wave, px, q);
+        } else {
+#pragma unroll
+            for (int t = 0; t < WM; ++t)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) VC_DMA_KEEP(acc[t][n]);
+        }
+        if (!nxt.valid) break;
+        cur = nxt;
+        cur_base = nxt_base;
+        nxt = tile_at(it + 2);
+        nxt_base = tile_base(nxt);
+    }
+    vc_wait_vmcnt<0>();
+}
+
+template <class C> int launch_conv_split3(hipStream_t st, const ConvArgs &a)
+{
+    const size_t lds_bytes = C::LDS_FIXED + (size_t)a.nblks * C::BN * sizeof(float);
+    if (lds_bytes > 160 * 1024) return VC_EINVAL;
+    auto kern = conv_split3_kernel<C>;
+    static vc_lds_raised raised;
+    if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds_bytes, st, a);
+    return hipGetLastError() == hipSuccess ? VC_OK : VC_ELAUNCH;
 }
 
 template <class C> int launch_conv_split(hipStream_t st, const ConvArgs &a)
