@@ -93,7 +93,12 @@ static void pack_split3_period(const float *w, int cout, int cin, int bn, int ps
                     }
             }
 }
-static bool split3_period(int k, int cin) { return k == 3 && (cin % 32) == 0 && !getenv("VC_SPLIT3_PADDED"); }
+// (VC_SPLIT3_PADDED=1: the padded instance for every 3 x 3 layer -- A/B runs; must not change between packing and launching)
+static bool split3_period(int k, int cin)
+{
+    const char *e = getenv("VC_SPLIT3_PADDED");
+    return k == 3 && (cin % 32) == 0 && !(e && e[0] && e[0] != '0');
+}
 
 extern "C" int vc_conv_pack_weights_split(const float *w, const float *bias, int cout, int cin, int k, int pixelshuffle, void *wpk_out,
                                           float *bias_out)
