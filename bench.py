@@ -955,7 +955,7 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                     # scale-table indexes against the CPU path's, and the CPU path's container through THIS decoder without handing
                     # it the encoder's indexes -- with plain fp32 scales and with vc_refine_scales (hip.SCALE_REFINE)
                     for refine in (False, True):
-                        hip.SCALE_REFINE = refine
+                        hip.SCALE_REFINE = refine          # (restored to True right below the loop)
                         t2 = {}
                         vlhbdc.encode_B(model, frames[pk[2]], frames[pk[1]], frames[pk[0]], trace=t2)
                         flips[refine] += sum(int((torch.from_numpy(t2[c]["y_idx"]).reshape(-1) != ref[c]["y_idx"].reshape(-1)).sum()) for c in ("mv", "res"))

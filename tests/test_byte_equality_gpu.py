@@ -79,20 +79,23 @@ def test_end_to_end_containers_against_the_cpu_path(dev, h, w):
     with torch.no_grad():
         for seed, (xb, xc, xa), ref in zip(SEEDS, triples, refs):
             # ---- round 5: the scales near a table entry recomputed in fp64 (hip.SCALE_REFINE) against plain fp32 scales ----
-            for refine in (False, True):
-                hip.SCALE_REFINE = refine
-                tr = {}
-                lhbdc.encode_B(prod, xa.to(dev), xc.to(dev), xb.to(dev), trace=tr)
-                flips[refine] += sum(int((torch.from_numpy(tr[c]["y_idx"]).reshape(-1) != ref[c]["y_idx"].reshape(-1)).sum()) for c in ("mv", "res"))
-                _, s_mv, s_res, sh_mv, sh_res = lhbdc.read_container(ref["container"])
-                try:
-                    td = {}
-                    lhbdc.decode_B(xb.to(dev), xa.to(dev), prod, s_mv, s_res, sh_mv, sh_res, trace=td)
-                    ok = all(int((torch.from_numpy(td[c]["y_sym"]).reshape(-1) != ref[c]["y_sym"].reshape(-1)).sum()) == 0 for c in ("mv", "res"))
-                except hip.VcError:
-                    ok = False
-                unaided[refine] += ok
-            hip.SCALE_REFINE = True
+            keep_refine = hip.SCALE_REFINE
+            try:
+                for refine in (False, True):
+                    hip.SCALE_REFINE = refine
+                    tr = {}
+                    lhbdc.encode_B(prod, xa.to(dev), xc.to(dev), xb.to(dev), trace=tr)
+                    flips[refine] += sum(int((torch.from_numpy(tr[c]["y_idx"]).reshape(-1) != ref[c]["y_idx"].reshape(-1)).sum()) for c in ("mv", "res"))
+                    _, s_mv, s_res, sh_mv, sh_res = lhbdc.read_container(ref["container"])
+                    try:
+                        td = {}
+                        lhbdc.decode_B(xb.to(dev), xa.to(dev), prod, s_mv, s_res, sh_mv, sh_res, trace=td)
+                        ok = all(int((torch.from_numpy(td[c]["y_sym"]).reshape(-1) != ref[c]["y_sym"].reshape(-1)).sum()) == 0 for c in ("mv", "res"))
+                    except hip.VcError:
+                        ok = False
+                    unaided[refine] += ok
+            finally:
+                hip.SCALE_REFINE = keep_refine
             trace = {}
             mv_bits, res_bits = lhbdc.encode_B(prod, xa.to(dev), xc.to(dev), xb.to(dev), trace=trace)
             blob = lhbdc.write_container(None, 1626, mv_bits, res_bits)
