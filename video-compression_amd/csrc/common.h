@@ -74,6 +74,46 @@ __device__ __forceinline__ void vc_store_split4(unsigned char *rec, int half, co
     *reinterpret_cast<u32x2 *>(d + 16) = pm;
     *reinterpret_cast<u32x2 *>(d + 32) = pl;
 }
+// 8 consecutive channels of one pixel as the three 16-byte pieces of its split record
+typedef unsigned vc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vc_split_record(const f32x4 &v0, const f32x4 &v1, vc_u32x4 &ph, vc_u32x4 &pm, vc_u32x4 &pl)
+{
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        vc_split3(v0[e], h[e], m[e], l[e]);
+        vc_split3(v1[e], h[4 + e], m[4 + e], l[4 + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ph[e] = (h[2 * e] >> 16) | h[2 * e + 1];
+        pm[e] = (m[2 * e] >> 16) | m[2 * e + 1];
+        pl[e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
+    }
+}
+// Records of a 256-thread workgroup -- thread tid holds the record of plane tid % PB, pixel tid / PB of a run of 256 / PB consecutive
+// pixels -- to memory as whole lines.  A lane storing its own record writes 16 bytes of every 48 per instruction (24+ lines touched per
+// wave-instruction, three instructions to complete each); through LDS every wave-instruction writes 1 KiB contiguous.
+// `sm`: VC_RECORDS_LDS(PB) bytes; `dst0`: the run's first record in plane 0, `plane_bytes` apart per plane; `npx`: valid pixels of the run
+#define VC_RECORDS_LDS(PB) (256 * 48 + 16 * (PB))
+template <int PB>
+__device__ __forceinline__ void vc_store_records_256(unsigned char *sm, int tid, bool valid, const vc_u32x4 &ph, const vc_u32x4 &pm,
+                                                     const vc_u32x4 &pl, unsigned char *dst0, long long plane_bytes, int npx)
+{
+    constexpr int PPS = 256 / PB, PLB = PPS * 48 + 16;     // + 16: the PB lanes of a pixel land on distinct banks
+    if (valid) {
+        unsigned char *d = sm + (tid % PB) * PLB + (tid / PB) * 48;
+        *reinterpret_cast<vc_u32x4 *>(d) = ph;
+        *reinterpret_cast<vc_u32x4 *>(d + 16) = pm;
+        *reinterpret_cast<vc_u32x4 *>(d + 32) = pl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int slot = k * 256 + tid, p = slot / (3 * PPS), wi = slot - p * (3 * PPS);
+        if (wi < 3 * npx) *reinterpret_cast<vc_u32x4 *>(dst0 + p * plane_bytes + wi * 16) = *reinterpret_cast<const vc_u32x4 *>(sm + p * PLB + wi * 16);
+    }
+}
 // the exact fp32 values back out of a split record (hi + mid + lo with lo + mid first: both partial sums are representable)
 __device__ __forceinline__ f32x4 vc_load_split4(const unsigned char *rec, int half)
 {

@@ -141,8 +141,12 @@ template <int K_, int NTW_, int CPL_ = 1, int TH_ = 16, int RING_ = 4, int KO_ =
     static_assert(WM * 8 == TH_ * 2, "the tile's 2 TH M-tiles split evenly over 8 waves");
     static constexpr int ROWS_IN = TH + K_ - 1, COLS = TW + K_ - 1, PIX = ROWS_IN * COLS;
     static constexpr int PXB = 48;                               // bytes per pixel of a plane image: 3 pieces x 8 channels x 2
-    static constexpr int PLANE_B = PIX * PXB;                    // the chunk image: [plane][pixel][piece] in 16-byte slots
-    static constexpr int NA = (CPL_ * PIX * 3 + 511) / 512;      // DMA instructions per wave and chunk image
+    // the chunk image: [plane][pixel][piece] in 16-byte slots.  With two planes the second one starts on a 256-byte bank row: the two
+    // k-groups that share a ds_read_b128 lane group (same tap, planes 0 / 1) then read 16 disjoint bank quads (pixel stride 48 bytes =
+    // 12 banks; a plane offset of 16 banks mod 64, as the unpadded 14 x 34 image has, makes 4 of the 8 pairs collide)
+    static constexpr int PLANE_SLOTS = CPL_ == 1 ? 3 * PIX : (3 * PIX + 15) / 16 * 16;
+    static constexpr int PLANE_B = PLANE_SLOTS * 16;
+    static constexpr int NA = (CPL_ * PLANE_SLOTS + 511) / 512;  // DMA instructions per wave and chunk image
     static constexpr int A_BYTES = NA * 8192;
     static constexpr int FRAGS = 3 * NTW_;                       // weight fragments (1 KiB) per unit: [piece][n-tile]
     // DMA rounds per unit: every wave fetches one KiB per round.  A last round of exactly 4 fragments is fetched by waves 0-3 (= wave
@@ -273,11 +277,11 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int s = k * 512 + tid;
-        const int pl = s / (3 * C::PIX), s2 = s - pl * (3 * C::PIX);
+        const int pl = s / C::PLANE_SLOTS, s2 = s - pl * C::PLANE_SLOTS;
         const int pix = s2 / 3, piece = s2 - 3 * pix;
         const int row = pix / C::COLS, col = pix - row * C::COLS;
         a_off[k] = pl * (int)plane + (row * p.W + col) * C::PXB + piece * 16;
-        a_rc[k] = pl < CPL ? (row | (col << 8)) : 0x7f7f7f;
+        a_rc[k] = (pl < CPL && s2 < 3 * C::PIX) ? (row | (col << 8)) : 0x7f7f7f;
     }
     auto tile_base = [&](const DmaTile &t) {       // chunk 0's first plane at the footprint's first pixel (may lie outside the tensor)
         return in_b + (long long)t.img * p.in_sn + ((long long)(t.oy0 - C::PAD) * p.W + (t.ox0 - C::PAD)) * C::PXB;
@@ -457,8 +461,9 @@ template <int NTW_, int RING_ = 4, int KO_ = 0> struct Split3Cfg {
     static constexpr int K = 3, NTW = NTW_, CPL = 2, RING = RING_, KO = KO_, U = 9, PAD = 1;
     static constexpr int TH = 12, TW = 32, BN = 16 * NTW_;
     static constexpr int WAVES = 8, WM = 3, WN = NTW_;
-    static constexpr int ROWS_IN = TH + 2, COLS = TW + 2, PIX = ROWS_IN * COLS, PXB = 48, PLANE_B = PIX * PXB;
-    static constexpr int NA = (2 * PIX * 3 + 511) / 512, A_BYTES = NA * 8192;
+    static constexpr int ROWS_IN = TH + 2, COLS = TW + 2, PIX = ROWS_IN * COLS, PXB = 48;
+    static constexpr int PLANE_SLOTS = (3 * PIX + 15) / 16 * 16, PLANE_B = PLANE_SLOTS * 16;   // second plane on a bank row: SplitCfg
+    static constexpr int NA = (2 * PLANE_SLOTS + 511) / 512, A_BYTES = NA * 8192;
     static constexpr int FRAGS = 3 * NTW_, ROUNDS = (FRAGS + 7) / 8, LASTW = FRAGS - 8 * (ROUNDS - 1);
     static constexpr bool EXACT = LASTW == 4;
     static constexpr int SLOTB = EXACT ? FRAGS * 1024 : ROUNDS * 8192;
@@ -531,11 +536,11 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split3_kernel(
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int s = k * 512 + tid;
-        const int pl = s / (3 * C::PIX), s2 = s - pl * (3 * C::PIX);
+        const int pl = s / C::PLANE_SLOTS, s2 = s - pl * C::PLANE_SLOTS;
         const int pix = s2 / 3, piece = s2 - 3 * pix;
         const int row = pix / C::COLS, col = pix - row * C::COLS;
         a_off[k] = pl * (int)plane + (row * p.W + col) * C::PXB + piece * 16;
-        a_rc[k] = pl < 2 ? (row | (col << 8)) : 0x7f7f7f;
+        a_rc[k] = (pl < 2 && s2 < 3 * C::PIX) ? (row | (col << 8)) : 0x7f7f7f;
     }
     auto tile_base = [&](const DmaTile &t) {
         return in_b + (long long)t.img * p.in_sn + ((long long)(t.oy0 - 1) * p.W + (t.ox0 - 1)) * C::PXB;

@@ -121,42 +121,24 @@ extern "C" int vc_conv_pack_weights_split(const float *w, const float *bias, int
 }
 
 // fp32 channels-last window -> split tensor [n][c/8][h][w][3][8] bf16 (48 bytes per pixel and group of 8 channels).
-// PB consecutive lanes take PB consecutive planes of ONE pixel (a 32 PB-byte contiguous read), lanes PB apart consecutive pixels (each
-// plane receives 64 / PB consecutive 48-byte records per wave): whole lines on the read side, long runs on the write side.
-template <int PB> __global__ void k_split3(vc_view a, unsigned char *__restrict__ out, long long out_img_bytes)
+// PB consecutive lanes take PB consecutive planes of ONE pixel (a 32 PB-byte contiguous read), lanes PB apart consecutive pixels:
+// whole lines on the read side; on the write side the workgroup's records go through LDS (vc_store_records_256).
+template <int PB> __global__ void __launch_bounds__(256) k_split3(vc_view a, unsigned char *__restrict__ out, long long out_img_bytes)
 {
-    const int cg = a.c >> 3, nb = cg / PB;
-    const long long per_plane = (long long)a.h * a.w;
-    const long long total = (long long)a.n * cg * per_plane;
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int gi = (int)(i % PB);
-        long long t = i / PB;
-        const long long pos = t % per_plane;
-        t /= per_plane;
-        const int b = (int)(t % nb), n = (int)(t / nb);
-        const int g = b * PB + gi;
-        const int y = (int)(pos / a.w), x = (int)(pos - (long long)y * a.w);
-        const float *src = a.p + view_off(a, n, y, x) + 8 * g;
-        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
-        unsigned h[8], m[8], l[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            vc_split3(v0[e], h[e], m[e], l[e]);
-            vc_split3(v1[e], h[4 + e], m[4 + e], l[4 + e]);
-        }
-        u32x4 ph, pm, pl4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ph[e] = (h[2 * e] >> 16) | h[2 * e + 1];
-            pm[e] = (m[2 * e] >> 16) | m[2 * e + 1];
-            pl4[e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
-        }
-        unsigned char *dst = out + n * out_img_bytes + ((long long)g * per_plane + pos) * 48;
-        *reinterpret_cast<u32x4 *>(dst) = ph;
-        *reinterpret_cast<u32x4 *>(dst + 16) = pm;
-        *reinterpret_cast<u32x4 *>(dst + 32) = pl4;
+    // grid: x = runs of 256 / PB pixels of a row, y = row, z = (image, block of PB planes); the records leave through LDS as whole lines
+    __shared__ __attribute__((aligned(16))) unsigned char sm[VC_RECORDS_LDS(PB)];
+    const int nb = (a.c >> 3) / PB;
+    const int x_run = (int)blockIdx.x * (256 / PB);
+    const int gi = threadIdx.x % PB, x = x_run + (int)threadIdx.x / PB, y = blockIdx.y;
+    const int n = blockIdx.z / nb, g0 = (blockIdx.z - n * nb) * PB;
+    vc_u32x4 ph = {0, 0, 0, 0}, pm = ph, pl = ph;
+    if (x < a.w) {
+        const float *src = a.p + view_off(a, n, y, x) + 8 * (g0 + gi);
+        vc_split_record(*reinterpret_cast<const f32x4 *>(src), *reinterpret_cast<const f32x4 *>(src + 4), ph, pm, pl);
     }
+    const long long plane_bytes = (long long)a.h * a.w * 48;
+    vc_store_records_256<PB>(sm, threadIdx.x, x < a.w, ph, pm, pl, out + n * out_img_bytes + g0 * plane_bytes + ((long long)y * a.w + x_run) * 48,
+                             plane_bytes, min(256 / PB, a.w - x_run));
 }
 
 // out_split: plane 0 of image 0; out_image_bytes: distance between images (0 = dense, c/8 planes per image) -- a window of
@@ -171,10 +153,14 @@ extern "C" int vc_split3(vc_stream s, vc_view a, void *out_split, long long out_
     const long long img = out_image_bytes ? out_image_bytes : (long long)(a.c / 8) * a.h * a.w * 48;
     unsigned char *o = static_cast<unsigned char *>(out_split);
     const int cg = a.c / 8;
-    if (cg % 8 == 0) hipLaunchKernelGGL(k_split3<8>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
-    else if (cg % 4 == 0) hipLaunchKernelGGL(k_split3<4>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
-    else if (cg % 2 == 0) hipLaunchKernelGGL(k_split3<2>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
-    else hipLaunchKernelGGL(k_split3<1>, dim3(ew_grid(total, 256)), dim3(256), 0, as_stream(s), a, o, img);
+    const int pb = cg % 8 == 0 ? 8 : (cg % 4 == 0 ? 4 : (cg % 2 == 0 ? 2 : 1));
+    const long long gz = (long long)a.n * (cg / pb);
+    if (a.h > 65535 || gz > 65535) return VC_EINVAL;
+    const dim3 grid((unsigned)((a.w + 256 / pb - 1) / (256 / pb)), (unsigned)a.h, (unsigned)gz);
+    if (pb == 8) hipLaunchKernelGGL(k_split3<8>, grid, dim3(256), 0, as_stream(s), a, o, img);
+    else if (pb == 4) hipLaunchKernelGGL(k_split3<4>, grid, dim3(256), 0, as_stream(s), a, o, img);
+    else if (pb == 2) hipLaunchKernelGGL(k_split3<2>, grid, dim3(256), 0, as_stream(s), a, o, img);
+    else hipLaunchKernelGGL(k_split3<1>, grid, dim3(256), 0, as_stream(s), a, o, img);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }

@@ -362,46 +362,39 @@ __global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int 
 // (PB consecutive lanes take PB consecutive planes of ONE output pixel: their source reads are one contiguous 32 PB-byte run per corner;
 //  lanes PB apart take consecutive pixels: each plane receives 64 / PB consecutive records per wave)
 template <int PB>
-__global__ void k_upsample_bilinear_sp3(vc_view in, unsigned char *__restrict__ out, long long out_img_bytes, int factor, int align_corners, float scale)
+__global__ void __launch_bounds__(EW_BLOCK) k_upsample_bilinear_sp3(vc_view in, unsigned char *__restrict__ out, long long out_img_bytes, int factor, int align_corners, float scale)
 {
+    // grid: x = runs of EW_BLOCK / PB pixels of a row, y = output row, z = (image, block of PB planes): no per-lane index division,
+    // the row's source rows and weights are wave-uniform
+    static_assert(EW_BLOCK == 256, "vc_store_records_256");
+    __shared__ __attribute__((aligned(16))) unsigned char sm[VC_RECORDS_LDS(PB)];
     const int cg = in.c >> 3, nb = cg / PB, oh = in.h * factor, ow = in.w * factor;
-    const long long total = (long long)in.n * cg * oh * ow;
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int gi = (int)(i % PB);
-        long long t = i / PB;
-        const int x = (int)(t % ow); t /= ow;
-        const int y = (int)(t % oh); t /= oh;
-        const int g = (int)(t % nb) * PB + gi;
-        const int n = (int)(t / nb);
+    const int x_run = (int)blockIdx.x * (EW_BLOCK / PB);
+    const int gi = threadIdx.x % PB, x = x_run + (int)threadIdx.x / PB, y = blockIdx.y;
+    const int n = blockIdx.z / nb, g0 = (blockIdx.z - n * nb) * PB;
+    vc_u32x4 ph = {0, 0, 0, 0}, pm = ph, pl = ph;
+    if (x < ow) {
         int y0, y1, x0, x1;
         float ly0, ly1, lx0, lx1;
         bilinear_src(y, in.h, oh, factor, align_corners, y0, y1, ly0, ly1);
         bilinear_src(x, in.w, ow, factor, align_corners, x0, x1, lx0, lx1);
-        const float *b = in.p + (long long)n * in.sn + 8 * g;
-        u32x4 ph, pm, pl;
+        const float *b = in.p + (long long)n * in.sn + 8 * (g0 + gi);
+        const float *r0 = b + (long long)y0 * in.sh, *r1 = b + (long long)y1 * in.sh;
+        const int o0 = x0 * in.sw, o1 = x1 * in.sw;
+        f32x4 v[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            const f32x4 v00 = *reinterpret_cast<const f32x4 *>(b + (long long)y0 * in.sh + (long long)x0 * in.sw + 4 * hf);
-            const f32x4 v01 = *reinterpret_cast<const f32x4 *>(b + (long long)y0 * in.sh + (long long)x1 * in.sw + 4 * hf);
-            const f32x4 v10 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x0 * in.sw + 4 * hf);
-            const f32x4 v11 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x1 * in.sw + 4 * hf);
-            const f32x4 v = bilinear4(v00, v01, v10, v11, lx0, lx1, ly0, ly1, scale);
-            unsigned h[4], m[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vc_split3(v[e], h[e], m[e], l[e]);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                ph[2 * hf + e] = (h[2 * e] >> 16) | h[2 * e + 1];
-                pm[2 * hf + e] = (m[2 * e] >> 16) | m[2 * e + 1];
-                pl[2 * hf + e] = (l[2 * e] >> 16) | (l[2 * e + 1] & 0xffff0000u);
-            }
+            const f32x4 v00 = *reinterpret_cast<const f32x4 *>(r0 + o0 + 4 * hf);
+            const f32x4 v01 = *reinterpret_cast<const f32x4 *>(r0 + o1 + 4 * hf);
+            const f32x4 v10 = *reinterpret_cast<const f32x4 *>(r1 + o0 + 4 * hf);
+            const f32x4 v11 = *reinterpret_cast<const f32x4 *>(r1 + o1 + 4 * hf);
+            v[hf] = bilinear4(v00, v01, v10, v11, lx0, lx1, ly0, ly1, scale);
         }
-        unsigned char *dst = out + n * out_img_bytes + (((long long)g * oh + y) * ow + x) * 48;
-        *reinterpret_cast<u32x4 *>(dst) = ph;
-        *reinterpret_cast<u32x4 *>(dst + 16) = pm;
-        *reinterpret_cast<u32x4 *>(dst + 32) = pl;
+        vc_split_record(v[0], v[1], ph, pm, pl);
     }
+    const long long plane_bytes = (long long)oh * ow * 48;
+    vc_store_records_256<PB>(sm, threadIdx.x, x < ow, ph, pm, pl, out + n * out_img_bytes + g0 * plane_bytes + ((long long)y * ow + x_run) * 48,
+                             plane_bytes, min(EW_BLOCK / PB, ow - x_run));
 }
 
 static inline bool view_vec4(const vc_view &v)
@@ -417,13 +410,17 @@ extern "C" int vc_upsample_bilinear_sp3(vc_stream s, vc_view in, void *out_split
     const long long total = (long long)in.n * (in.c / 8) * in.h * factor * in.w * factor;
     if (total <= 0) return VC_OK;
     unsigned char *o = static_cast<unsigned char *>(out_split);
-    const int cg = in.c / 8;
-    if (cg % 8 == 0)
-        hipLaunchKernelGGL(k_upsample_bilinear_sp3<8>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
-    else if (cg % 4 == 0)
-        hipLaunchKernelGGL(k_upsample_bilinear_sp3<4>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
+    const int cg = in.c / 8, oh = in.h * factor, ow = in.w * factor;
+    const int pb = cg % 8 == 0 ? 8 : (cg % 4 == 0 ? 4 : 1);
+    const long long gz = (long long)in.n * (cg / pb);
+    if (oh > 65535 || gz > 65535 || (long long)in.w * in.sw > 0x7fffffffll) return VC_EINVAL;
+    const dim3 grid((unsigned)((ow + EW_BLOCK / pb - 1) / (EW_BLOCK / pb)), (unsigned)oh, (unsigned)gz);
+    if (pb == 8)
+        hipLaunchKernelGGL(k_upsample_bilinear_sp3<8>, grid, dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
+    else if (pb == 4)
+        hipLaunchKernelGGL(k_upsample_bilinear_sp3<4>, grid, dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
     else
-        hipLaunchKernelGGL(k_upsample_bilinear_sp3<1>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
+        hipLaunchKernelGGL(k_upsample_bilinear_sp3<1>, grid, dim3(EW_BLOCK), 0, as_stream(s), in, o, img, factor, align_corners, scale);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -798,12 +795,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // first Basic-block layer runs on the split-operand pipeline and reads it as it lies (no fp32 copy, no conversion pass)
 template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
 {
-    const long long total = (long long)feat.n * feat.h * feat.w;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % feat.w);
-        long long t = i / feat.w;
-        const int y = (int)(t % feat.h);
-        const int n = (int)(t / feat.h);
+    // grid: x = strips of EW_BLOCK pixels of a row, y = row, z = image (no per-lane index division; the row's weights are wave-uniform)
+    const int x = (int)(blockIdx.x * EW_BLOCK + threadIdx.x), y = blockIdx.y, n = blockIdx.z;
+    vc_u32x4 ph = {0, 0, 0, 0}, pm = ph, pl = ph;
+    if (x < feat.w) {
         float u = 0.0f, v = 0.0f;
         if (fc.p) {
             // F.interpolate(x2, bilinear, align_corners=True) * 2, then replicate-pad one row/col when
@@ -831,25 +826,7 @@ template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_vi
         float *q = up.p + view_off(up, n, y, x);
         if (SP3) {
             const f32x4 lo = {f1[0], f1[1], f1[2], w0}, hi = {w1, w2, u, v};
-            unsigned char *rec = reinterpret_cast<unsigned char *>(feat.p) + (((long long)n * feat.h + y) * feat.w + x) * 48;
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 ph, pm, pl;
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const f32x4 vv = hf ? hi : lo;
-                unsigned h4[4], m4[4], l4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vc_split3(vv[e], h4[e], m4[e], l4[e]);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    ph[2 * hf + e] = (h4[2 * e] >> 16) | h4[2 * e + 1];
-                    pm[2 * hf + e] = (m4[2 * e] >> 16) | m4[2 * e + 1];
-                    pl[2 * hf + e] = (l4[2 * e] >> 16) | (l4[2 * e + 1] & 0xffff0000u);
-                }
-            }
-            *reinterpret_cast<u32x4 *>(rec) = ph;
-            *reinterpret_cast<u32x4 *>(rec + 16) = pm;
-            *reinterpret_cast<u32x4 *>(rec + 32) = pl;
+            vc_split_record(lo, hi, ph, pm, pl);
             const f32x2 uv = {u, v};
             *reinterpret_cast<f32x2 *>(q) = uv;
         } else if (VEC) {      // the 8 channels of a pixel as two 16-byte stores (eight 4-byte stores touched every line eight times)
@@ -865,6 +842,12 @@ template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_vi
             q[0] = u; q[1] = v;
         }
     }
+    if constexpr (SP3) {          // the row's records as whole lines (vc_store_records_256)
+        __shared__ __attribute__((aligned(16))) unsigned char sm[VC_RECORDS_LDS(1)];
+        const int x_run = (int)blockIdx.x * EW_BLOCK;
+        vc_store_records_256<1>(sm, threadIdx.x, x < feat.w, ph, pm, pl,
+                                reinterpret_cast<unsigned char *>(feat.p) + (((long long)n * feat.h + y) * feat.w + x_run) * 48, 0, min(EW_BLOCK, feat.w - x_run));
+    }
 }
 
 extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
@@ -875,14 +858,14 @@ extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second,
     if (up.h != feat.h || up.w != feat.w) return VC_EINVAL;
     if (fc.p && (fc.c != 2 || (2 * fc.h != feat.h && 2 * fc.h + 1 != feat.h) || (2 * fc.w != feat.w && 2 * fc.w + 1 != feat.w)))
         return VC_EINVAL;
-    const long long total = (long long)feat.n * feat.h * feat.w;
+    if (feat.n < 1 || feat.h < 1 || feat.w < 1) return VC_OK;
+    if (feat.h > 65535 || feat.n > 65535) return VC_EINVAL;
+    const dim3 grid((unsigned)((feat.w + EW_BLOCK - 1) / EW_BLOCK), (unsigned)feat.h, (unsigned)feat.n);
     const bool vec = view_vec4(feat) && reinterpret_cast<uintptr_t>(up.p) % 8 == 0 && up.sn % 2 == 0 && up.sh % 2 == 0 && up.sw % 2 == 0;
     if (vec)
-        hipLaunchKernelGGL(k_spynet_level_input<true>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
-                           fc, feat, up);
+        hipLaunchKernelGGL(k_spynet_level_input<true>, grid, dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
     else
-        hipLaunchKernelGGL(k_spynet_level_input<false>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
-                           fc, feat, up);
+        hipLaunchKernelGGL(k_spynet_level_input<false>, grid, dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -898,8 +881,10 @@ extern "C" int vc_spynet_level_input_sp3(vc_stream s, vc_view first, vc_view sec
     vc_view feat = first;                     // (shape only; p = the split tensor)
     feat.p = static_cast<float *>(feat_split);
     feat.c = 8;
-    const long long total = (long long)feat.n * feat.h * feat.w;
-    hipLaunchKernelGGL((k_spynet_level_input<true, true>), dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
+    if (feat.n < 1 || feat.h < 1 || feat.w < 1) return VC_OK;
+    if (feat.h > 65535 || feat.n > 65535) return VC_EINVAL;
+    const dim3 grid((unsigned)((feat.w + EW_BLOCK - 1) / EW_BLOCK), (unsigned)feat.h, (unsigned)feat.n);
+    hipLaunchKernelGGL((k_spynet_level_input<true, true>), grid, dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
