@@ -274,6 +274,9 @@ def parse_args():
                     help="LHBDC / Flex-Rate: independent GOPs coded per step and GPU with their hierarchy levels batched together "
                          "(default at 1080p: 4 / 2; 1 at 2160p)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--poison", choices=["nan", "zero", "ones"], default=None,
+                    help="debugging aid: fill 96 GB of device memory with this pattern and hand it back to the caching allocator before "
+                         "anything else is allocated -- results must not depend on it (no kernel may read memory nobody wrote)")
     ap.add_argument("--data", default=None, metavar="DIR",
                     help="weak scaling, LHBDC: stream the frames of every step from PNG files through vcamd.data.SequenceReader "
                          "(decode workers -> pinned ring -> async H2D) instead of coding device-resident tensors; the synthetic clip "
@@ -301,6 +304,12 @@ def main():
     if bool(int(os.environ.get("VC_BENCH_SHARE_GPU", "0"))):
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    if args.poison:
+        blocks = [torch.empty(1 << 30, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(24)]       # 24 x 4 GB
+        for b in blocks:
+            b.fill_({"nan": 0x7fc00000, "zero": 0, "ones": 0x3f800000}[args.poison])
+        torch.cuda.synchronize()
+        del blocks                        # (back to the caching allocator, NOT to the driver: the next allocations are carved from it)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -428,6 +437,9 @@ def main():
         t_gathered = time.perf_counter() - t0
         barrier()
         elapsed = time.perf_counter() - t0
+    if os.environ.get("VC_BENCH_DUMP_RECORDS") and rank == 0:      # debugging aid: the gathered per-frame records, exact (float.hex)
+        with open(os.environ["VC_BENCH_DUMP_RECORDS"], "w") as f:
+            json.dump([[float(v).hex() for v in r] for r in sorted(rows.tolist())], f)
     rank_stats = None
     if world > 1:
         cdev = dev if backend == "nccl" else "cpu"

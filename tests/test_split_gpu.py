@@ -47,6 +47,10 @@ CASES = [  # cin, cout, k, n, h, w  (>= 48 tiles of 16 x 32 per image: the sizes
     (96, 32, 5, 1, 120, 230),
     (192, 64, 5, 1, 120, 200),
     (32, 128, 7, 1, 97, 130),      # two blocks of 64 output channels
+    (16, 32, 7, 1, 128, 200),      # 7x7 period instance, ONE period of two 8-channel chunks per tile
+    (48, 64, 5, 1, 120, 230),      # 5x5 period instance, three periods
+    (24, 32, 5, 1, 120, 230),      # 5x5, input channels no multiple of 16: the per-chunk (tap-padded) instance
+    (48, 64, 3, 1, 100, 170),      # 3x3, input channels no multiple of 32: the per-chunk instance
 ]
 
 

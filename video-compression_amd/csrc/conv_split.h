@@ -448,22 +448,27 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_kernel(c
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// 3 x 3 WITHOUT tap padding (input channels a multiple of 32).  K of an MFMA = four (tap, 8-channel plane) k-groups; a 16-channel chunk
-// has 9 x 2 = 18 of them = 4.5 units, which SplitPairs<3> pads to 5.  Here the k-groups of TWO consecutive chunks are walked as one
-// PERIOD of 36 = 9 full units: k-group q of unit u is number g = 4 u + q -> chunk g / 18 of the period, tap (g % 18) / 2, plane g % 2;
-// unit 4 straddles the two chunks (taps 8 of the first, tap 0 of the second).  The first chunk of a period lives in image buffer X,
-// the second in Y, always: the per-lane read offset of a unit (buffer, plane, tap offset of the lane's k-group) is a loop-invariant
-// register.  DMA schedule of a period: Y (this period's second chunk) in phases 1-2 -- Y was last read in phase 8 of the period before,
-// is first read in phase 4 --, X (the next period's / tile's first chunk) in phases 6-7 -- last read in phase 4, first read in the next
-// phase 0.  10 % fewer MFMAs than the padded instance, same results up to the order of the k-groups inside a chunk pair.
+// PERIOD instances: two consecutive chunks walked as one period, so that a chunk's k-groups need not fill whole units.  K of an MFMA =
+// four (tap, 8-channel plane) k-groups; a chunk has KG = K^2 x CPL of them: 3 x 3 (two planes) 18 = 4.5 units, which SplitPairs<3> pads
+// to 5; 5 x 5 25 = 6.25 (padded: 7); 7 x 7 49 = 12.25 (padded: 13).  The 2 KG k-groups of TWO chunks are U = ceil(2 KG / 4) units: 9
+// instead of 10, 13 instead of 14, 25 instead of 26 (3 x 3: none padded; 5 x 5 / 7 x 7: the last two k-groups of the last unit carry
+// zero weights and re-read a valid tap).  k-group q of unit u is number g = 4 u + q -> chunk g / KG of the period, tap (g % KG) / CPL,
+// plane (g % KG) % CPL; one unit straddles the two chunks.  The first chunk of a period lives in image buffer X, the second in Y,
+// always: the per-lane read offset of a unit (buffer, plane, tap offset of the lane's k-group) is a loop-invariant register.  DMA
+// schedule of a period: Y (this period's second chunk) from phase 1 on -- Y was last read in the last phase of the period before, is
+// first read in phase YFIRST = KG / 4 --, X (the next period's / tile's first chunk) from phase XLAST + 2 on -- last read in phase
+// XLAST = (KG - 1) / 4, first read in the next phase 0; a piece requested in phase j is waited for at the end of phase j + D - 1.
+// Same results as the padded instances up to the order of the k-groups inside a chunk pair.  Input channels: a multiple of 16 CPL.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int NTW_, int RING_ = 4, int KO_ = 0> struct Split3Cfg {
-    static constexpr int K = 3, NTW = NTW_, CPL = 2, RING = RING_, KO = KO_, U = 9, PAD = 1;
-    static constexpr int TH = 12, TW = 32, BN = 16 * NTW_;
-    static constexpr int WAVES = 8, WM = 3, WN = NTW_;
-    static constexpr int ROWS_IN = TH + 2, COLS = TW + 2, PIX = ROWS_IN * COLS, PXB = 48;
-    static constexpr int PLANE_SLOTS = (3 * PIX + 15) / 16 * 16, PLANE_B = PLANE_SLOTS * 16;   // second plane on a bank row: SplitCfg
-    static constexpr int NA = (2 * PLANE_SLOTS + 511) / 512, A_BYTES = NA * 8192;
+template <int K_, int NTW_, int TH_ = (K_ == 3 ? 12 : 16), int RING_ = 4, int KO_ = 0> struct SplitPeriodCfg {
+    static constexpr int K = K_, NTW = NTW_, CPL = K_ == 3 ? 2 : 1, RING = RING_, KO = KO_, PAD = K_ / 2;
+    static constexpr int KG = K_ * K_ * CPL, U = (2 * KG + 3) / 4;
+    static constexpr int TH = TH_, TW = 32, BN = 16 * NTW_;
+    static constexpr int WAVES = 8, WM = TH_ * 2 / 8, WN = NTW_;
+    static_assert(WM * 8 == TH_ * 2, "the tile's 2 TH M-tiles split evenly over 8 waves");
+    static constexpr int ROWS_IN = TH + K_ - 1, COLS = TW + K_ - 1, PIX = ROWS_IN * COLS, PXB = 48;
+    static constexpr int PLANE_SLOTS = CPL == 1 ? 3 * PIX : (3 * PIX + 15) / 16 * 16, PLANE_B = PLANE_SLOTS * 16;   // second plane on a bank row: SplitCfg
+    static constexpr int NA = (CPL * PLANE_SLOTS + 511) / 512, A_BYTES = NA * 8192;
     static constexpr int FRAGS = 3 * NTW_, ROUNDS = (FRAGS + 7) / 8, LASTW = FRAGS - 8 * (ROUNDS - 1);
     static constexpr bool EXACT = LASTW == 4;
     static constexpr int SLOTB = EXACT ? FRAGS * 1024 : ROUNDS * 8192;
@@ -471,12 +476,17 @@ template <int NTW_, int RING_ = 4, int KO_ = 0> struct Split3Cfg {
     static constexpr int B_OFF = 2 * A_BYTES, BIAS_OFF = B_OFF + RING_ * SLOTB, LDS_FIXED = BIAS_OFF;
     static constexpr int D = RING_ - 2;
     static_assert(D == 2, "the issue windows below are laid out for weights requested two units ahead");
-    static constexpr int kg_chunk(int u, int q) { return (4 * u + q) / 18; }
-    static constexpr int kg_tap(int u, int q) { return ((4 * u + q) % 18) / 2; }
-    static constexpr int kg_plane(int u, int q) { return (4 * u + q) % 2; }
-    static constexpr int PPP = (NA + 1) / 2;                                       // pieces per phase of a two-phase window
+    static constexpr bool kg_valid(int u, int q) { return 4 * u + q < 2 * KG; }
+    static constexpr int kg_chunk(int u, int q) { return kg_valid(u, q) ? (4 * u + q) / KG : 1; }
+    static constexpr int kg_tap(int u, int q) { return kg_valid(u, q) ? ((4 * u + q) % KG) / CPL : 0; }
+    static constexpr int kg_plane(int u, int q) { return kg_valid(u, q) ? ((4 * u + q) % KG) % CPL : 0; }
+    static constexpr int XLAST = (KG - 1) / 4, YFIRST = KG / 4;
+    static constexpr int YWIN = YFIRST - D, XWIN = U - D - XLAST - 1;               // phases 1 .. YFIRST - D / XLAST + 2 .. U - D
+    static_assert(YWIN >= 1 && XWIN >= 1, "no issue window for a chunk image");
+    static constexpr int PPP = (NA + (YWIN < XWIN ? YWIN : XWIN) - 1) / (YWIN < XWIN ? YWIN : XWIN);   // pieces per phase
     // phase in which piece k of buffer Y (which = 1) / X (which = 0) is requested
-    static constexpr int piece_phase(int which, int k) { return (which ? 1 : 6) + k / PPP; }
+    static constexpr int piece_phase(int which, int k) { return (which ? 1 : XLAST + 2) + k / PPP; }
+    static_assert(piece_phase(1, NA - 1) <= YFIRST - D && piece_phase(0, NA - 1) <= U - D, "chunk image pieces outside their window");
     static constexpr int nA(int u)
     {
         int n = 0;
@@ -490,10 +500,16 @@ template <int NTW_, int RING_ = 4, int KO_ = 0> struct Split3Cfg {
         for (int j = u + 2 - D; j <= u; ++j) n += nA(((j % U) + U) % U) + nb(grp);
         return n;
     }
-    static_assert(nwait(7, 0) <= 63, "vmcnt is a 6-bit counter");
+    static constexpr int max_wait()
+    {
+        int m = 0;
+        for (int u = 0; u < U; ++u) m = nwait(u, 0) > m ? nwait(u, 0) : m;
+        return m;
+    }
+    static_assert(max_wait() <= 63, "vmcnt is a 6-bit counter");
 };
 
-template <class C> __global__ void __launch_bounds__(512, 2) conv_split3_kernel(const ConvArgs p)
+template <class C> __global__ void __launch_bounds__(512, 2) conv_split_period_kernel(const ConvArgs p)
 {
     constexpr int U = C::U, WM = C::WM, WN = C::WN, NA = C::NA, RING = C::RING, D = C::D;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];   // the kernel's only LDS object: starts at LDS address 0
@@ -525,7 +541,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split3_kernel(
     DmaTile cur = tile_at(0);
     if (!cur.valid) return;
 
-    const int nper = p.Cin >> 5;                                  // periods of two 16-channel chunks
+    const int nper = p.Cin / (16 * C::CPL);                       // periods of two chunks of CPL 8-channel planes
     const int upt = nper * U;
     const unsigned char *const in_b = reinterpret_cast<const unsigned char *>(p.in);
     const unsigned char *const wpk = reinterpret_cast<const unsigned char *>(p.wpk);
@@ -540,17 +556,17 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split3_kernel(
         const int pix = s2 / 3, piece = s2 - 3 * pix;
         const int row = pix / C::COLS, col = pix - row * C::COLS;
         a_off[k] = pl * (int)plane + (row * p.W + col) * C::PXB + piece * 16;
-        a_rc[k] = (pl < 2 && s2 < 3 * C::PIX) ? (row | (col << 8)) : 0x7f7f7f;
+        a_rc[k] = (pl < C::CPL && s2 < 3 * C::PIX) ? (row | (col << 8)) : 0x7f7f7f;
     }
     auto tile_base = [&](const DmaTile &t) {
-        return in_b + (long long)t.img * p.in_sn + ((long long)(t.oy0 - 1) * p.W + (t.ox0 - 1)) * C::PXB;
+        return in_b + (long long)t.img * p.in_sn + ((long long)(t.oy0 - C::PAD) * p.W + (t.ox0 - C::PAD)) * C::PXB;
     };
-    auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {      // c: 16-channel chunk of the layer
+    auto issue_a = [&](const DmaTile &t, const unsigned char *tbase, int c, int k, int buf) {      // c: chunk (CPL planes) of the layer
         int rc = a_rc[k], off = a_off[k];
         asm volatile("" : "+v"(rc), "+v"(off));
-        const unsigned iy = (unsigned)(t.oy0 - 1 + (rc & 0xff)), ix = (unsigned)(t.ox0 - 1 + (rc >> 8));
+        const unsigned iy = (unsigned)(t.oy0 - C::PAD + (rc & 0xff)), ix = (unsigned)(t.ox0 - C::PAD + (rc >> 8));
         const bool ok = t.valid && iy < (unsigned)p.H && ix < (unsigned)p.W;
-        const unsigned char *sp = ok ? tbase + ((long long)c * 2 * plane + off) : zero_lane;
+        const unsigned char *sp = ok ? tbase + ((long long)c * C::CPL * plane + off) : zero_lane;
         if constexpr (!(C::KO & 16)) vc_glds16<true>(sp, (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
     };
     const unsigned lane16 = 16 * lane;
@@ -578,7 +594,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split3_kernel(
     vc_wait_vmcnt<0>();
     __syncthreads();
 
-    // per-lane read offsets: M-tile base + (buffer, plane, tap) of the lane's k-group in each of the 9 units
+    // per-lane read offsets: M-tile base + (buffer, plane, tap) of the lane's k-group in each of the U units
     int a_t[WM], a_unit[U];
 #pragma unroll
     for (int t = 0; t < WM; ++t) {
@@ -591,7 +607,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split3_kernel(
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
             if (q == qq)
-                off = C::kg_chunk(u, qq) * C::A_BYTES + C::kg_plane(u, qq) * C::PLANE_B + ((C::kg_tap(u, qq) / 3) * C::COLS + C::kg_tap(u, qq) % 3) * C::PXB;
+                off = C::kg_chunk(u, qq) * C::A_BYTES + C::kg_plane(u, qq) * C::PLANE_B + ((C::kg_tap(u, qq) / C::K) * C::COLS + C::kg_tap(u, qq) % C::K) * C::PXB;
         a_unit[u] = off;
     }
     const int b_lane = C::B_OFF + lane * 16;
@@ -682,11 +698,11 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split3_kernel(
     vc_wait_vmcnt<0>();
 }
 
-template <class C> int launch_conv_split3(hipStream_t st, const ConvArgs &a)
+template <class C> int launch_conv_split_period(hipStream_t st, const ConvArgs &a)
 {
     const size_t lds_bytes = C::LDS_FIXED + (size_t)a.nblks * C::BN * sizeof(float);
     if (lds_bytes > 160 * 1024) return VC_EINVAL;
-    auto kern = conv_split3_kernel<C>;
+    auto kern = conv_split_period_kernel<C>;
     static vc_lds_raised raised;
     if (!vc_raise_lds_limit(reinterpret_cast<const void *>(kern), lds_bytes, raised)) return VC_ELAUNCH;
     hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds_bytes, st, a);

@@ -72,32 +72,40 @@ template <class UN, int K, int CPL> static void pack_split(const float *w, int c
             }
 }
 
-// 3 x 3, input channels a multiple of 32: the period order of Split3Cfg (no tap padding) -- [n-block][period of 32 channels][unit 0..8]
-static void pack_split3_period(const float *w, int cout, int cin, int bn, int ps, unsigned short *dst)
+// Period order of SplitPeriodCfg<K> (two chunks = one period of U units; input channels a multiple of 16 CPL):
+// [n-block][period][unit 0 .. U-1][piece][n-tile][lane][8]; k-groups past the second chunk's last one stay zero
+template <int K> static void pack_split_period(const float *w, int cout, int cin, int bn, int ps, unsigned short *dst)
 {
-    const int ntw = bn / 16, nper = cin / 32, cps = cout / 4;
+    typedef SplitPeriodCfg<K, 4> C;
+    constexpr int CPL = C::CPL, KG = C::KG, U = C::U;
+    const int ntw = bn / 16, nper = cin / (16 * CPL), cps = cout / 4;
     for (int nb = 0; nb < cout / bn; ++nb)
         for (int pr = 0; pr < nper; ++pr)
-            for (int u = 0; u < 9; ++u) {
-                unsigned short *unit = dst + (((size_t)nb * nper + pr) * 9 + u) * (3 * ntw * 512);
+            for (int u = 0; u < U; ++u) {
+                unsigned short *unit = dst + (((size_t)nb * nper + pr) * U + u) * (3 * ntw * 512);
                 for (int n = 0; n < ntw; ++n)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int cop = nb * bn + 16 * n + (lane & 15), q = lane >> 4;
                         const int co = ps ? (cop % cps) * 4 + cop / cps : cop;
-                        const int g = 4 * u + q, chunk = g / 18, tap = (g % 18) / 2, pl = g % 2;
+                        const int g = 4 * u + q;
+                        if (g >= 2 * KG) continue;                       // (memset to zero by the caller)
+                        const int chunk = g / KG, tap = (g % KG) / CPL, pl = (g % KG) % CPL;
                         for (int j = 0; j < 8; ++j) {
                             unsigned short pc[3];
-                            split3_host(w[(((size_t)co * cin + 32 * pr + 16 * chunk + 8 * pl + j) * 3 + tap / 3) * 3 + tap % 3], pc);
+                            split3_host(w[(((size_t)co * cin + (2 * pr + chunk) * 8 * CPL + 8 * pl + j) * K + tap / K) * K + tap % K], pc);
                             for (int piece = 0; piece < 3; ++piece) unit[((piece * ntw + n) * 64 + lane) * 8 + j] = pc[piece];
                         }
                     }
             }
 }
-// (VC_SPLIT3_PADDED=1: the padded instance for every 3 x 3 layer -- A/B runs; must not change between packing and launching)
-static bool split3_period(int k, int cin)
+// (VC_SPLIT_PADDED=1 -- or its first name VC_SPLIT3_PADDED --: the per-chunk padded instances for every layer -- A/B runs; must not
+//  change between packing and launching)
+static bool split_period(int k, int cin, int bn)
 {
-    const char *e = getenv("VC_SPLIT3_PADDED");
-    return k == 3 && (cin % 32) == 0 && !(e && e[0] && e[0] != '0');
+    if (bn == 16) return false;      // (7 x 7 32 -> 16 on 24-row tiles: the period instance measured 2.49 ms against 2.42)
+    const char *e = getenv("VC_SPLIT_PADDED"), *e3 = getenv("VC_SPLIT3_PADDED");
+    if ((e && e[0] && e[0] != '0') || (e3 && e3[0] && e3[0] != '0')) return false;
+    return (k == 3 && (cin % 32) == 0) || ((k == 5 || k == 7) && (cin % 16) == 0);
 }
 
 extern "C" int vc_conv_pack_weights_split(const float *w, const float *bias, int cout, int cin, int k, int pixelshuffle, void *wpk_out,
@@ -108,9 +116,12 @@ extern "C" int vc_conv_pack_weights_split(const float *w, const float *bias, int
     memset(wpk_out, 0, bytes);
     unsigned short *dst = static_cast<unsigned short *>(wpk_out);
     const int bn = split_block(cout, k);
-    if (k == 7) pack_split<SplitUnits<7>, 7, 1>(w, cout, cin, bn, pixelshuffle, dst);
+    if (split_period(k, cin, bn)) {
+        if (k == 7) pack_split_period<7>(w, cout, cin, bn, pixelshuffle, dst);
+        else if (k == 5) pack_split_period<5>(w, cout, cin, bn, pixelshuffle, dst);
+        else pack_split_period<3>(w, cout, cin, bn, pixelshuffle, dst);
+    } else if (k == 7) pack_split<SplitUnits<7>, 7, 1>(w, cout, cin, bn, pixelshuffle, dst);
     else if (k == 5) pack_split<SplitUnits<5>, 5, 1>(w, cout, cin, bn, pixelshuffle, dst);
-    else if (split3_period(k, cin)) pack_split3_period(w, cout, cin, bn, pixelshuffle, dst);
     else pack_split<SplitPairs<3>, 3, 2>(w, cout, cin, bn, pixelshuffle, dst);
     const int cps = cout / 4;
     for (int cop = 0; cop < cout; ++cop) {
@@ -205,10 +216,14 @@ int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
         }
     }
 #endif
+    if (split_period(k, a.Cin, bn)) {
+        if (k == 7) return bn == 64 ? launch_conv_split_period<SplitPeriodCfg<7, 4>>(st, a) : launch_conv_split_period<SplitPeriodCfg<7, 2>>(st, a);
+        if (k == 5) return bn == 64 ? launch_conv_split_period<SplitPeriodCfg<5, 4>>(st, a) : launch_conv_split_period<SplitPeriodCfg<5, 2>>(st, a);
+        return bn == 64 ? launch_conv_split_period<SplitPeriodCfg<3, 4>>(st, a) : launch_conv_split_period<SplitPeriodCfg<3, 2>>(st, a);
+    }
     if (k == 7 && bn == 16) return launch_conv_split<SplitCfg<7, 1, 1, 24>>(st, a);
     if (k == 7) return bn == 64 ? launch_conv_split<SplitCfg<7, 4>>(st, a) : launch_conv_split<SplitCfg<7, 2>>(st, a);
     if (k == 5) return bn == 64 ? launch_conv_split<SplitCfg<5, 4>>(st, a) : launch_conv_split<SplitCfg<5, 2>>(st, a);
-    if (k == 3 && split3_period(k, a.Cin)) return bn == 64 ? launch_conv_split3<Split3Cfg<4>>(st, a) : launch_conv_split3<Split3Cfg<2>>(st, a);
     if (k == 3) return bn == 64 ? launch_conv_split<SplitCfg<3, 4, 2, 12>>(st, a) : launch_conv_split<SplitCfg<3, 2, 2, 12>>(st, a);
     return VC_EINVAL;
 }

@@ -795,10 +795,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // first Basic-block layer runs on the split-operand pipeline and reads it as it lies (no fp32 copy, no conversion pass)
 template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
 {
-    // grid: x = strips of EW_BLOCK pixels of a row, y = row, z = image (no per-lane index division; the row's weights are wave-uniform)
-    const int x = (int)(blockIdx.x * EW_BLOCK + threadIdx.x), y = blockIdx.y, n = blockIdx.z;
-    vc_u32x4 ph = {0, 0, 0, 0}, pm = ph, pl = ph;
-    if (x < feat.w) {
+    const long long total = (long long)feat.n * feat.h * feat.w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % feat.w);
+        long long t = i / feat.w;
+        const int y = (int)(t % feat.h);
+        const int n = (int)(t / feat.h);
         float u = 0.0f, v = 0.0f;
         if (fc.p) {
             // F.interpolate(x2, bilinear, align_corners=True) * 2, then replicate-pad one row/col when
@@ -826,7 +828,25 @@ template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_vi
         float *q = up.p + view_off(up, n, y, x);
         if (SP3) {
             const f32x4 lo = {f1[0], f1[1], f1[2], w0}, hi = {w1, w2, u, v};
-            vc_split_record(lo, hi, ph, pm, pl);
+            unsigned char *rec = reinterpret_cast<unsigned char *>(feat.p) + (((long long)n * feat.h + y) * feat.w + x) * 48;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 ph, pm, pl;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const f32x4 vv = hf ? hi : lo;
+                unsigned h4[4], m4[4], l4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vc_split3(vv[e], h4[e], m4[e], l4[e]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    ph[2 * hf + e] = (h4[2 * e] >> 16) | h4[2 * e + 1];
+                    pm[2 * hf + e] = (m4[2 * e] >> 16) | m4[2 * e + 1];
+                    pl[2 * hf + e] = (l4[2 * e] >> 16) | (l4[2 * e + 1] & 0xffff0000u);
+                }
+            }
+            *reinterpret_cast<u32x4 *>(rec) = ph;
+            *reinterpret_cast<u32x4 *>(rec + 16) = pm;
+            *reinterpret_cast<u32x4 *>(rec + 32) = pl;
             const f32x2 uv = {u, v};
             *reinterpret_cast<f32x2 *>(q) = uv;
         } else if (VEC) {      // the 8 channels of a pixel as two 16-byte stores (eight 4-byte stores touched every line eight times)
@@ -842,12 +862,6 @@ template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_vi
             q[0] = u; q[1] = v;
         }
     }
-    if constexpr (SP3) {          // the row's records as whole lines (vc_store_records_256)
-        __shared__ __attribute__((aligned(16))) unsigned char sm[VC_RECORDS_LDS(1)];
-        const int x_run = (int)blockIdx.x * EW_BLOCK;
-        vc_store_records_256<1>(sm, threadIdx.x, x < feat.w, ph, pm, pl,
-                                reinterpret_cast<unsigned char *>(feat.p) + (((long long)n * feat.h + y) * feat.w + x_run) * 48, 0, min(EW_BLOCK, feat.w - x_run));
-    }
 }
 
 extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
@@ -858,14 +872,14 @@ extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second,
     if (up.h != feat.h || up.w != feat.w) return VC_EINVAL;
     if (fc.p && (fc.c != 2 || (2 * fc.h != feat.h && 2 * fc.h + 1 != feat.h) || (2 * fc.w != feat.w && 2 * fc.w + 1 != feat.w)))
         return VC_EINVAL;
-    if (feat.n < 1 || feat.h < 1 || feat.w < 1) return VC_OK;
-    if (feat.h > 65535 || feat.n > 65535) return VC_EINVAL;
-    const dim3 grid((unsigned)((feat.w + EW_BLOCK - 1) / EW_BLOCK), (unsigned)feat.h, (unsigned)feat.n);
+    const long long total = (long long)feat.n * feat.h * feat.w;
     const bool vec = view_vec4(feat) && reinterpret_cast<uintptr_t>(up.p) % 8 == 0 && up.sn % 2 == 0 && up.sh % 2 == 0 && up.sw % 2 == 0;
     if (vec)
-        hipLaunchKernelGGL(k_spynet_level_input<true>, grid, dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
+        hipLaunchKernelGGL(k_spynet_level_input<true>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
+                           fc, feat, up);
     else
-        hipLaunchKernelGGL(k_spynet_level_input<false>, grid, dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
+        hipLaunchKernelGGL(k_spynet_level_input<false>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
+                           fc, feat, up);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -881,10 +895,8 @@ extern "C" int vc_spynet_level_input_sp3(vc_stream s, vc_view first, vc_view sec
     vc_view feat = first;                     // (shape only; p = the split tensor)
     feat.p = static_cast<float *>(feat_split);
     feat.c = 8;
-    if (feat.n < 1 || feat.h < 1 || feat.w < 1) return VC_OK;
-    if (feat.h > 65535 || feat.n > 65535) return VC_EINVAL;
-    const dim3 grid((unsigned)((feat.w + EW_BLOCK - 1) / EW_BLOCK), (unsigned)feat.h, (unsigned)feat.n);
-    hipLaunchKernelGGL((k_spynet_level_input<true, true>), grid, dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
+    const long long total = (long long)feat.n * feat.h * feat.w;
+    hipLaunchKernelGGL((k_spynet_level_input<true, true>), dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }

@@ -626,8 +626,9 @@ class PackedConv:
             ntw = 4 if self.cout % 64 == 0 else (2 if self.cout % 32 == 0 else 1)
             cpl, th = (2, 12) if self.k == 3 else (1, 24 if ntw == 1 else 16)
             kernel_symbols[key] = f"conv_split_kernel<SplitCfg<{self.k}, {ntw}, {cpl}, {th},"
-            if self.k == 3 and self.cin % 32 == 0 and os.environ.get("VC_SPLIT3_PADDED", "0") in ("", "0"):
-                kernel_symbols[key] = f"conv_split3_kernel<Split3Cfg<{ntw},"       # the period instance (no tap padding)
+            if (ntw > 1 and self.cin % (32 if self.k == 3 else 16) == 0 and os.environ.get("VC_SPLIT_PADDED", "0") in ("", "0")
+                    and os.environ.get("VC_SPLIT3_PADDED", "0") in ("", "0")):
+                kernel_symbols[key] = f"conv_split_period_kernel<SplitPeriodCfg<{self.k}, {ntw}, {th},"    # two chunks per period: less tap padding
             timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
         return out
 
