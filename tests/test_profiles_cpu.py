@@ -53,7 +53,7 @@ def test_dominant_kernel_time_in_the_trace_reproduces_the_roofline_fraction():
     assert roof["bound"] == "mfma" and roof["kernel"].startswith("conv k7 s1") and "@4x1088x1920" in roof["kernel"]
     trace = json.load(open(TRACE))
     sym = roof["kernel_symbol"]
-    assert sym and ("conv_split_kernel" in sym or "conv_dma_kernel" in sym or "conv_mfma_kernel" in sym), sym
+    assert sym and any(k in sym for k in ("conv_split_kernel", "conv_split_period_kernel", "conv_dma_kernel", "conv_mfma_kernel")), sym
     mine = [k for k in trace["names"] if sym in k["name"]]
     assert len(mine) == 1, (sym, [k["name"][:90] for k in trace["names"] if "conv_" in k["name"]][:12])
     # the instance also serves the coarser pyramid levels (and, the native instances, other layers): the instrumented frame is the
