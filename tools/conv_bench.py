@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--half-io", action="store_true",
                     help="fp16 path: half-precision input AND output tensors (VC_CFG_IN_F16 / OUT_F16), as inside a chain of "
                          "fp16-path layers; default is fp32 tensors either side (the first / last layer of a chain)")
+    ap.add_argument("--split-out", action="store_true", help="with --split: the output as a split tensor too (what the layer writes inside the "
+                                                             "models when its consumer is a split layer: 6 instead of 4 bytes per element)")
     ap.add_argument("--split", action="store_true",
                     help="fp32 layers on the split-operand pipeline (VC_CFG_SPLIT, csrc/conv_split.h); the input is converted to a split "
                          "tensor ONCE before the timed launches (inside a chain the producing epilogue writes it)")
@@ -67,6 +69,8 @@ def main():
                 print(f"conv k{k} s{s} {cin}->{cout}: no split-operand instance")
                 continue
             x = hip.split3(x)
+            if args.split_out and co % 8 == 0:
+                out = hip.T.empty(n, ho, wo, co, dev, "sp3")
         for _ in range(2):
             pc(x, out=out, act=hip.ACT_LRELU, res=res)
         stamps = hasattr(hip.lib(), "vc_debug_dma_stamps") and os.environ.get("VC_DMA_VARIANT") == "64"
