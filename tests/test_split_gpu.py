@@ -120,6 +120,23 @@ def test_split_result_does_not_depend_on_the_batch(dev):
     assert torch.equal(again, full)
 
 
+@pytest.mark.parametrize("cin,cout,k,n,h,w", [(64, 32, 7, 3, 272, 480), (96, 32, 5, 2, 544, 960), (128, 128, 3, 3, 272, 480), (32, 16, 7, 2, 544, 960)])
+def test_period_instances_same_bits_alone_in_a_batch_and_launch_after_launch(dev, cin, cout, k, n, h, w):
+    """The period instances (two chunks per period; csrc/conv_split.h SplitPeriodCfg) and the 16-channel per-chunk instance at sizes where
+    every CU walks several tiles and the next tile's first chunk is requested under the current tile's last period."""
+    from vcamd import hip
+    hip.set_fp32_mode("split")
+    _, _, pc = _layer(cin, cout, k, 9, dev)
+    x = hip.T.empty(n, h, w, cin, dev)
+    x.buf.normal_()
+    xs = hip.split3(x)
+    full = pc(xs, act=hip.ACT_RELU).buf.clone()
+    for _ in range(3):
+        assert torch.equal(pc(xs, act=hip.ACT_RELU).buf, full)
+    for i in range(n):
+        assert torch.equal(pc(xs.images(i, i + 1), act=hip.ACT_RELU).buf.reshape(-1), full.reshape(n, -1)[i])
+
+
 def test_split_path_refuses_what_it_does_not_serve(dev):
     from vcamd import hip
     hip.set_fp32_mode("split")
