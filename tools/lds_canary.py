@@ -2,6 +2,7 @@
 """Which kernel writes into LDS it does not own?  A canary kernel (tools/micro/lds_canary.hip: 12 KiB of LDS per workgroup, pattern,
 sleep, check) runs on one stream while a convolution of one kind loops on another: co-resident on the CUs.
 
+    hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/micro/lds_canary.so tools/micro/lds_canary.hip     (once; *.so is not tracked)
     python tools/lds_canary.py
 """
 import ctypes
