@@ -1,6 +1,6 @@
 """CPU: the host side of the split-operand fp32 path (csrc/conv_split.hip) -- the packed weights hold, per (output channel, input
 channel, tap), three bf16 pieces whose sum is the fp32 weight EXACTLY, every weight exactly once, zeros in the padded k-groups; the
-3x3 period order (cin % 32 == 0) has no padding at all.  No GPU needed (vc_conv_pack_weights_split runs on the host)."""
+3x3 period order (cin % 32 == 0) has no padding at all, the 5x5 / 7x7 period order (cin % 16 == 0) two padded k-groups per period.  No GPU needed (vc_conv_pack_weights_split runs on the host)."""
 import numpy as np
 import pytest
 
@@ -24,10 +24,12 @@ def _pieces_to_float(u16):
 
 
 @pytest.mark.parametrize("cout,cin,k,units_per_block", [
-    (64, 32, 7, 13 * 4),        # 7x7: 13 units per 8-channel chunk
-    (32, 64, 7, 13 * 8),
-    (16, 32, 7, 13 * 4),        # one N-tile of 16 channels
-    (64, 96, 5, 7 * 12),        # 5x5: 7 units per chunk
+    (64, 32, 7, 25 * 2),        # 7x7, cin % 16 == 0: periods of two 8-channel chunks = 25 units (two padded k-groups per period)
+    (32, 64, 7, 25 * 4),
+    (16, 32, 7, 13 * 4),        # one N-tile of 16 channels: the per-chunk order, 13 units per 8-channel chunk
+    (32, 8, 7, 13 * 1),         # cin = 8: one chunk, the per-chunk order
+    (64, 96, 5, 13 * 6),        # 5x5, cin % 16 == 0: periods of 13 units
+    (32, 24, 5, 7 * 3),         # 5x5, cin = 24: the per-chunk order, 7 units per chunk
     (128, 64, 3, 9 * 2),        # 3x3, cin % 32 == 0: periods of 9 units, no padding
     (64, 48, 3, 5 * 3),         # 3x3, cin = 48: the padded order, 5 units per 16-channel chunk
 ])
@@ -53,6 +55,8 @@ def test_packed_split_weights_are_an_exact_permutation_of_the_weights(cout, cin,
     slots = total.size
     if k == 3 and cin % 32 == 0:
         assert slots == w.size                                           # the period order: no padded k-group at all
+    elif k in (5, 7) and cin % 16 == 0 and bn > 16:
+        assert slots == w.size + cout * (cin // 16) * 2 * 8              # two padded k-groups (of 8 channels) per period and output channel
     else:
         assert slots > w.size
     assert np.array_equal(bias, b_in)
