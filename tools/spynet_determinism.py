@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """SPyNet alone, launch after launch (run two instances at once to share the GPU): per level, the level input, the up-sampled flow and
 the level's flow must be the same bits every time.
-    python tools/spynet_determinism.py [reps] [--native]
+    python tools/spynet_determinism.py [reps] [--native] [--prealloc] [--no-clones]
 """
 import os
 import sys
@@ -30,6 +30,16 @@ def main():
     a, b = base[..., :H, 0:W].contiguous().to(dev), base[..., :H, 6:W + 6].contiguous().to(dev)
     L = hip.lib()
 
+    prealloc = "--prealloc" in sys.argv      # every per-level tensor allocated once and reused by every run (no allocator reuse inside a run)
+    pool = {}
+
+    def buf(key, *shape_and_dtype):
+        if not prealloc:
+            return T.empty(*shape_and_dtype)
+        if key not in pool:
+            pool[key] = T.empty(*shape_and_dtype)
+        return pool[key]
+
     def run():
         stages = {}
         with torch.no_grad():
@@ -44,8 +54,8 @@ def main():
                 f1, f2 = pyr1[lvl], pyr2[lvl]
                 c = net._convs(lvl)
                 sp = hip.fp32_mode() == "split" and c[0].split_ok and c[1].split_ok and c[1].split_pays(f1.n, f1.h, f1.w)
-                feat = T.empty(f1.n, f1.h, f1.w, 8, dev, "sp3" if sp else "f32")
-                up = T.empty(f1.n, f1.h, f1.w, 2, dev)
+                feat = buf(("feat", lvl), f1.n, f1.h, f1.w, 8, dev, "sp3" if sp else "f32")
+                up = buf(("up", lvl), f1.n, f1.h, f1.w, 2, dev)
                 fv = flow.view() if flow is not None else lhbdc._zero_flow_view(f1)
                 if sp:
                     hip.check(L.vc_spynet_level_input_sp3(hip.stream(), f1.view(), f2.view(), fv, feat.ptr, up.view()), "li")
@@ -56,9 +66,11 @@ def main():
                 stages[f"L{lvl} up"] = up.buf.clone()
                 x = feat
                 for j in range(4):
-                    x = c[j](x, act=hip.ACT_RELU, out_sp3=sp and (j < 2 or (j == 2 and hip.wants_split(c[3], f1))))
+                    osp = sp and (j < 2 or (j == 2 and hip.wants_split(c[3], f1)))
+                    o = buf(("x", lvl, j), f1.n, f1.h, f1.w, c[j].cout, dev, "sp3" if osp else "f32") if prealloc else None
+                    x = c[j](x, out=o, act=hip.ACT_RELU, out_sp3=osp)
                     stages[f"L{lvl} conv{j}"] = x.buf.clone()
-                flow = c[4](x, res=up)
+                flow = c[4](x, res=up, out=buf(("flow", lvl), f1.n, f1.h, f1.w, 2, dev) if prealloc else None)
                 stages[f"L{lvl} flow"] = flow.buf.clone()
         torch.cuda.synchronize()
         return stages
