@@ -58,8 +58,13 @@ def test_dominant_kernel_time_in_the_trace_reproduces_the_roofline_fraction():
     assert len(mine) == 1, (sym, [k["name"][:90] for k in trace["names"] if "conv_" in k["name"]][:12])
     # the instance also serves the coarser pyramid levels (and, the native instances, other layers): the instrumented frame is the
     # LAST thing bench.py launches and its finest level the last dispatch of the instance
-    avg_ms = mine[0]["last_ns"] / 1e6
-    n = 1
+    # (bench.py averages THREE instrumented frames: a single launch varies by +-2-3 % with the clock; their finest-level launches are
+    #  the three longest of the instance's last dispatches)
+    if "last12_ns" in mine[0]:
+        top = sorted(mine[0]["last12_ns"])[-3:]
+        avg_ms, n = sum(top) / len(top) / 1e6, len(top)
+    else:
+        avg_ms, n = mine[0]["last_ns"] / 1e6, 1
     frac = roof["algorithmic_flop_per_launch"] / (avg_ms * 1e-3) / 1e12 / roof["peak"]
     print(f"dominant kernel: {n} dispatch (instrumented frame) in the trace, {avg_ms:.3f} ms -> {frac:.4f} of peak; bench.py HIP events: "
           f"{roof['avg_launch_ms']:.3f} ms -> {roof['frac']:.4f}")

@@ -46,9 +46,10 @@ def main():
         a[3] = max(a[3], ns)
         if int(r["Start_Timestamp"]) > a[4]:          # the class's LAST dispatch in time order
             a[4], a[5] = int(r["Start_Timestamp"]), ns
-        b = by_name.setdefault(name, [0, 0, -1, 0])    # total ns, dispatches, start of the last dispatch, its duration
+        b = by_name.setdefault(name, [0, 0, -1, 0, []])    # total ns, dispatches, start of the last dispatch, its duration, (start, ns) of all
         b[0] += ns
         b[1] += 1
+        b[4].append((int(r["Start_Timestamp"]), ns))
         if int(r["Start_Timestamp"]) > b[2]:
             b[2], b[3] = int(r["Start_Timestamp"]), ns
         total += ns
@@ -57,7 +58,8 @@ def main():
                for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])]
     # (persistent kernels launch one workgroup per CU whatever the layer: all their shapes share ONE grid size, so a class is also
     #  reported per NAME -- the template arguments separate the instances -- with the duration of its last dispatch in time order)
-    names = [{"name": n, "total_ns": b[0], "dispatches": b[1], "share": b[0] / max(total, 1), "last_ns": b[3]}
+    names = [{"name": n, "total_ns": b[0], "dispatches": b[1], "share": b[0] / max(total, 1), "last_ns": b[3],
+              "last12_ns": [d for _, d in sorted(b[4])[-12:]]}
              for n, b in sorted(by_name.items(), key=lambda kv: -kv[1][0])]
     with open(out, "w") as f:
         json.dump({"what": "rocprofv3 --kernel-trace folded by (kernel name, grid size); durations = End - Start timestamps (ns); last_ns = the "
