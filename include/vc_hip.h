@@ -180,6 +180,10 @@ int vc_conv_pack_weights_split(const float *w_oihw, const float *bias, int cout,
                                float *bias_out);
 /* fp32 channels-last window (c % 8 == 0, 16-byte aligned rows) -> dense split tensor, 6 bytes per element */
 int vc_split3(vc_stream s, vc_view in, void *out_split, long long out_image_bytes /* 0 = dense */);
+/* The same for a window whose channel count is no multiple of 8 (or of the layer's chunk): c_out (multiple of 8, >= in.c) channels
+ * are written, those past in.c as zeros -- the input of a split layer packed with zero weights for the padding channels (first layers
+ * with 6 input channels: LHBDC/model/layers.py:202, Flex-Rate.../b_model/unet.py:43). */
+int vc_split3_pad(vc_stream s, vc_view in, void *out_split, long long out_image_bytes /* 0 = dense */, int c_out);
 int vc_conv2d_nhwc(vc_stream s, const vc_conv_desc *d);
 
 /* ------------------------------------------------------------------------------------------

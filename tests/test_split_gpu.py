@@ -51,6 +51,9 @@ CASES = [  # cin, cout, k, n, h, w  (>= 48 tiles of 16 x 32 per image: the sizes
     (48, 64, 5, 1, 120, 230),      # 5x5 period instance, three periods
     (24, 32, 5, 1, 120, 230),      # 5x5, input channels no multiple of 16: the per-chunk (tap-padded) instance
     (48, 64, 3, 1, 100, 170),      # 3x3, input channels no multiple of 32: the per-chunk instance
+    (6, 32, 5, 1, 120, 230),       # input channels padded to the chunk with zero weights (vc_split3_pad): the mask U-Net's first layer
+    (6, 32, 3, 2, 150, 260),       # 3x3: 6 -> 16 channels
+    (24, 64, 3, 1, 100, 170),      # 3x3: 24 -> 32 channels (one period)
 ]
 
 

@@ -87,9 +87,9 @@ def main():
         out = hip.T.empty(n, 2 * h, 2 * w, cout // 4, dev) if ps else hip.T.empty(n, h, w, cout, dev)
         variants = [("native", lambda: pc(x, out=out, act=hip.ACT_RELU))]
         hip.set_fp32_mode("split")
-        xs = hip.split3(x)
+        xs = hip.split3(x, c_out=pc.cin_split)
         variants.append(("split (input already split)", lambda: pc(xs, out=out, act=hip.ACT_RELU)))
-        variants.append(("split + vc_split3 of the input", lambda: pc(hip.split3(x, out=xs), out=out, act=hip.ACT_RELU)))
+        variants.append(("split + vc_split3 of the input", lambda: pc(hip.split3(x, out=xs, c_out=pc.cin_split), out=out, act=hip.ACT_RELU)))
         if cout % 32 == 0:
             osp = hip.T.empty(n, 2 * h, 2 * w, cout // 4, dev, "sp3") if ps else hip.T.empty(n, h, w, cout, dev, "sp3")
             variants.append(("split, split output", lambda: pc(xs, out=osp, act=hip.ACT_RELU)))

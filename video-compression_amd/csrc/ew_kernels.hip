@@ -902,6 +902,47 @@ extern "C" int vc_spynet_level_input_sp3(vc_stream s, vc_view first, vc_view sec
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 window with ANY channel count -> split tensor of c_out channels (a multiple of 8, >= c), channels past c zero: the input of a
+// split-operand layer whose channel count is no multiple of the chunk (first layers: 6 = two warped frames, LHBDC/model/layers.py:202,
+// Flex.../b_model/unet.py:43) -- the layer's weights are packed with zero rows for the padding channels (vcamd/hip.py: PackedConv).
+// One lane per (pixel, group of 8 channels), scalar loads (no alignment asked of the window), three 16-byte stores.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_split3_pad(vc_view a, unsigned char *__restrict__ out, long long out_img_bytes, int planes)
+{
+    const long long per_plane = (long long)a.h * a.w;
+    const long long total = (long long)a.n * planes * per_plane;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pos = i % per_plane;
+        long long t = i / per_plane;
+        const int g = (int)(t % planes), n = (int)(t / planes);
+        const int y = (int)(pos / a.w), x = (int)(pos - (long long)y * a.w);
+        const float *src = a.p + view_off(a, n, y, x) + 8 * g;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (8 * g + e < a.c) ? src[e] : 0.0f;
+        const f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
+        vc_u32x4 ph, pm, pl;
+        vc_split_record(v0, v1, ph, pm, pl);
+        unsigned char *dst = out + n * out_img_bytes + ((long long)g * per_plane + pos) * 48;
+        *reinterpret_cast<vc_u32x4 *>(dst) = ph;
+        *reinterpret_cast<vc_u32x4 *>(dst + 16) = pm;
+        *reinterpret_cast<vc_u32x4 *>(dst + 32) = pl;
+    }
+}
+
+extern "C" int vc_split3_pad(vc_stream s, vc_view a, void *out_split, long long out_image_bytes, int c_out)
+{
+    if (!a.p || !out_split || a.c < 1 || c_out < a.c || (c_out % 8) || ((uintptr_t)out_split % 16) || (out_image_bytes % 16)) return VC_EINVAL;
+    const int planes = c_out / 8;
+    const long long total = (long long)a.n * planes * a.h * a.w;
+    if (total <= 0) return VC_OK;
+    const long long img = out_image_bytes ? out_image_bytes : (long long)planes * a.h * a.w * 48;
+    hipLaunchKernelGGL(k_split3_pad, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, static_cast<unsigned char *>(out_split), img, planes);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // blending
 // ------------------------------------------------------------------------------------------------
 __global__ void k_lhbdc_blend(vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid)

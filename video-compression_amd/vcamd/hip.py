@@ -133,6 +133,7 @@ def lib():
     sig("vc_conv_packed_weight_bytes_split", sz, ci, ci, ci)
     sig("vc_conv_pack_weights_split", ci, vp, vp, ci, ci, ci, ci, vp, vp)
     sig("vc_split3", ci, vp, View, vp, cll)
+    sig("vc_split3_pad", ci, vp, View, vp, cll, ci)
     sig("vc_nchw_to_nhwc", ci, vp, vp, View)
     sig("vc_nhwc_to_nchw", ci, vp, View, vp)
     sig("vc_u8hwc_to_f32nchw_pad", ci, vp, vp, ci, ci, vp, ci, ci)
@@ -186,7 +187,7 @@ EXPORTED_SYMBOLS = [
     "vc_version", "vc_abi_version", "vc_target_arch", "vc_conv_select_cfg", "vc_conv_chunk", "vc_conv_packed_weight_floats",
     "vc_conv_packed_bias_floats", "vc_conv_pack_weights", "vc_conv_packed_weight_bytes_f16",
     "vc_conv_pack_weights_f16", "vc_conv_pack_tail_f16", "vc_conv2d_nhwc", "vc_conv_packed_weight_bytes_split",
-    "vc_conv_pack_weights_split", "vc_split3", "vc_nchw_to_nhwc",
+    "vc_conv_pack_weights_split", "vc_split3", "vc_split3_pad", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_maxpool2_sp3", "vc_avgpool2_sp3", "vc_upsample_bilinear", "vc_upsample_bilinear_sp3", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_spynet_level_input_sp3", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
@@ -398,18 +399,26 @@ def fp32_mode():
 
 
 def wants_split_at(pc, n, h, w):
-    return _FP32_MODE == "split" and pc is not None and pc.split_ok and pc.split_pays(n, h, w)
+    return _FP32_MODE == "split" and pc is not None and pc.split_ok and pc.cin_split == pc.cin and pc.split_pays(n, h, w)
 
 
 def wants_split(pc, x, h=None, w=None):
     """Will the layer ``pc`` run on the split-operand pipeline for an input of x's batch at h x w (default: x's own size)?  The hint
     a producer needs to leave its result as a split tensor (``out_sp3``)."""
-    return (_FP32_MODE == "split" and pc is not None and pc.split_ok
+    return (_FP32_MODE == "split" and pc is not None and pc.split_ok and pc.cin_split == pc.cin      # (a producer cannot write padding channels)
             and pc.split_pays(x.n, x.h if h is None else h, x.w if w is None else w))
 
 
-def split3(x, out=None):
-    """fp32 channels-last window -> split tensor (three bf16 pieces per value, exact): the input format of CFG_SPLIT layers."""
+def split3(x, out=None, c_out=None):
+    """fp32 channels-last window -> split tensor (three bf16 pieces per value, exact): the input format of CFG_SPLIT layers.
+    ``c_out`` (a multiple of 8, >= x.c): pad with zero channels (a layer whose weights are packed with zero rows for them)."""
+    if c_out is not None and c_out != x.c or x.c % 8:
+        c_out = c_out or (x.c + 7) // 8 * 8
+        if out is None:
+            out = T.empty(x.n, x.h, x.w, c_out, x.buf.device, "sp3")
+        timed_hbm(f"k_split3_pad c{x.c}->{c_out} @{x.n}x{x.h}x{x.w}", x.n * x.h * x.w * (4.0 * x.c + 6.0 * c_out),
+                  lambda: check(lib().vc_split3_pad(stream(), x.view(), out.ptr, out.image_bytes, c_out), "vc_split3_pad"))
+        return out
     if out is None:
         out = T.empty(x.n, x.h, x.w, x.c, x.buf.device, "sp3")
     timed_hbm(f"k_split3 c{x.c} @{x.n}x{x.h}x{x.w}", 10.0 * x.n * x.h * x.w * x.c,
@@ -456,9 +465,18 @@ class PackedConv:
         self.tuned = {}
         self._tail = None
         self._wsplit = None
-        split_shape = stride == 1 and ((kh in (5, 7) and cin % 8 == 0 and (cout % 32 == 0 or (kh == 7 and cout % 16 == 0)) and not pixelshuffle) or
-                                       (kh == 3 and cin % 16 == 0 and cout % 32 == 0))
-        self._raw32 = (wnp, bnp) if split_shape else None
+        # input channels are padded to the chunk of the split instance (8 for 5x5 / 7x7, 16 for 3x3) with zero weights: first layers
+        # with 6 channels (LHBDC mask U-Net, Flex-Rate U-Net) run on the split pipeline behind vc_split3_pad
+        chunk = 16 if kh == 3 else 8
+        self.cin_split = (cin + chunk - 1) // chunk * chunk
+        split_shape = stride == 1 and ((kh in (5, 7) and (cout % 32 == 0 or (kh == 7 and cout % 16 == 0)) and not pixelshuffle) or
+                                       (kh == 3 and cout % 32 == 0))
+        if split_shape and self.cin_split != cin:
+            wpad = np.zeros((cout, self.cin_split, kh, kw), dtype=np.float32)
+            wpad[:, :cin] = wnp.reshape(cout, cin, kh, kw)
+            self._raw32 = (wpad, bnp)
+        else:
+            self._raw32 = (wnp, bnp) if split_shape else None
         self._raw = (wnp, bnp) if (_PRECISION == "fp16" and kh == 1 and stride == 1 and cout == cin and cin in (64, 128) and not pixelshuffle) else None
         self._device = device
         ck = L.vc_conv_chunk(self.cfg, kh, stride, cin)
@@ -540,12 +558,12 @@ class PackedConv:
             if self._raw32 is None:
                 raise VcError("no split-operand instance for this layer")
             wnp, bnp = self._raw32
-            nbytes = lib().vc_conv_packed_weight_bytes_split(self.cout, self.cin, self.k)
+            nbytes = lib().vc_conv_packed_weight_bytes_split(self.cout, self.cin_split, self.k)
             if not nbytes:
                 raise VcError("no split-operand instance for this layer")
             w = np.zeros(nbytes // 2, dtype=np.int16)
             b = np.empty(self.cout, dtype=np.float32)
-            check(lib().vc_conv_pack_weights_split(wnp.ctypes.data, None if bnp is None else bnp.ctypes.data, self.cout, self.cin, self.k,
+            check(lib().vc_conv_pack_weights_split(wnp.ctypes.data, None if bnp is None else bnp.ctypes.data, self.cout, self.cin_split, self.k,
                                                    int(self.ps), w.ctypes.data, b.ctypes.data), "vc_conv_pack_weights_split")
             self._wsplit = (torch.from_numpy(w).to(self._device), torch.from_numpy(b).to(self._device))
         return self._wsplit
@@ -592,7 +610,9 @@ class PackedConv:
         front; ``out_sp3``: leave the result as a split tensor for a split consumer."""
         if not self.split_ok:
             raise VcError("a split tensor reached a layer the split-operand pipeline does not serve")
-        xs = x if x.dtype == "sp3" else split3(x)
+        if x.dtype == "sp3" and x.c != self.cin_split:
+            raise VcError("a split tensor must bring the layer's (padded) channel count")
+        xs = x if x.dtype == "sp3" else split3(x, c_out=self.cin_split)
         ho, wo, co = self.out_shape(x.h, x.w)
         if out is None:
             out = T.empty(x.n, ho, wo, co, x.buf.device, "sp3" if out_sp3 else "f32")
@@ -626,7 +646,7 @@ class PackedConv:
             ntw = 4 if self.cout % 64 == 0 else (2 if self.cout % 32 == 0 else 1)
             cpl, th = (2, 12) if self.k == 3 else (1, 24 if ntw == 1 else 16)
             kernel_symbols[key] = f"conv_split_kernel<SplitCfg<{self.k}, {ntw}, {cpl}, {th},"
-            if (ntw > 1 and self.cin % (32 if self.k == 3 else 16) == 0 and os.environ.get("VC_SPLIT_PADDED", "0") in ("", "0")
+            if (ntw > 1 and self.cin_split % (32 if self.k == 3 else 16) == 0 and os.environ.get("VC_SPLIT_PADDED", "0") in ("", "0")
                     and os.environ.get("VC_SPLIT3_PADDED", "0") in ("", "0")):
                 kernel_symbols[key] = f"conv_split_period_kernel<SplitPeriodCfg<{self.k}, {ntw}, {th},"    # two chunks per period: less tap padding
             timer.bracket(key, flops, lambda: check(lib().vc_conv2d_nhwc(stream(), ctypes.byref(d)), what), nbytes)
@@ -641,7 +661,8 @@ class PackedConv:
         if x.dtype == "sp3" or (_FP32_MODE == "split" and self.split_ok and self.split_pays(x.n, x.h, x.w) and epi == EPI_NONE
                                 and in_xform == IN_NONE and act < ACT_SIGMOID
                                 and mul is None and tail is None and (out is None or out.dtype != "f16")
-                                and x.dtype == "f32" and x.c % 8 == 0 and x.sw % 4 == 0 and x.sh % 4 == 0 and x.sn % 4 == 0 and x.ptr % 16 == 0):
+                                and x.dtype == "f32" and x.c == self.cin
+                                and (self.cin_split != self.cin or (x.c % 8 == 0 and x.sw % 4 == 0 and x.sh % 4 == 0 and x.sn % 4 == 0 and x.ptr % 16 == 0))):
             return self._call_split(x, out, act, slope, res, chscale, out_sp3, res_first)
         half_in = x.dtype == "f16"
         esz = 8 if half_in else 4
