@@ -48,7 +48,7 @@ const char *vc_version(void);
 /* ABI number of this header: bumped whenever a struct below changes size or layout (vc_conv_desc grew trailing fields in
  * rounds 4 and 5).  A caller compiled against another number must not call the library (the Python binding checks it on
  * load); descriptors must be zero-initialised (memset) so that fields a caller does not know stay NULL / 0. */
-#define VC_ABI_VERSION 5
+#define VC_ABI_VERSION 6
 int vc_abi_version(void);
 /* Name of the code-object target compiled in ("gfx950"). */
 const char *vc_target_arch(void);
@@ -343,6 +343,30 @@ int vc_gc_indexes(vc_stream s, vc_view scales, const float *scale_table, int n_s
 int vc_refine_scales(vc_stream s, vc_view scales, vc_view in, const float *w_oihw, const float *bias, const float *scale_table,
                      int n_scales, float rel_eps, int *counter);
 int vc_gc_dequant(vc_stream s, const int32_t *symbols, vc_view means, const float *out_gain, vc_view y_hat);
+/* Symbol refinement (ABI 6): the twin of vc_refine_scales for the coded integers.  `vc_refine_layer` names a convolution
+ * (k x k, k odd <= 7, stride 1 or 2, padding k / 2, nn.Conv2d weights [cout][cin][k][k] as stored in the checkpoint, nullable
+ * bias) whose output channels c0 .. c0 + C - 1 are the tensor under refinement, and `in` its channels-last fp32 input.
+ *   vc_refine_y_symbols: elements of y (the analysis transform's last layer, LHBDC/model/layers.py:48-56) with
+ *     | frac(y - mu) - 1/2 | <= eps: y from `y_layer` and mu from `mu_layer` (the hyper-synthesis transform's last layer,
+ *     c0 = M: the means half, layers.py:70-80) in fp64, rounded once to fp32; symbols[n,c,y,x] = round(y - mu) of THOSE values
+ *     (GaussianConditional.compress, layers.py:103).  y / means in memory stay as they are (the decoder re-derives the same mu
+ *     without knowing which elements were refined); y_hat (p nullable) receives (symbol + means) * out_gain for the refined
+ *     elements -- the closed-loop encoder's reconstruction stays what the decoder rebuilds.
+ *   vc_refine_z_symbols: elements of z (the hyper-analysis transform's last layer, layers.py:58-68) with
+ *     | frac(z * in_gain - median) - 1/2 | <= eps (eb_params: the layout of vc_eb_forward): z from `z_layer` in fp64;
+ *     symbols = round(z * in_gain - median), z_hat (p nullable) = (symbol + median) * out_gain (EntropyBottleneck.compress /
+ *     decompress, layers.py:97-98).  Call it BEFORE the hyper-synthesis transform reads z_hat.
+ * counter (optional, device): +1 per refined element.  0 < eps <= 1e-2. */
+typedef struct vc_refine_layer {
+    vc_view in;
+    const float *w_oihw;
+    const float *bias;
+    int k, stride, c0;
+} vc_refine_layer;
+int vc_refine_y_symbols(vc_stream s, vc_view y, vc_refine_layer y_layer, vc_view means, vc_refine_layer mu_layer, float eps,
+                        int32_t *symbols, vc_view y_hat, const float *out_gain, int *counter);
+int vc_refine_z_symbols(vc_stream s, vc_view z, vc_refine_layer z_layer, const float *eb_params, const float *in_gain, float eps,
+                        int32_t *symbols, vc_view z_hat, const float *out_gain, int *counter);
 /* Deterministic two-stage reduction of the per-workgroup partial sums written by the kernels above:
  * out[i] = sum_j partial[i*slots + j], i < count. */
 int vc_bits_reduce(vc_stream s, const double *partial, int slots, int count, double *out);

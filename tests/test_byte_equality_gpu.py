@@ -74,18 +74,31 @@ def test_end_to_end_containers_against_the_cpu_path(dev, h, w):
     refs = pool.run_jobs(triples, pool.lhbdc_encode_job(ora.state_dict()))
     identical, report = 0, []
     from vcamd import hip
-    flips = {False: 0, True: 0}          # scale-table indexes differing from the CPU path's, without / with vc_refine_scales
-    unaided = {False: 0, True: 0}        # CPU-path containers this decoder reads WITHOUT being handed the encoder's indexes
+    # settings: (vc_refine_scales, vc_refine_*_symbols).  Counted over the eight frames against the CPU path's integers:
+    SETTINGS = ((False, False), (True, False), (True, True))
+    flips = {k: 0 for k in SETTINGS}      # differing scale-table indexes
+    sflips = {k: 0 for k in SETTINGS}     # differing symbols (y and z of both codecs)
+    same_blob = {k: 0 for k in SETTINGS}  # byte-identical containers
+    refined = [0, 0]                      # (y, z) elements the symbol refinement decided in fp64 (default setting)
+    unaided = {False: 0, True: 0}         # CPU-path containers this decoder reads WITHOUT being handed the encoder's indexes
     with torch.no_grad():
         for seed, (xb, xc, xa), ref in zip(SEEDS, triples, refs):
-            # ---- round 5: the scales near a table entry recomputed in fp64 (hip.SCALE_REFINE) against plain fp32 scales ----
-            keep_refine = hip.SCALE_REFINE
+            keep = hip.SCALE_REFINE, hip.SYMBOL_REFINE
             try:
-                for refine in (False, True):
-                    hip.SCALE_REFINE = refine
+                for setting in SETTINGS:
+                    hip.SCALE_REFINE, hip.SYMBOL_REFINE = setting
                     tr = {}
-                    lhbdc.encode_B(prod, xa.to(dev), xc.to(dev), xb.to(dev), trace=tr)
-                    flips[refine] += sum(int((torch.from_numpy(tr[c]["y_idx"]).reshape(-1) != ref[c]["y_idx"].reshape(-1)).sum()) for c in ("mv", "res"))
+                    mvb, resb = lhbdc.encode_B(prod, xa.to(dev), xc.to(dev), xb.to(dev), trace=tr)
+                    flips[setting] += sum(int((torch.from_numpy(tr[c]["y_idx"]).reshape(-1) != ref[c]["y_idx"].reshape(-1)).sum()) for c in ("mv", "res"))
+                    sflips[setting] += sum(int((torch.from_numpy(tr[c][k]).reshape(-1) != ref[c][k].reshape(-1)).sum())
+                                           for c in ("mv", "res") for k in ("y_sym", "z_sym"))
+                    same_blob[setting] += lhbdc.write_container(None, 1626, mvb, resb) == ref["container"]
+                    if setting == (True, True):
+                        for c in ("mv", "res"):
+                            refined[0] += tr[c]["refined"][0]
+                            refined[1] += tr[c]["refined"][1]
+                    if setting[1]:
+                        continue
                     _, s_mv, s_res, sh_mv, sh_res = lhbdc.read_container(ref["container"])
                     try:
                         td = {}
@@ -93,9 +106,9 @@ def test_end_to_end_containers_against_the_cpu_path(dev, h, w):
                         ok = all(int((torch.from_numpy(td[c]["y_sym"]).reshape(-1) != ref[c]["y_sym"].reshape(-1)).sum()) == 0 for c in ("mv", "res"))
                     except hip.VcError:
                         ok = False
-                    unaided[refine] += ok
+                    unaided[setting[0]] += ok
             finally:
-                hip.SCALE_REFINE = keep_refine
+                hip.SCALE_REFINE, hip.SYMBOL_REFINE = keep
             trace = {}
             mv_bits, res_bits = lhbdc.encode_B(prod, xa.to(dev), xc.to(dev), xb.to(dev), trace=trace)
             blob = lhbdc.write_container(None, 1626, mv_bits, res_bits)
@@ -117,8 +130,11 @@ def test_end_to_end_containers_against_the_cpu_path(dev, h, w):
                 check_teacher_forced(f"triple {seed}: residual_compressor", teacher_forced(prod.residual_compressor, ref["res"], dev))
             assert abs(len(blob) - len(ref["container"])) <= max(64, 0.001 * len(blob)), (seed, len(blob), len(ref["container"]))
     print(f"end-to-end encode_B containers byte-identical to the CPU path: {identical} of {len(SEEDS)} ({h}x{w}, calibrated checkpoint)")
-    print(f"scale-table indexes differing from the CPU path's over the {len(SEEDS)} frames: {flips[False]} with plain fp32 scales, {flips[True]} with "
-          f"vc_refine_scales; CPU-path containers the HIP decoder reads unaided (no index override): {unaided[False]} / {unaided[True]} of {len(SEEDS)}")
+    print(f"over the {len(SEEDS)} frames, against the CPU path's integers -- plain fp32 / + vc_refine_scales / + vc_refine_*_symbols: "
+          f"scale-table indexes differing {flips[SETTINGS[0]]} / {flips[SETTINGS[1]]} / {flips[SETTINGS[2]]}; symbols differing "
+          f"{sflips[SETTINGS[0]]} / {sflips[SETTINGS[1]]} / {sflips[SETTINGS[2]]}; containers byte-identical "
+          f"{same_blob[SETTINGS[0]]} / {same_blob[SETTINGS[1]]} / {same_blob[SETTINGS[2]]}; elements decided in fp64: {refined[0]} y, {refined[1]} z; "
+          f"CPU-path containers the HIP decoder reads unaided (no index override): {unaided[False]} / {unaided[True]} of {len(SEEDS)}")
     for seed, same, n, m, sym, idx in report:
         print(f"  triple {seed}: {'identical' if same else 'DIFFERENT'} ({n} vs {m} bytes); symbols differing {sym}; indexes differing {idx}")
     if h * w <= 192 * 256:

@@ -159,14 +159,24 @@ def test_lhbdc_1080p_against_oracle(dev, calibrated):
 
 
 def test_flex_1080p_against_oracle(dev):
+    """Round 6: ONE quality bound, |dPSNR| < 1e-3 dB, unconditionally, and at most 2 flipped symbols per tensor of the flow codec (each
+    shown a boundary case by the teacher-forced check).  The test sits on the CALIBRATED checkpoint (trained-like statistics: a
+    flipped symbol is a local +-1 behind a synthesis transform of small gain).  Rounds 2-5 ran it on the seeded 7 dB checkpoint,
+    whose untrained mask U-Net turns ONE flipped flow symbol into a moved prediction (dPSNR 1.15e-3 dB behind 3 flips on the split
+    pipeline, round 5; 3 flips on the native instances as well since the round-5 kernels, measured round 6) -- a property of that
+    checkpoint, not of either pipeline, which is why the bound had been widened at run time; that widening is gone."""
     from helpers import psnr
     from oracle import flex as oflex
     from oracle.cai.entropy_models import get_scale_table
     from oracle.trace import CallLog, CodecTrace
     from vcamd import flex
-    from vcamd.seeding import seeded_state_dict
+    from vcamd.seeding import calibrated_state_dict
+    _flex_1080p_against_oracle(dev, "calibrated", psnr, oflex, get_scale_table, CallLog, CodecTrace, flex, calibrated_state_dict)
+
+
+def _flex_1080p_against_oracle(dev, checkpoint, psnr, oflex, get_scale_table, CallLog, CodecTrace, flex, state_dict_fn):
     prod = flex.BidirFlowRef(n=4)
-    sd = seeded_state_dict(prod.state_dict(), seed=1234)
+    sd = state_dict_fn(prod.state_dict(), seed=1234)
     prod.load_state_dict(sd)
     prod = prod.to(dev).eval()
     ora = oflex.FlexModel(n=4).eval()
@@ -200,13 +210,10 @@ def test_flex_1080p_against_oracle(dev):
         fc, rc = prod.flow_compressor, prod.residual_compressor
         check_teacher_forced("Flex flow_compressor", teacher_forced(fc, ref["flow"], dev, fc.gains([n], l)))
         check_teacher_forced("Flex residual_compressor", teacher_forced(rc, ref["res"], dev, rc.gains([n], l)))
-    assert frac < 2e-3, rep          # end to end: a flip in the motion codec moves the residual codec's whole input
-    # (seeded, non-contractive checkpoint at 7 dB: the bound of the un-cascaded case stays 1e-3 dB; behind OBSERVED flips of the flow
-    #  codec -- each shown a boundary case by the teacher-forced check above -- the cascade gets the LHBDC twin's seeded bound.
-    #  Round 5, split-operand pipeline: 3 flow symbols of 1.04 M flip on this triple, dPSNR 1.15e-3 dB)
-    upstream = rep["flow_y_sym"][0] + rep["flow_z_sym"][0]
-    assert upstream <= 4, rep
-    assert d_psnr < (1e-3 if upstream == 0 else 1e-2) and abs(bits - ref_bits) / ref_bits < 2e-3
+    assert frac < 2e-3, rep
+    for name in ("flow_y_sym", "flow_z_sym"):       # at most 2 boundary-case flips per tensor (each shown one by the teacher-forced check)
+        assert rep[name][0] <= 2, rep
+    assert d_psnr < 1e-3 and abs(bits - ref_bits) / ref_bits < 2e-3, (checkpoint, d_psnr, rep)
     if rep["flow_y_sym"][0] == 0 and rep["flow_z_sym"][0] == 0:
         assert stage["mask"] < 2e-3 and stage["prediction"] < 2e-3
 

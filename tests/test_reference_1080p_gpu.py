@@ -272,6 +272,99 @@ def test_flex_forward_meets_the_reference_at_1088x1920(dev, bundled, frames, tag
     assert d_psnr < 1e-3 and d_bits < 1e-3
 
 
+@pytest.fixture(scope="module")
+def flex_fx():
+    fx = load_fixture("flex_fullsize_1080p.npz")
+    if "container" not in fx:
+        pytest.fail("tests/golden/flex_fullsize_1080p.npz has no bitstream part: regenerate with oracle/gen_golden.py --only flexfullsize")
+    return fx
+
+
+@pytest.fixture(scope="module")
+def flex_codec_model(dev, flex_fx):
+    from vcamd import flex
+    from vcamd.seeding import calibrated_state_dict
+    prod = flex.BidirFlowRef(n=4)
+    prod.load_state_dict(calibrated_state_dict(prod.state_dict(), seed=int(flex_fx["seed"])))
+    prod = prod.to(dev).eval()
+    prod.flow_compressor.update(force=True)
+    prod.residual_compressor.update(force=True)
+    return prod
+
+
+def test_flex_encode_B_gives_the_reference_container_at_1088x1920(dev, flex_fx, flex_codec_model, frames):
+    """Flex-Rate.../test/encode_B.py:74-145 on the full bundled frames (n = 1, l = 1, calibrated checkpoint): the integers handed to
+    the range coder against the reference's (<= 2 boundary-case symbols per tensor; indexes: <= 2e-5 N boundary cases, one bin
+    apart); with no integer differing the four strings and the whole container are the reference's, byte for byte.  The residual
+    codec's input -- behind the flow codec's forward() reconstruction (encode_B.py:92-93) -- on the 1/8 grid."""
+    from vcamd import flex
+    fx = flex_fx
+    xb, xc, xa = frames
+    n_, l_ = int(fx["enc_cfg"][0]), float(fx["enc_cfg"][1])
+    trace = {}
+    with torch.no_grad():
+        mv_bits, res_bits = flex.encode_B(flex_codec_model, xb, xc, xa, n=n_, l=l_, trace=trace)
+    n = {"flow_z": flips("flow z", trace["flow"]["z_sym"], fx["enc_flow_z_sym"]), "res_z": flips("res z", trace["res"]["z_sym"], fx["enc_res_z_sym"])}
+    n["flow_y"] = flips("flow y", trace["flow"]["y_sym"], fx["enc_flow_y_sym"], fx["enc_flow_y_fragile"] if not n["flow_z"] else None)
+    res_in = float((nchw(trace["resid"])[:, :, ::8, ::8] - torch.from_numpy(fx["enc_res_input_sub8"])).abs().max())
+    # (the flow the encoder goes on with is forward()'s: its gained rounding is not among the coded integers, so "upstream" is
+    #  observed on the residual codec's input itself)
+    upstream = n["flow_z"] or n["flow_y"] or res_in > 2e-4
+    n["res_y"] = flips("res y", trace["res"]["y_sym"], fx["enc_res_y_sym"], fx["enc_res_y_fragile"] if not (upstream or n["res_z"]) else None)
+    n_idx = {"flow_idx": flips("flow idx", trace["flow"]["y_idx"], fx["enc_flow_y_idx"], fx["enc_flow_idx_fragile"] if not n["flow_z"] else None),
+             "res_idx": flips("res idx", trace["res"]["y_idx"], fx["enc_res_y_idx"],
+                              fx["enc_res_idx_fragile"] if not (upstream or n["res_z"]) else None)}
+    strings = {"flow_y": mv_bits["strings"][0][0], "flow_z": mv_bits["strings"][1][0],
+               "res_y": res_bits["strings"][0][0], "res_z": res_bits["strings"][1][0]}
+    same = {k: v == fx[k].tobytes() for k, v in strings.items()}
+    blob = flex.write_container(None, l_, mv_bits, res_bits)
+    print(f"Flex-Rate encode_B (n = {n_}, l = {l_}) vs THE REFERENCE at 1088x1920: symbols differing {n}; scale-table indexes differing {n_idx}; "
+          f"residual codec input max|d| (1/8 grid) {res_in:.2e}; strings byte-identical {same}; container {len(blob)} bytes vs {fx['container'].size}")
+    assert all(v <= MAX_FLIPS for v in n.values()), n
+    assert res_in < 2e-3, res_in          # (a flipped gained flow latent moves the prediction locally: calibrated checkpoint, small gain)
+    assert n_idx["flow_idx"] <= max_idx_flips(fx["enc_flow_y_idx"].size) * (10 if n["flow_z"] else 1), n_idx
+    assert n_idx["res_idx"] <= max_idx_flips(fx["enc_res_y_idx"].size) * (10 if n["res_z"] else 1), n_idx
+    n.update(n_idx)
+    assert tuple(mv_bits["shape"]) == tuple(fx["flow_shape"]) and tuple(res_bits["shape"]) == tuple(fx["res_shape"])
+    for k, deps in (("flow_z", ("flow_z",)), ("flow_y", ("flow_z", "flow_y", "flow_idx")), ("res_z", ("res_z",)),
+                    ("res_y", ("res_z", "res_y", "res_idx"))):
+        if not any(n[d] for d in deps):
+            assert same[k], k
+    if not any(n.values()):
+        assert blob == fx["container"].tobytes()
+    assert abs(len(blob) - fx["container"].size) <= 64
+
+
+def test_flex_decode_B_reads_the_reference_container_at_1088x1920(dev, flex_fx, bundled, flex_codec_model, frames):
+    """Flex-Rate.../test/decode_B.py:74-114: the reference's own container through the HIP decoder, unaided -- every integer the range
+    decoder produces equals the reference encoder's (0 differing), the uint8 frame is the reference's up to isolated +-1 roundings,
+    PSNR within 1e-3 dB."""
+    from vcamd import flex
+    fx = flex_fx
+    xb, _, xa = frames
+    n_, l_ = int(fx["enc_cfg"][0]), float(fx["enc_cfg"][1])
+    l_hdr, s_mv, s_res, sh_mv, sh_res = flex.read_container(fx["container"].tobytes())
+    assert l_hdr == int(np.array(l_).astype(np.uint32))      # the header holds the interpolation factor truncated to an integer (quirk B.8)
+    assert tuple(sh_mv) == tuple(fx["flow_shape"]) and tuple(sh_res) == tuple(fx["res_shape"])
+    trace = {}
+    with torch.no_grad():
+        dec = flex.decode_B(flex_codec_model, xb, xa, s_mv, s_res, sh_mv, sh_res, n_, l_, trace=trace)
+    idx_flips = {c: flips(f"{c} idx", trace[c]["y_idx"], fx[f"enc_{c}_y_idx"], fx[f"enc_{c}_idx_fragile"]) for c in ("flow", "res")}
+    n = {f"{c}_{k}": flips(f"{c} {k}", trace[c][k], fx[f"enc_{c}_{k}"]) for c in ("flow", "res") for k in ("z_sym", "y_sym")}
+    ref_u8 = (fx["dec_u8_minus_current"].astype(np.int16) + bundled["current"].astype(np.int16)).astype(np.uint8)
+    u8 = np.round(np.clip(dec[0].cpu().numpy(), 0, 1) * 255.0).astype(np.uint8).transpose(1, 2, 0)[:H, :W]
+    diff = u8.astype(np.int16) - ref_u8.astype(np.int16)
+    moved = float((diff != 0).mean())
+    d_psnr = abs(psnr_u8(u8, bundled["current"]) - float(fx["dec_psnr_u8"]))
+    d_sub = float((dec.cpu()[:, :, ::8, ::8] - torch.from_numpy(fx["dec_sub8"])).abs().max())
+    print(f"Flex-Rate decode_B of THE REFERENCE's container at 1088x1920 (unaided): scale-table indexes differing {idx_flips}; symbols differing {n}; "
+          f"uint8 pixels differing {moved:.2e} (max {int(np.abs(diff).max())} level); float max|d| (1/8 grid) {d_sub:.2e}; dPSNR(uint8) {d_psnr:.2e} dB")
+    assert not any(idx_flips.values()), idx_flips
+    assert not any(n.values()), n
+    assert np.abs(diff).max() <= 1 and moved < 2e-3 and d_sub < 1e-4
+    assert d_psnr < 1e-3
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # ICIP2024 FlowGuidedB (SURVEY 8(f)-4) against the reference's own search + forward at 1088x1920
 # (fixture icip2024_fullsize_1080p.npz, oracle/gen_golden.py --only icipfullsize; seeded checkpoint, quality level 2)

@@ -14,6 +14,60 @@ from vcamd import hip, lhbdc  # noqa: E402
 from vcamd.hip import T  # noqa: E402
 
 
+def describe(key, cur, ref, n, h, w):
+    """Error signature of a differing up-sampled flow ([n, h, w, 2] fp32): where the wrong pixels sit and what they hold."""
+    cur, ref = cur.reshape(n, h, w, 2).cpu(), ref.reshape(n, h, w, 2).cpu()
+    bad = (cur != ref).any(-1)
+    rows = torch.nonzero(bad.any(-1))
+    print(f"    {key}: {int(bad.sum())} wrong pixels in {rows.shape[0]} rows", flush=True)
+    for img, y in rows[:6].tolist():
+        xs = torch.nonzero(bad[img, y]).reshape(-1)
+        runs, start, prev = [], int(xs[0]), int(xs[0])
+        for x in xs[1:].tolist():
+            if x != prev + 1:
+                runs.append((start, prev))
+                start = x
+            prev = x
+        runs.append((start, prev))
+        x0, x1 = runs[0]
+        got, want = cur[img, y, x0:x1 + 1], ref[img, y, x0:x1 + 1]
+        like = [dy for dy in range(-6, 7) if dy and 0 <= y + dy < h and torch.equal(got, ref[img, y + dy, x0:x1 + 1])]
+        other = [j for j in range(n) if j != img and torch.equal(got, ref[j, y, x0:x1 + 1])]
+        print(f"      image {img} row {y}: x runs {runs[:6]} (first run: start % 16 = {x0 % 16}, length {x1 - x0 + 1}); max|d| {float((got - want).abs().max()):.3e}; "
+              f"all zero: {bool((got == 0).all())}; NaN: {bool(torch.isnan(got).any())}; equals another row's values: {like}; another image's: {other}; "
+              f"first wrong / right: {got[0].tolist()} / {want[0].tolist()}", flush=True)
+
+
+def where(cur, ref, n, h, w, slot):
+    """Diagnostic library only (vc_li_diag_read): the hardware unit every wave with a wrong result ran on."""
+    import ctypes
+    import numpy as np
+    L = hip.lib()
+    if not hasattr(L, "vc_li_diag_read"):
+        return
+    SLOT = 1 << 17
+    buf = np.zeros(6 * SLOT * 2, dtype=np.uint32)
+    L.vc_li_diag_read.argtypes = [ctypes.c_void_p]
+    if L.vc_li_diag_read(buf.ctypes.data) != 0:
+        return
+    buf = buf.reshape(6, SLOT, 2)
+    cur, ref = cur.reshape(n, h, w, 2).cpu(), ref.reshape(n, h, w, 2).cpu()
+    bad = torch.nonzero((cur != ref).any(-1))
+    gx = (w + 255) // 256
+    units, all_units = {}, set()
+
+    def unit(hw, xcc):
+        return (int(xcc) & 15, (int(hw) >> 13) & 7, (int(hw) >> 12) & 1, (int(hw) >> 8) & 15, (int(hw) >> 4) & 3)     # XCC, SE, SH, CU, SIMD
+    for img, y, x in bad.tolist():
+        idx = ((img * h + y) * gx + x // 256) * 4 + (x % 256) // 64
+        if idx < SLOT:
+            u = unit(*buf[slot, idx])
+            units[u] = units.get(u, 0) + 1
+    for idx in range(min(SLOT, n * h * gx * 4)):
+        all_units.add(unit(*buf[slot, idx]))
+    print(f"    wrong pixels by (XCC, SE, SH, CU, SIMD) of the wave that produced them: {units}; the launch used {len(all_units)} distinct SIMDs", flush=True)
+
+
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 30
     if "--native" in sys.argv:
@@ -30,6 +84,8 @@ def main():
     a, b = base[..., :H, 0:W].contiguous().to(dev), base[..., :H, 6:W + 6].contiguous().to(dev)
     L = hip.lib()
 
+    global pyr_sizes
+    pyr_sizes = []
     prealloc = "--prealloc" in sys.argv      # every per-level tensor allocated once and reused by every run (no allocator reuse inside a run)
     pool = {}
 
@@ -49,6 +105,7 @@ def main():
                 net.preprocess_into(a[i], p1.images(i, i + 1))
                 net.preprocess_into(b[i], p2.images(i, i + 1))
             pyr1, pyr2 = net.pyramid(p1), net.pyramid(p2)
+            pyr_sizes[:] = [t.h for t in pyr1]
             flow = None
             for lvl in range(len(pyr1)):
                 f1, f2 = pyr1[lvl], pyr2[lvl]
@@ -83,6 +140,20 @@ def main():
         nbad += bool(bad)
         if bad:
             print(f"run {r}: first stages that differ: {bad[:4]}", flush=True)
+            for k, _ in bad[:3]:
+                if k.endswith(" up"):
+                    size = [q for q in ref if q.startswith(k.split()[0] + " ") and q.endswith("pyramid")][0].split()[1]
+                    describe(k, cur[k], ref[k], n, *(int(v) for v in size.split("x")))
+                    lvl = int(k.split()[0][1:])
+                    where(cur[k], ref[k], n, *(int(v) for v in size.split("x")), len(pyr_sizes) - 1 - lvl)
+                    dump = os.environ.get("VC_LI_DUMP")
+                    if dump and lvl > 0 and not os.path.exists(dump):
+                        hh, ww = (int(v) for v in size.split("x"))
+                        c_, r_ = cur[k].reshape(n, hh, ww, 2).cpu(), ref[k].reshape(n, hh, ww, 2).cpu()
+                        rows = torch.nonzero((c_ != r_).any(-1).any(-1))
+                        torch.save({"level": lvl, "h": hh, "w": ww, "rows": rows, "cur_rows": [c_[i, y] for i, y in rows.tolist()],
+                                    "ref_rows": [r_[i, y] for i, y in rows.tolist()], "coarse_cur": cur[f"L{lvl - 1} flow"].cpu(),
+                                    "coarse_same": bool(torch.equal(cur[f"L{lvl - 1} flow"], ref[f"L{lvl - 1} flow"]))}, dump)
     print(f"{nbad} of {reps} runs differ from the first", flush=True)
 
 

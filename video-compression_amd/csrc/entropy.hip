@@ -456,3 +456,117 @@ extern "C" int vc_refine_scales(vc_stream s, vc_view scales, vc_view in, const f
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Symbol refinement (round 6): the twin of vc_refine_scales for the coded integers themselves.  A symbol is round(y - mu)
+// (GaussianConditional.compress, LHBDC/model/layers.py:93-104,168-179) or round(z * gain - median) (EntropyBottleneck.compress);
+// a difference within fp32 summation noise of a half-integer rounds the other way on another platform.  For exactly those
+// elements (| frac(d) - 1/2 | <= eps; ~2 eps of them) the producing layers -- the analysis transform's last convolution for y / z
+// and the hyper-synthesis transform's last convolution for mu -- are recomputed from their inputs in fp64 (k * k * cin exact
+// products, double accumulation, one rounding to fp32 each) and the symbol is taken from those values.  y, z and mu in memory are
+// NOT changed (the decoder cannot know which elements were refined: its mu must stay the encoder's mu); only `symbols` and, when
+// given, the de-quantised tensor `hat` ( = (symbol + mu) * out_gain: the closed-loop encoder's reconstruction) are rewritten.
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_conv_f64(const vc_refine_layer &L, int n, int oy, int ox, int oc, int lane)
+{
+    const int cin = L.in.c, k = L.k, kk = k * k * cin, pad = k >> 1;
+    double acc = 0.0;
+    for (int idx = lane; idx < kk; idx += 64) {
+        const int tap = idx / cin, ci = idx - tap * cin;
+        const int iy = oy * L.stride + tap / k - pad, ix = ox * L.stride + tap % k - pad;
+        if (iy >= 0 && iy < L.in.h && ix >= 0 && ix < L.in.w)
+            acc = fma((double)L.in.p[view_off(L.in, n, iy, ix) + ci], (double)L.w_oihw[((long long)(L.c0 + oc) * cin + ci) * (k * k) + tap], acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    return (float)(acc + (double)(L.bias ? L.bias[L.c0 + oc] : 0.0f));
+}
+
+// MODE 0: Gaussian conditional (centre = mu, a tensor produced by layer `lb`); MODE 1: factorised prior (centre = the channel's median)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_refine_symbols(vc_view v, vc_refine_layer la, vc_view mu, vc_refine_layer lb,
+                                                        const float *__restrict__ eb_params, const float *__restrict__ in_gain, float eps,
+                                                        int32_t *__restrict__ symbols, vc_view hat, const float *__restrict__ out_gain,
+                                                        int *__restrict__ counter)
+{
+    const long long total = (long long)v.n * v.h * v.w * v.c;
+    const int lane = threadIdx.x & 63;
+    const long long nwave = (long long)gridDim.x * (blockDim.x >> 6), wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (long long base = wave0 * 64; base < total; base += nwave * 64) {
+        const long long i = base + lane;
+        bool near = false;
+        if (i < total) {
+            const int c = (int)(i % v.c);
+            long long t = i / v.c;
+            const int x = (int)(t % v.w); t /= v.w;
+            const int y = (int)(t % v.h);
+            const int n = (int)(t / v.h);
+            float a = v.p[view_off(v, n, y, x) + c];
+            if (in_gain) a *= in_gain[c];
+            const float m = MODE == 0 ? mu.p[view_off(mu, n, y, x) + c] : eb_params[(long long)c * VC_EB_PARAMS_PER_CHANNEL + 58];
+            const float d = a - m;
+            near = fabsf((d - floorf(d)) - 0.5f) <= eps;
+        }
+        unsigned long long mask = __ballot(near);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const long long e = base + src;                    // wave-uniform
+            const int c = (int)(e % v.c);
+            long long t = e / v.c;
+            const int x = (int)(t % v.w); t /= v.w;
+            const int y = (int)(t % v.h);
+            const int n = (int)(t / v.h);
+            float a = wave_conv_f64(la, n, y, x, c, lane);
+            if (in_gain) a *= in_gain[c];
+            const float m_mem = MODE == 0 ? mu.p[view_off(mu, n, y, x) + c] : eb_params[(long long)c * VC_EB_PARAMS_PER_CHANNEL + 58];
+            const float m = MODE == 0 ? wave_conv_f64(lb, n, y, x, c, lane) : m_mem;
+            if (lane == 0) {
+                const float q = rintf(a - m);
+                symbols[(((long long)n * v.c + c) * v.h + y) * v.w + x] = (int32_t)q;
+                if (hat.p) {
+                    const float r = q + m_mem;              // the decoder's own centre
+                    hat.p[view_off(hat, n, y, x) + c] = out_gain ? r * out_gain[c] : r;
+                }
+                if (counter) atomicAdd(counter, 1);
+            }
+        }
+    }
+}
+
+static bool refine_layer_ok(const vc_refine_layer &L, const vc_view &out, int need_c)
+{
+    if (!L.in.p || !L.w_oihw || L.k < 1 || !(L.k & 1) || L.k > 7 || L.stride < 1 || L.stride > 2 || L.c0 < 0 || need_c < 1) return false;
+    return L.in.n == out.n && (L.in.h - 1) / L.stride + 1 == out.h && (L.in.w - 1) / L.stride + 1 == out.w;
+}
+
+extern "C" int vc_refine_y_symbols(vc_stream s, vc_view y, vc_refine_layer y_layer, vc_view means, vc_refine_layer mu_layer, float eps,
+                                   int32_t *symbols, vc_view y_hat, const float *out_gain, int *counter)
+{
+    if (!y.p || !means.p || !symbols || !(eps > 0.0f) || eps > 1e-2f) return VC_EINVAL;
+    if (means.n != y.n || means.h != y.h || means.w != y.w || means.c != y.c) return VC_EINVAL;
+    if (y_hat.p && (y_hat.n != y.n || y_hat.h != y.h || y_hat.w != y.w || y_hat.c != y.c)) return VC_EINVAL;
+    if (!refine_layer_ok(y_layer, y, y.c) || !refine_layer_ok(mu_layer, y, y.c)) return VC_EINVAL;
+    const long long total = (long long)y.n * y.h * y.w * y.c;
+    if (total <= 0) return VC_OK;
+    hipLaunchKernelGGL(k_refine_symbols<0>, dim3(ew_grid((total + 63) / 64 * 64, 256)), dim3(256), 0, as_stream(s), y, y_layer, means, mu_layer,
+                       (const float *)nullptr, (const float *)nullptr, eps, symbols, y_hat, out_gain, counter);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
+extern "C" int vc_refine_z_symbols(vc_stream s, vc_view z, vc_refine_layer z_layer, const float *eb_params, const float *in_gain, float eps,
+                                   int32_t *symbols, vc_view z_hat, const float *out_gain, int *counter)
+{
+    if (!z.p || !eb_params || !symbols || !(eps > 0.0f) || eps > 1e-2f) return VC_EINVAL;
+    if (z_hat.p && (z_hat.n != z.n || z_hat.h != z.h || z_hat.w != z.w || z_hat.c != z.c)) return VC_EINVAL;
+    if (!refine_layer_ok(z_layer, z, z.c)) return VC_EINVAL;
+    const long long total = (long long)z.n * z.h * z.w * z.c;
+    if (total <= 0) return VC_OK;
+    vc_view none = {};
+    vc_refine_layer nol = {};
+    hipLaunchKernelGGL(k_refine_symbols<1>, dim3(ew_grid((total + 63) / 64 * 64, 256)), dim3(256), 0, as_stream(s), z, z_layer, none, nol,
+                       eb_params, in_gain, eps, symbols, z_hat, out_gain, counter);
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}

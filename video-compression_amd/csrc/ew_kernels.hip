@@ -864,6 +864,142 @@ template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_vi
     }
 }
 
+#ifdef VC_LI_DIAG
+// ------------------------------------------------------------------------------------------------------------------------------
+// Diagnostic build only (make li_diag -> libvc_hip_lidiag.so; tools/li_diag.sh): the 3-D-grid form of the level-input kernel that gave
+// intermittent wrong pixels when two processes shared the GPU, with one suspect removed per variant
+// (VC_LI_VARIANT): 1 = as it was; 2 = coarse flow through non-temporal loads; 3 = coarse flow through system-scope (sc0 sc1) loads;
+// 4 = ~2 us of s_sleep before the first load; 5 = row index kept in a VGPR (no wave-uniform hoisting of the row weights through
+// v_readfirstlane); 6 = variant 1 behind a hipStreamSynchronize on the host; 7 = variant 1 with every store system-scope; 8 = no packed
+// fp32 instructions pairing u with v (opaque asm barriers: no v_pk_mov_b32 swizzles); 9 = the interpolation in scalar inline asm.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int VAR> __device__ __forceinline__ float li_load(const float *p)
+{
+    if (VAR == 2) return __builtin_nontemporal_load(p);
+    if (VAR == 3) {
+        float r;
+        asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+        return r;
+    }
+    return *p;
+}
+// where each wave ran: HW_ID (wave / SIMD / CU / SE ...) and XCC_ID per (image, row, strip, wave) of the launch, one slot per pyramid level
+#define LI_DBG_SLOT (1 << 17)
+__device__ unsigned li_dbg[6 * LI_DBG_SLOT * 2];
+extern "C" int vc_li_diag_read(unsigned *host_dst)      // 6 slots x LI_DBG_SLOT x {HW_ID, XCC_ID}
+{
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(li_dbg), sizeof(unsigned) * 6 * LI_DBG_SLOT * 2) == hipSuccess ? VC_OK : VC_ELAUNCH;
+}
+template <bool SP3, int VAR> __global__ void k_spynet_level_input_3d(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up, int slot)
+{
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned idx = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+        if (idx < LI_DBG_SLOT) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+            li_dbg[(slot * LI_DBG_SLOT + idx) * 2] = hw;
+            li_dbg[(slot * LI_DBG_SLOT + idx) * 2 + 1] = xcc;
+        }
+    }
+    if (VAR == 4) {
+#pragma unroll 1
+        for (int i = 0; i < 40; ++i) __builtin_amdgcn_s_sleep(100);
+    }
+    int x = (int)(blockIdx.x * EW_BLOCK + threadIdx.x), y = blockIdx.y, n = blockIdx.z;
+    if (VAR == 5) asm volatile("" : "+v"(y));
+    vc_u32x4 ph = {0, 0, 0, 0}, pm = ph, pl = ph;
+    if (x < feat.w) {
+        float u = 0.0f, v = 0.0f;
+        if (fc.p) {
+            const int uh = 2 * fc.h, uw = 2 * fc.w;
+            const int yy = y < uh ? y : uh - 1, xx = x < uw ? x : uw - 1;
+            int y0, y1, x0, x1;
+            float ly0, ly1, lx0, lx1;
+            bilinear_src(yy, fc.h, uh, 2, 1, y0, y1, ly0, ly1);
+            bilinear_src(xx, fc.w, uw, 2, 1, x0, x1, lx0, lx1);
+            const float *b = fc.p + (long long)n * fc.sn;
+            const float *p00 = b + (long long)y0 * fc.sh + (long long)x0 * fc.sw, *p01 = b + (long long)y0 * fc.sh + (long long)x1 * fc.sw;
+            const float *p10 = b + (long long)y1 * fc.sh + (long long)x0 * fc.sw, *p11 = b + (long long)y1 * fc.sh + (long long)x1 * fc.sw;
+            if (VAR == 9) {      // scalar VALU instructions only, written out
+                auto lerp4 = [&](float a0, float a1, float a2, float a3) {
+                    float t0, t1, r;
+                    asm volatile("v_mul_f32 %0, %3, %5\n\tv_fma_f32 %0, %2, %4, %0\n\tv_mul_f32 %1, %3, %7\n\tv_fma_f32 %1, %2, %6, %1"
+                                 : "=&v"(t0), "=&v"(t1) : "v"(lx0), "v"(lx1), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+                    asm volatile("v_mul_f32 %0, %2, %4\n\tv_fma_f32 %0, %1, %3, %0\n\tv_add_f32 %0, %0, %0" : "=&v"(r) : "v"(ly0), "v"(ly1), "v"(t0), "v"(t1));
+                    return r;
+                };
+                u = lerp4(p00[0], p01[0], p10[0], p11[0]);
+                v = lerp4(p00[1], p01[1], p10[1], p11[1]);
+            } else if (VAR == 8) {
+                float a0 = p00[0], a1 = p01[0], a2 = p10[0], a3 = p11[0], b0 = p00[1], b1 = p01[1], b2 = p10[1], b3 = p11[1];
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+                u = (ly0 * (lx0 * a0 + lx1 * a1) + ly1 * (lx0 * a2 + lx1 * a3)) * 2.0f;
+                asm volatile("" : "+v"(u), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+                v = (ly0 * (lx0 * b0 + lx1 * b1) + ly1 * (lx0 * b2 + lx1 * b3)) * 2.0f;
+                asm volatile("" : "+v"(v));
+            } else {
+            u = (ly0 * (lx0 * li_load<VAR>(p00) + lx1 * li_load<VAR>(p01)) + ly1 * (lx0 * li_load<VAR>(p10) + lx1 * li_load<VAR>(p11))) * 2.0f;
+            v = (ly0 * (lx0 * li_load<VAR>(p00 + 1) + lx1 * li_load<VAR>(p01 + 1)) + ly1 * (lx0 * li_load<VAR>(p10 + 1) + lx1 * li_load<VAR>(p11 + 1))) * 2.0f;
+            }
+        }
+        const float gx = grid_coord(VC_WARP_W1, x, u, feat.w, second.w);
+        const float gy = grid_coord(VC_WARP_W1, y, v, feat.h, second.h);
+        const float *f1 = first.p + view_off(first, n, y, x);
+        const float *s2 = second.p + (long long)n * second.sn;
+        float *o = feat.p + view_off(feat, n, y, x);
+        const float w0 = sample_bilinear(s2 + 0, second.sh, second.sw, second.h, second.w, gx, gy, true);
+        const float w1 = sample_bilinear(s2 + 1, second.sh, second.sw, second.h, second.w, gx, gy, true);
+        const float w2 = sample_bilinear(s2 + 2, second.sh, second.sw, second.h, second.w, gx, gy, true);
+        float *q = up.p + view_off(up, n, y, x);
+        const f32x4 lo = {f1[0], f1[1], f1[2], w0}, hi = {w1, w2, u, v};
+        const f32x2 uv = {u, v};
+        if (SP3) {
+            vc_split_record(lo, hi, ph, pm, pl);
+            if (VAR == 7) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(q), "v"(uv) : "memory");
+            else *reinterpret_cast<f32x2 *>(q) = uv;
+        } else if (VAR == 7) {
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1\n\t"
+                         "global_store_dwordx2 %3, %4, off sc0 sc1" :: "v"(o), "v"(lo), "v"(hi), "v"(q), "v"(uv) : "memory");
+        } else {
+            *reinterpret_cast<f32x4 *>(o) = lo;
+            *reinterpret_cast<f32x4 *>(o + 4) = hi;
+            *reinterpret_cast<f32x2 *>(q) = uv;
+        }
+    }
+    if constexpr (SP3) {
+        __shared__ __attribute__((aligned(16))) unsigned char sm[VC_RECORDS_LDS(1)];
+        const int x_run = (int)blockIdx.x * EW_BLOCK;
+        vc_store_records_256<1>(sm, threadIdx.x, x < feat.w, ph, pm, pl,
+                                reinterpret_cast<unsigned char *>(feat.p) + (((long long)n * feat.h + y) * feat.w + x_run) * 48, 0, min(EW_BLOCK, feat.w - x_run));
+    }
+}
+static int li_variant()
+{
+    const char *e = getenv("VC_LI_VARIANT");
+    return e ? atoi(e) : 0;
+}
+template <bool SP3> static bool li_launch_3d(hipStream_t st, vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
+{
+    const int var = li_variant();
+    if (var < 1 || var > 9) return false;
+    const dim3 grid((unsigned)((feat.w + EW_BLOCK - 1) / EW_BLOCK), (unsigned)feat.h, (unsigned)feat.n);
+    int slot = 0;
+    for (int hh = feat.h; hh < 1000 && slot < 5; hh *= 2) ++slot;       // 1088 -> 0, 544 -> 1, ... 34 -> 5
+    if (var == 6) (void)hipStreamSynchronize(st);
+    switch (var) {
+    case 2: hipLaunchKernelGGL((k_spynet_level_input_3d<SP3, 2>), grid, dim3(EW_BLOCK), 0, st, first, second, fc, feat, up, slot); break;
+    case 3: hipLaunchKernelGGL((k_spynet_level_input_3d<SP3, 3>), grid, dim3(EW_BLOCK), 0, st, first, second, fc, feat, up, slot); break;
+    case 4: hipLaunchKernelGGL((k_spynet_level_input_3d<SP3, 4>), grid, dim3(EW_BLOCK), 0, st, first, second, fc, feat, up, slot); break;
+    case 5: hipLaunchKernelGGL((k_spynet_level_input_3d<SP3, 5>), grid, dim3(EW_BLOCK), 0, st, first, second, fc, feat, up, slot); break;
+    case 7: hipLaunchKernelGGL((k_spynet_level_input_3d<SP3, 7>), grid, dim3(EW_BLOCK), 0, st, first, second, fc, feat, up, slot); break;
+    case 8: hipLaunchKernelGGL((k_spynet_level_input_3d<SP3, 8>), grid, dim3(EW_BLOCK), 0, st, first, second, fc, feat, up, slot); break;
+    case 9: hipLaunchKernelGGL((k_spynet_level_input_3d<SP3, 9>), grid, dim3(EW_BLOCK), 0, st, first, second, fc, feat, up, slot); break;
+    default: hipLaunchKernelGGL((k_spynet_level_input_3d<SP3, 1>), grid, dim3(EW_BLOCK), 0, st, first, second, fc, feat, up, slot); break;
+    }
+    return true;
+}
+#endif
+
 extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up)
 {
     if (!first.p || !second.p || !feat.p || !up.p) return VC_EINVAL;
@@ -874,6 +1010,9 @@ extern "C" int vc_spynet_level_input(vc_stream s, vc_view first, vc_view second,
         return VC_EINVAL;
     const long long total = (long long)feat.n * feat.h * feat.w;
     const bool vec = view_vec4(feat) && reinterpret_cast<uintptr_t>(up.p) % 8 == 0 && up.sn % 2 == 0 && up.sh % 2 == 0 && up.sw % 2 == 0;
+#ifdef VC_LI_DIAG
+    if (vec && li_launch_3d<false>(as_stream(s), first, second, fc, feat, up)) return VC_OK;
+#endif
     if (vec)
         hipLaunchKernelGGL(k_spynet_level_input<true>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second,
                            fc, feat, up);
@@ -896,6 +1035,9 @@ extern "C" int vc_spynet_level_input_sp3(vc_stream s, vc_view first, vc_view sec
     feat.p = static_cast<float *>(feat_split);
     feat.c = 8;
     const long long total = (long long)feat.n * feat.h * feat.w;
+#ifdef VC_LI_DIAG
+    if (li_launch_3d<true>(as_stream(s), first, second, fc, feat, up)) return VC_OK;
+#endif
     hipLaunchKernelGGL((k_spynet_level_input<true, true>), dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
     VC_LAUNCH_CHECK();
     return VC_OK;

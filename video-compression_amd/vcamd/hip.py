@@ -3,6 +3,7 @@
 This is the only door to the compute path: there is NO CPU fallback.  If the library is missing the
 import of any model module fails loudly with instructions to build it.
 """
+import contextlib
 import ctypes
 import os
 
@@ -14,7 +15,7 @@ _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("VC_HIP_LIB") or os.path.join(_PKG_DIR, "libvc_hip.so")
 
 VC_OK = 0
-ABI_VERSION = 5          # VC_ABI_VERSION of include/vc_hip.h (struct layouts below)
+ABI_VERSION = 6          # VC_ABI_VERSION of include/vc_hip.h (struct layouts below)
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID, ACT_CLAMP01 = 0, 1, 2, 3, 4
 EPI_NONE, EPI_GDN, EPI_IGDN = 0, 1, 2
 IN_NONE, IN_SQUARE = 0, 1
@@ -48,6 +49,12 @@ class ConvDesc(ctypes.Structure):
                 ("epi", ctypes.c_int), ("in_xform", ctypes.c_int), ("out_mode", ctypes.c_int),
                 ("cfg", ctypes.c_int),
                 ("tail_wpk", ctypes.c_void_p), ("tail_bias", ctypes.c_void_p)]      # fused 1x1 tail (VC_CFG_DMA), include/vc_hip.h
+
+
+class RefineLayer(ctypes.Structure):
+    """vc_refine_layer of include/vc_hip.h: the convolution whose output is recomputed in fp64 for boundary-case symbols"""
+    _fields_ = [("inp", View), ("w_oihw", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("k", ctypes.c_int), ("stride", ctypes.c_int),
+                ("c0", ctypes.c_int)]
 
 
 _lib = None
@@ -169,6 +176,8 @@ def lib():
     sig("vc_gc_indexes", ci, vp, View, vp, ci, vp)
     sig("vc_refine_scales", ci, vp, View, View, vp, vp, vp, ci, cf, vp)
     sig("vc_gc_dequant", ci, vp, vp, View, vp, View)
+    sig("vc_refine_y_symbols", ci, vp, View, RefineLayer, View, RefineLayer, cf, vp, View, vp, vp)
+    sig("vc_refine_z_symbols", ci, vp, View, RefineLayer, vp, vp, cf, vp, View, vp, vp)
     sig("vc_bits_reduce", ci, vp, vp, ci, ci, vp)
     sig("vc_bits_slots", ci)
     sig("vc_psnr_uint8", ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp)
@@ -192,7 +201,7 @@ EXPORTED_SYMBOLS = [
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_spynet_level_input_sp3", "vc_lhbdc_blend", "vc_flex_blend",
     "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes", "vc_refine_scales",
-    "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_psnr_uint8", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
+    "vc_refine_y_symbols", "vc_refine_z_symbols", "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_psnr_uint8", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes", "vc_rans_decode_stream",
     # the operator spellings of SURVEY.md 8(b), thin forwards (csrc/abi_aliases.cpp)
     "vc_gdn", "vc_spynet_level", "vc_pool", "vc_upsample", "vc_pad", "vc_blend", "vc_factorized_bits", "vc_gaussian_symbols",
@@ -248,6 +257,8 @@ class T:
         return T(self.buf, self.n, self.h, self.w, c1 - c0, self.sn, self.sh, self.sw, self.off + c0, self.dtype)
 
     def crop(self, h, w):
+        if self.dtype == "sp3":
+            raise VcError("a split tensor is plane-major: it has no crop window")
         return T(self.buf, self.n, h, w, self.c, self.sn, self.sh, self.sw, self.off, self.dtype)
 
     def images(self, n0, n1):
@@ -278,6 +289,8 @@ class T:
 
     def to_nchw(self):
         """Debug/inspection helper (torch indexing, not on the hot path)."""
+        if self.dtype == "sp3":
+            raise VcError("to_nchw reads fp32 / half windows (a split tensor holds three bf16 pieces per value)")
         full = self.buf[self.off:]
         return torch.as_strided(full, (self.n, self.c, self.h, self.w), (self.sn, 1, self.sh, self.sw)).contiguous().float()
 
@@ -371,6 +384,12 @@ HALF_DEFORM = bool(int(os.environ.get("VC_HALF_DEFORM", "1")))
 # VC_SCALE_REFINE=0 keeps the plain fp32 scales (A/B, tests).
 SCALE_REFINE = bool(int(os.environ.get("VC_SCALE_REFINE", "1")))
 SCALE_REFINE_EPS = 2e-5
+# Encoder side of the bitstream paths: latents whose difference with their centre (mu / the channel's median) lies within
+# SYMBOL_REFINE_EPS of a half-integer are recomputed in fp64 from the inputs of the layers that produced them
+# (vc_refine_y_symbols / vc_refine_z_symbols): the coded integer stops depending on this side's summation order in those layers.
+# VC_SYMBOL_REFINE=0 keeps the plain fp32 rounding (A/B, tests).
+SYMBOL_REFINE = bool(int(os.environ.get("VC_SYMBOL_REFINE", "1")))
+SYMBOL_REFINE_EPS = 2e-5
 
 
 def set_conv_precision(mode):
@@ -396,6 +415,23 @@ def set_fp32_mode(mode):
 
 def fp32_mode():
     return _FP32_MODE
+
+
+# The hyper-synthesis transform of the BITSTREAM paths always runs on this pipeline, whatever VC_FP32_MODE says: the scale-table
+# indexes a decoder derives from it are part of the stream's meaning (the CompressAI format carries none), so a stream written
+# under one fp32 mode must decode under the other.  (The transform is five small layers: its cost is nothing.)
+BITSTREAM_HS_MODE = "native"
+
+
+@contextlib.contextmanager
+def fp32_mode_pinned(mode):
+    global _FP32_MODE
+    keep = _FP32_MODE
+    _FP32_MODE = mode
+    try:
+        yield
+    finally:
+        _FP32_MODE = keep
 
 
 def wants_split_at(pc, n, h, w):
@@ -605,9 +641,17 @@ class PackedConv:
         (see VC_CFG_RES_F16 in include/vc_hip.h)."""
         return self.wpk16 is not None and (CFG_PWS in self.candidates or (self.k == 3 and self.stride == 1 and CFG_DMA in self.candidates))
 
-    def _call_split(self, x, out, act, slope, res, chscale, out_sp3, res_first):
+    def _call_split(self, x, out, act, slope, res, chscale, out_sp3, res_first, epi=EPI_NONE, mul=None, in_xform=IN_NONE, tail=None,
+                    out_f16=False):
         """The layer on the split-operand pipeline.  ``x``: an fp32 window (converted here) or a split tensor left by the layer in
         front; ``out_sp3``: leave the result as a split tensor for a split consumer."""
+        if epi != EPI_NONE or mul is not None or in_xform != IN_NONE or tail is not None or act >= ACT_SIGMOID:
+            raise VcError("the split-operand pipeline has plain / (Leaky)ReLU epilogues only: no GDN, multiplier, input transform, "
+                          "fused tail, sigmoid or clamp (a split tensor reached a layer that needs one)")
+        if out_f16 and out is None:
+            out_f16 = False            # (a hint, like on the native path: the result of a split layer stays fp32 / split)
+        if out is not None and out.dtype == "f16":
+            raise VcError("the split-operand pipeline stores fp32 or split tensors")
         if not self.split_ok:
             raise VcError("a split tensor reached a layer the split-operand pipeline does not serve")
         if x.dtype == "sp3" and x.c != self.cin_split:
@@ -658,12 +702,17 @@ class PackedConv:
         result may be stored as half (bit-identical downstream, half the traffic).  Honoured only when this layer
         itself runs on the fp16 path and allocates its own output; otherwise the result stays fp32."""
         ho, wo, co = self.out_shape(x.h, x.w)
+
+        def vec16(t):
+            """an fp32 window the split epilogue can touch in 16-byte groups (split windows are always aligned)"""
+            return t is None or t.dtype == "sp3" or (t.dtype == "f32" and t.ptr % 16 == 0 and t.sn % 4 == 0 and t.sh % 4 == 0 and t.sw % 4 == 0)
         if x.dtype == "sp3" or (_FP32_MODE == "split" and self.split_ok and self.split_pays(x.n, x.h, x.w) and epi == EPI_NONE
                                 and in_xform == IN_NONE and act < ACT_SIGMOID
                                 and mul is None and tail is None and (out is None or out.dtype != "f16")
+                                and vec16(out) and vec16(res) and co % 4 == 0
                                 and x.dtype == "f32" and x.c == self.cin
                                 and (self.cin_split != self.cin or (x.c % 8 == 0 and x.sw % 4 == 0 and x.sh % 4 == 0 and x.sn % 4 == 0 and x.ptr % 16 == 0))):
-            return self._call_split(x, out, act, slope, res, chscale, out_sp3, res_first)
+            return self._call_split(x, out, act, slope, res, chscale, out_sp3, res_first, epi, mul, in_xform, tail, out_f16)
         half_in = x.dtype == "f16"
         esz = 8 if half_in else 4
         use16 = (self.wpk16 is not None and in_xform == IN_NONE and x.sw % esz == 0 and x.sh % esz == 0 and x.sn % esz == 0

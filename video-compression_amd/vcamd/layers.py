@@ -596,33 +596,130 @@ class MeanScaleHyperprior(_Prepared):
         """(gain, inv_gain, hyper_gain, hyper_inv_gain) device vectors or Nones (Flex overrides)."""
         return None, None, None, None
 
+    @staticmethod
+    def _refinable(last):
+        """a plain k x k convolution (k odd <= 7, stride 1 / 2, padding k // 2) the fp64 refinement kernels can recompute"""
+        return (isinstance(last, nn.Conv2d) and last.kernel_size[0] == last.kernel_size[1] and last.kernel_size[0] % 2 == 1
+                and last.kernel_size[0] <= 7 and last.stride[0] == last.stride[1] and last.stride[0] in (1, 2)
+                and tuple(last.padding) == (last.kernel_size[0] // 2,) * 2 and last.groups == 1 and tuple(last.dilation) == (1, 1)
+                and getattr(last, "mask", None) is None)
+
+    def _run_keeping_last_input(self, name, x, final_chscale=None):
+        """Run transform ``name`` as head + last layer; returns (result, t, last) with ``t`` the last layer's fp32 input -- what the
+        refinement kernels recompute that layer from -- or (result, None, None) when the transform does not end in a plain
+        convolution."""
+        seq = getattr(self, name)
+        cache = self._cache[name]
+        mods = list(seq)
+        last = mods[-1]
+        if len(mods) < 2 or not self._refinable(last):
+            return run_sequential(seq, x, cache, final_chscale=final_chscale), None, None
+        if cache.get("seq") is None:
+            cache["seq"] = {}
+        if "head" not in cache:        # (the parts share the transform's packed weights)
+            cache["head"] = (nn.Sequential(*mods[:-1]), {"seq": cache["seq"]})
+            cache["tail"] = (nn.Sequential(last), {"seq": cache["seq"]})
+        t = run_sequential(cache["head"][0], x, cache["head"][1])
+        if t.dtype != "f32":
+            raise hip.VcError("the refinement kernels read the last layer's input in fp32")
+        return run_sequential(cache["tail"][0], t, cache["tail"][1], final_chscale=final_chscale), t, last
+
+    @staticmethod
+    def _refine_layer(t, conv, c0=0):
+        w = conv.weight.detach()
+        if not w.is_contiguous() or w.dtype != torch.float32:
+            raise hip.VcError("the refinement kernels read the checkpoint's fp32 weights in place")
+        rl = hip.RefineLayer(t.view(), w.data_ptr(), None if conv.bias is None else conv.bias.detach().data_ptr(),
+                             conv.kernel_size[0], conv.stride[0], c0)
+        rl.keep = (t, w)       # the record holds raw pointers: the input tensor must outlive it (its block would be re-used otherwise)
+        return rl
+
     def _hs_for_bitstream(self, z_hat):
         """Hyper-synthesis for the BITSTREAM paths (compress / decompress): the scales whose table index could go either way -- within
         hip.SCALE_REFINE_EPS of a table entry -- are recomputed in fp64 from the last layer's input (vc_refine_scales), so this
-        side's indexes do not depend on its fp32 summation order.  Encoder and decoder call the same function: identical indexes."""
-        mods = list(self.h_s)
-        last = mods[-1]
-        if not (hip.SCALE_REFINE and isinstance(last, nn.Conv2d) and tuple(last.kernel_size) == (3, 3) and tuple(last.stride) == (1, 1)
-                and last.out_channels == 2 * self.M):
-            return run_sequential(self.h_s, z_hat, self._cache["h_s"])
-        head = self._cache["h_s"].get("head")
-        if head is None:
-            head = self._cache["h_s"]["head"] = nn.Sequential(*mods[:-1])
-        t = run_sequential(head, z_hat, self._cache["h_s"])
-        if t.dtype != "f32":
-            raise hip.VcError("scale refinement reads the last hyper-synthesis layer's input in fp32")
-        tail = self._cache["h_s"].get("tail")
-        if tail is None:
-            tail = self._cache["h_s"]["tail"] = nn.Sequential(last)
-        gp = run_sequential(tail, t, self._cache["h_s"])
+        side's indexes do not depend on its fp32 summation order.  Encoder and decoder call the same function: identical indexes.
+        Returns (gaussian parameters, mu_layer): mu_layer = the vc_refine_layer of the MEANS half, for the encoder's symbol
+        refinement (None when the transform does not end in a plain convolution)."""
+        last = list(self.h_s)[-1]
+        if not (isinstance(last, nn.Conv2d) and last.out_channels == 2 * self.M):
+            with hip.fp32_mode_pinned(hip.BITSTREAM_HS_MODE):
+                return run_sequential(self.h_s, z_hat, self._cache["h_s"]), None
+        with hip.fp32_mode_pinned(hip.BITSTREAM_HS_MODE):         # (one pipeline for every stream: see hip.BITSTREAM_HS_MODE)
+            gp, t, last = self._run_keeping_last_input("h_s", z_hat)
+        if t is None:
+            return gp, None
+        if hip.SCALE_REFINE and last.kernel_size[0] == 3 and last.stride[0] == 1:
+            table = self._scale_table_dev()
+            hip.check(hip.lib().vc_refine_scales(hip.stream(), gp.channels(0, self.M).view(), t.view(), last.weight.detach().data_ptr(),
+                                                 None if last.bias is None else last.bias.detach().data_ptr(), table.data_ptr(), table.numel(),
+                                                 hip.SCALE_REFINE_EPS, None), "vc_refine_scales")
+        return gp, self._refine_layer(t, last, self.M)
+
+    def _analysis_for_bitstream(self, x, gains, code_ungained_y):
+        """g_a and h_a of the encoder's bitstream paths.  Returns (y, y_raw, z, y_layer, z_layer): ``y`` feeds h_a (gained when a gain is
+        set), ``y_raw`` (or None) is the un-gained latent Flex-Rate's compress() codes (b_model/layers.py:167), ``y_layer`` /
+        ``z_layer`` the vc_refine_layer records of the two transforms' last convolutions (None = no symbol refinement)."""
+        g = gains[0]
+        L = hip.lib()
+        refine = hip.SYMBOL_REFINE
+        y_layer = z_layer = None
+        if g is not None and code_ungained_y:
+            if refine:
+                y_raw, t, last = self._run_keeping_last_input("g_a", x)
+                y_layer = None if t is None else self._refine_layer(t, last)
+            else:
+                y_raw = run_sequential(self.g_a, x, self._cache["g_a"])
+            y = T.empty(y_raw.n, y_raw.h, y_raw.w, y_raw.c, x.buf.device)
+            # scaled_y = gain * y  (Gain_Module.forward) -- needed by h_a; the un-gained y is what gets coded
+            hip.check(L.vc_channel_scale(hip.stream(), y_raw.view(), g.data_ptr(), y.view()), "vc_channel_scale")
+        else:
+            y_raw = None
+            if refine and g is None:
+                y, t, last = self._run_keeping_last_input("g_a", x)
+                y_layer = None if t is None else self._refine_layer(t, last)
+            else:                              # (a gained latent that is itself coded: not a reference path -- plain rounding)
+                y = run_sequential(self.g_a, x, self._cache["g_a"], final_chscale=g)
+        if refine:
+            z, t, last = self._run_keeping_last_input("h_a", y)
+            z_layer = None if t is None else self._refine_layer(t, last)
+        else:
+            z = run_sequential(self.h_a, y, self._cache["h_a"])
+        return y, y_raw, z, y_layer, z_layer
+
+    def _quantise_for_bitstream(self, y, y_raw, z, y_layer, z_layer, gains, want_y_hat, counters=None):
+        """Hyper-latent symbols -> z_hat -> (scales, means) -> latent symbols and scale-table indexes, with the boundary cases of both
+        roundings decided in fp64 (hip.SYMBOL_REFINE).  Returns (z_sym [n, count], y_sym, y_idx, y_hat or None, (hz, wz)); device
+        int32 tensors.  ``counters``: an int32 device tensor [2] that receives the number of refined (y, z) elements."""
+        g, ig, hg, hig = gains
+        L = hip.lib()
+        dev = y.buf.device
+        z_hat = T.empty(z.n, z.h, z.w, z.c, dev)
+        z_sym = torch.empty((z.n, z.c * z.h * z.w), dtype=torch.int32, device=dev)
+        eb = self.entropy_bottleneck.device_params()
+        hip.check(L.vc_eb_forward(hip.stream(), z.view(), eb.data_ptr(), None if hg is None else hg.data_ptr(),
+                                  None if hig is None else hig.data_ptr(), z_hat.view(), z_sym.data_ptr(), None, 0, None), "vc_eb_forward")
+        if z_layer is not None:
+            hip.check(L.vc_refine_z_symbols(hip.stream(), z.view(), z_layer, eb.data_ptr(), None if hg is None else hg.data_ptr(),
+                                            hip.SYMBOL_REFINE_EPS, z_sym.data_ptr(), z_hat.view(), None if hig is None else hig.data_ptr(),
+                                            None if counters is None else counters.data_ptr() + 4), "vc_refine_z_symbols")
+        gp, mu_layer = self._hs_for_bitstream(z_hat)
+        m = self.M
+        scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
+        y_hat = T.empty(y.n, y.h, y.w, y.c, dev) if want_y_hat else None
+        y_sym = torch.empty((y.n, y.c * y.h * y.w), dtype=torch.int32, device=dev)
+        y_idx = torch.empty_like(y_sym)
         table = self._scale_table_dev()
-        w = last.weight.detach()
-        if not w.is_contiguous():
-            w = w.contiguous()
-        hip.check(hip.lib().vc_refine_scales(hip.stream(), gp.channels(0, self.M).view(), t.view(), w.data_ptr(),
-                                             None if last.bias is None else last.bias.detach().data_ptr(), table.data_ptr(), table.numel(),
-                                             hip.SCALE_REFINE_EPS, None), "vc_refine_scales")
-        return gp
+        hip.check(L.vc_gc_forward(hip.stream(), y.view(), scales.view(), means.view(), None, None if ig is None else ig.data_ptr(),
+                                  hip.NULL_VIEW if y_hat is None else y_hat.view(), None, 0, None if y_raw is None else y_raw.ptr,
+                                  y_sym.data_ptr(), y_idx.data_ptr(), table.data_ptr(), table.numel(), None), "vc_gc_forward")
+        if y_layer is not None and mu_layer is not None:
+            # (Flex-Rate codes the un-gained latent while y_hat comes from the gained one -- quirk B.6: y_hat is then left alone)
+            fix_hat = y_hat is not None and y_raw is None
+            hip.check(L.vc_refine_y_symbols(hip.stream(), (y if y_raw is None else y_raw).view(), y_layer, means.view(), mu_layer,
+                                            hip.SYMBOL_REFINE_EPS, y_sym.data_ptr(), y_hat.view() if fix_hat else hip.NULL_VIEW,
+                                            None if (ig is None or not fix_hat) else ig.data_ptr(),
+                                            None if counters is None else counters.data_ptr()), "vc_refine_y_symbols")
+        return z_sym, y_sym, y_idx, y_hat, (z.h, z.w)
 
     def forward_t(self, x, bits, gains=(None, None, None, None), likelihoods=None, trace=None):
         """x: T [n,h,w,c_in] -> x_hat T; appends two rows (y then z) PER IMAGE to the BitCounter.
@@ -682,36 +779,17 @@ class MeanScaleHyperprior(_Prepared):
         """Analysis + symbolisation on the GPU, range coding on the host.  Returns (strings, (hz,wz)).
         ``trace``: a dict that receives the integers handed to the range coder ("y_sym", "y_idx", "z_sym": host int32
         arrays [n, count]) -- parity instrumentation."""
-        g, ig, hg, hig = gains
-        L = hip.lib()
-        dev = x.buf.device
-        if g is not None and code_ungained_y:
-            y_raw = run_sequential(self.g_a, x, self._cache["g_a"])
-            y = T.empty(y_raw.n, y_raw.h, y_raw.w, y_raw.c, dev)
-            # scaled_y = gain * y  (Gain_Module.forward) -- needed by h_a; the un-gained y is what gets coded
-            hip.check(L.vc_channel_scale(hip.stream(), y_raw.view(), g.data_ptr(), y.view()), "vc_channel_scale")
-        else:
-            y_raw = None
-            y = run_sequential(self.g_a, x, self._cache["g_a"], final_chscale=g)
-        z = run_sequential(self.h_a, y, self._cache["h_a"])
-        z_hat = T.empty(z.n, z.h, z.w, z.c, dev)
-        z_sym = torch.empty(z.n * z.c * z.h * z.w, dtype=torch.int32, device=dev)
-        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
-                                  None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
-                                  z_hat.view(), z_sym.data_ptr(), None, 0, None), "vc_eb_forward")
-        gp = self._hs_for_bitstream(z_hat)
-        m = self.M
-        scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
-        y_sym = torch.empty(y.n * y.c * y.h * y.w, dtype=torch.int32, device=dev)
-        y_idx = torch.empty_like(y_sym)
-        table = self._scale_table_dev()
-        hip.check(L.vc_gc_forward(hip.stream(), y.view(), scales.view(), means.view(), None, None, hip.NULL_VIEW,
-                                  None, 0, None if y_raw is None else y_raw.ptr, y_sym.data_ptr(), y_idx.data_ptr(),
-                                  table.data_ptr(), table.numel(), None), "vc_gc_forward")
+        y, y_raw, z, y_layer, z_layer = self._analysis_for_bitstream(x, gains, code_ungained_y)
+        counters = None
+        if trace is not None:
+            counters = torch.zeros(2, dtype=torch.int32, device=x.buf.device)
+        z_sym, y_sym, y_idx, _, _ = self._quantise_for_bitstream(y, y_raw, z, y_layer, z_layer, gains, False, counters)
+        if trace is not None:
+            trace["refined"] = tuple(int(v) for v in counters.cpu())      # (y, z) elements decided in fp64
         # single D2H of the integer symbols, then the serial coder on the host
-        z_sym_h = z_sym.cpu().numpy().reshape(z.n, -1)
-        y_sym_h = y_sym.cpu().numpy().reshape(y.n, -1)
-        y_idx_h = y_idx.cpu().numpy().reshape(y.n, -1)
+        z_sym_h = z_sym.cpu().numpy()
+        y_sym_h = y_sym.cpu().numpy()
+        y_idx_h = y_idx.cpu().numpy()
         if trace is not None:
             trace.update({"y_sym": y_sym_h, "y_idx": y_idx_h, "z_sym": z_sym_h})
         eb_cdf, eb_len, eb_off = self.entropy_bottleneck.tables()
@@ -727,32 +805,8 @@ class MeanScaleHyperprior(_Prepared):
         will rebuild from the coded integers) and the integers themselves, left on the device for an asynchronous copy:
         returns (x_hat T, {"y_sym", "y_idx", "z_sym": int32 [n, count], "shape": (hz, wz)}).  Equivalent to
         forward_t + compress_t without running g_a / h_a / h_s twice."""
-        g, ig, hg, hig = gains
-        L = hip.lib()
-        dev = x.buf.device
-        if g is not None and code_ungained_y:
-            y_raw = run_sequential(self.g_a, x, self._cache["g_a"])
-            y = T.empty(y_raw.n, y_raw.h, y_raw.w, y_raw.c, dev)
-            hip.check(L.vc_channel_scale(hip.stream(), y_raw.view(), g.data_ptr(), y.view()), "vc_channel_scale")
-        else:
-            y_raw = None
-            y = run_sequential(self.g_a, x, self._cache["g_a"], final_chscale=g)
-        z = run_sequential(self.h_a, y, self._cache["h_a"])
-        z_hat = T.empty(z.n, z.h, z.w, z.c, dev)
-        z_sym = torch.empty((z.n, z.c * z.h * z.w), dtype=torch.int32, device=dev)
-        hip.check(L.vc_eb_forward(hip.stream(), z.view(), self.entropy_bottleneck.device_params().data_ptr(),
-                                  None if hg is None else hg.data_ptr(), None if hig is None else hig.data_ptr(),
-                                  z_hat.view(), z_sym.data_ptr(), None, 0, None), "vc_eb_forward")
-        gp = self._hs_for_bitstream(z_hat)
-        m = self.M
-        scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
-        y_hat = T.empty(y.n, y.h, y.w, y.c, dev)
-        y_sym = torch.empty((y.n, y.c * y.h * y.w), dtype=torch.int32, device=dev)
-        y_idx = torch.empty_like(y_sym)
-        table = self._scale_table_dev()
-        hip.check(L.vc_gc_forward(hip.stream(), y.view(), scales.view(), means.view(), None, None if ig is None else ig.data_ptr(),
-                                  y_hat.view(), None, 0, None if y_raw is None else y_raw.ptr, y_sym.data_ptr(), y_idx.data_ptr(),
-                                  table.data_ptr(), table.numel(), None), "vc_gc_forward")
+        y, y_raw, z, y_layer, z_layer = self._analysis_for_bitstream(x, gains, code_ungained_y)
+        z_sym, y_sym, y_idx, y_hat, _ = self._quantise_for_bitstream(y, y_raw, z, y_layer, z_layer, gains, True)
         x_hat = run_sequential(self.g_s, y_hat, self._cache["g_s"])
         return x_hat, {"y_sym": y_sym, "y_idx": y_idx, "z_sym": z_sym, "shape": (z.h, z.w)}
 
@@ -766,7 +820,7 @@ class MeanScaleHyperprior(_Prepared):
         z_hat = T.empty(n, hz, wz, self.N, device)
         hip.check(L.vc_eb_dequant(hip.stream(), z_sym_d.data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
                                   None if hig is None else hig.data_ptr(), z_hat.view()), "vc_eb_dequant")
-        gp = self._hs_for_bitstream(z_hat)
+        gp, _ = self._hs_for_bitstream(z_hat)
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
         idx_d = torch.empty((n, m * gp.h * gp.w), dtype=torch.int32, device=device)
@@ -803,7 +857,7 @@ class MeanScaleHyperprior(_Prepared):
         z_hat = T.empty(n, hz, wz, c, device)
         hip.check(L.vc_eb_dequant(hip.stream(), z_sym_d.data_ptr(), self.entropy_bottleneck.device_params().data_ptr(),
                                   None if hig is None else hig.data_ptr(), z_hat.view()), "vc_eb_dequant")
-        gp = self._hs_for_bitstream(z_hat)
+        gp, _ = self._hs_for_bitstream(z_hat)
         m = self.M
         scales, means = gp.channels(0, m), gp.channels(m, 2 * m)
         idx_d = torch.empty(n * m * gp.h * gp.w, dtype=torch.int32, device=device)
