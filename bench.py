@@ -38,7 +38,22 @@ sys.path.insert(0, os.path.join(ROOT, "video-compression_amd"))
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # BF16/FP16 matrix peak, dense
 PEAK_HBM_GBPS = 8000.0           # HBM3E peak (same guide)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05", "traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06", "traffic.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r06", "b_pmc_split.json")     # SQ counters of the split kernels (tools/profile_split_r06.sh)
+PMC_KEYS = {"conv k7 s1 32->64 @4x1088x1920": "k7_32_64", "conv k7 s1 64->32 @4x1088x1920": "k7_64_32",
+            "conv k3 s1 128->128 @1x544x960": "k3_128_128", "conv k7 s1 32->16 @4x1088x1920": "k7_32_16"}
+
+
+def fp32_algorithmic_bytes(key):
+    """SURVEY.md 8(d)'s count for a convolution launch named "conv k<K> s<S> <cin>-><cout> @<n>x<h>x<w>": every operand once as fp32
+    NHWC -- input, output, weights (4 bytes per element) -- whatever format the tensors have in HBM on the pipeline that ran."""
+    import re
+    m = re.match(r"conv k(\d+)(?:\+k1)? s(\d+) (\d+)->(\d+) @(\d+)x(\d+)x(\d+)", key)
+    if not m:
+        return None
+    k, st, cin, cout, n, h, w = (int(v) for v in m.groups())
+    ho, wo = (h + 2 * (k // 2) - k) // st + 1, (w + 2 * (k // 2) - k) // st + 1
+    return 4.0 * (n * h * w * cin + n * ho * wo * cout + cout * cin * k * k)
 
 
 def kernel_source_stamp():
@@ -145,6 +160,45 @@ def rd_checksum(rows, frames_limit=None):
 def strong_frames_per_sequence(seconds_per_step, world, sequences):
     per_seq = 17.0 * world * seconds_per_step / sequences
     return 8 * max(1, int(round((per_seq - 1) / 8))) + 1
+
+
+def strong_hbm_plan(args, dev, world, rank, H, W, G, frames_per_sequence, head_pool_gb, limit=0.85):
+    """Will the strong block fit?  need = this rank's resident frames (uint8) + one graph pool per captured pass size, each
+    ``head_pool_gb`` (the headline's pool for G GOPs) x GOPs of the pass / G; budget = ``limit`` x device memory - what the process
+    already holds.  Returns the (possibly shrunk) sizing and what was done: "none", "whole_passes" (frames per sequence cut so that
+    this rank's GOP count is a multiple of G: one graph size instead of two) or "eager" (no graphs at all)."""
+    from vcamd import gop as vgop
+    total_gb = torch.cuda.get_device_properties(dev).total_memory / 2 ** 30
+    held_gb = torch.cuda.memory_reserved(dev) / 2 ** 30
+    budget_gb = limit * total_gb - held_gb
+
+    def need(fps):
+        plan = vgop.workload_plan([fps] * args.sequences)
+        lo, hi = vgop.shard_gops(len(plan), world, rank)
+        n = hi - lo
+        frames = len({(v, i) for v, _, idxs in plan[lo:hi] for i in idxs})
+        sizes = {min(G, n), n % G} - {0}
+        return frames * H * W * 3 / 2 ** 30 + (0.0 if args.no_graph else head_pool_gb * sum(sizes) / G), sorted(sizes)
+    out = {"device_gb": round(total_gb, 1), "held_before_gb": round(held_gb, 1), "limit": limit, "budget_gb": round(budget_gb, 1),
+           "frames_per_sequence": frames_per_sequence, "action": "none"}
+    est, sizes = need(frames_per_sequence)
+    out.update({"estimated_gb": round(est, 1), "pass_sizes_gops": sizes})
+    if est <= budget_gb:
+        return out
+    fps = frames_per_sequence
+    while fps > 9:                         # shorter sequences until this rank codes whole passes only
+        fps -= 8
+        e2, s2 = need(fps)
+        if len(s2) == 1 and e2 <= budget_gb:
+            out.update({"frames_per_sequence": fps, "action": "whole_passes", "estimated_gb": round(e2, 1), "pass_sizes_gops": s2,
+                        "message": f"estimated pool {est:.0f} GB + {held_gb:.0f} GB held exceeds {100 * limit:.0f} % of {total_gb:.0f} GB: "
+                                   f"sequences cut from {frames_per_sequence} to {fps} frames (whole passes of {G} GOPs only, {e2:.0f} GB)"})
+            return out
+    frames_gb = need(frames_per_sequence)[0] - (0.0 if args.no_graph else head_pool_gb * sum(sizes) / G)
+    out.update({"action": "eager", "estimated_gb": round(frames_gb, 1),
+                "message": f"estimated pool {est:.0f} GB + {held_gb:.0f} GB held exceeds {100 * limit:.0f} % of {total_gb:.0f} GB even with one "
+                           f"graph size: the block runs on eager launches (no graph pool; frames/s of the block is launch-bound)"})
+    return out
 
 
 class StrongWorkload:
@@ -537,7 +591,19 @@ def main():
         torch.cuda.reset_peak_memory_stats(dev)
         fps_n = strong_frames_per_sequence(args.strong_seconds, world, args.sequences)
         fps_1 = strong_frames_per_sequence(args.strong_seconds, 1, args.sequences)
+        # ---- HBM headroom (round 6): the block's pool is estimated BEFORE anything is allocated -- the resident 8-bit frames plus one
+        # graph pool per pass size, each like the headline's (measured above) scaled by its GOP count -- and the block is shrunk until
+        # the device stays below 85 % of its memory: first to whole passes only (one graph size), then to eager launches (no graph
+        # pool).  What was done is printed and recorded in the line. ----
+        hbm_guard = strong_hbm_plan(args, dev, world, rank, H, W, G, fps_n, head_pool_gb=result["peak_hbm_gb"])
+        if hbm_guard["action"] != "none":
+            print(f"[bench] strong block: {hbm_guard['message']}", file=sys.stderr, flush=True)
+        fps_n = hbm_guard["frames_per_sequence"]
+        fps_1 = min(fps_1, fps_n)
+        keep_graph = args.no_graph
+        args.no_graph = args.no_graph or hbm_guard["action"] == "eager"
         sw = StrongWorkload(args, model, dev, world, rank, H, W, G, fps_n)
+        args.no_graph = keep_graph
         sw.capture()
         s_records = []
         with torch.no_grad():
@@ -577,6 +643,7 @@ def main():
                                        what="records of the frames every world size codes (the N = 1 sizing of the set): equal across N"),
         }
         result["strong"]["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1)   # test set + graphs of this block
+        result["strong"]["hbm_guard"] = hbm_guard
         sw.release()
         del sw
         torch.cuda.empty_cache()          # (the test set and its graphs: ~100 GB of cached blocks nothing below needs)
@@ -687,7 +754,24 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
                                "share_of_conv_time": dom["ms"] / total_ms,
                                "algorithmic_flop_per_launch": per_launch_flop,
                                "algorithmic_bytes_per_launch": per_launch_bytes,
+                               "algorithmic_bytes_fp32": fp32_algorithmic_bytes(key),
+                               "algorithmic_bytes_note": "algorithmic_bytes_per_launch counts the formats the tensors have in HBM on the pipeline "
+                                                         "that ran (split tensors: 6 bytes per element); algorithmic_bytes_fp32 is SURVEY 8(d)'s "
+                                                         "count, 4 bytes per element, input + output + weights",
                                "flop_per_byte": intensity})
+    # executed matrix instructions per launch from the committed SQ counters: nine v_mfma_f32_16x16x32_bf16 (16 384 FLOP each) per exact
+    # fp32 block -- the count shows that no piece product is dropped
+    try:
+        with open(PMC_JSON) as f:
+            pk = json.load(f)["kernels"].get(PMC_KEYS.get(key, ""))
+        if pk and dom_split:
+            insts = pk["SQ_INSTS_MFMA"]
+            result["roofline"].update({"mfma_insts": insts, "mfma_flop_executed": insts * 16384.0,
+                                       "mfma_flop_executed_over_9x_algorithmic": insts * 16384.0 / (9.0 * per_launch_flop),
+                                       "mfma_busy_fraction": pk.get("mfma_busy_fraction"),
+                                       "mfma_insts_source": f"{os.path.relpath(PMC_JSON, ROOT)} (rocprofv3 --pmc SQ_INSTS_MFMA, per launch)"})
+    except (OSError, KeyError, ValueError):
+        pass
     # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected
     # in separate runs and corrected as tools/pmc_traffic.py documents).  The file is stamped with a hash of the kernel
     # sources it was measured on: a stale one is refused rather than quoted.
@@ -704,6 +788,8 @@ def single_gpu_extras(args, result, model, frames, sd, dev, H, W):
             if tr:
                 result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 result["roofline"]["traffic_over_algorithmic"] = tr["hbm_bytes_per_launch"] / per_launch_bytes
+                if fp32_algorithmic_bytes(key):
+                    result["roofline"]["traffic_over_algorithmic_fp32"] = tr["hbm_bytes_per_launch"] / fp32_algorithmic_bytes(key)
                 result["roofline"]["traffic_source"] = f"{os.path.relpath(TRAFFIC_JSON, ROOT)} (rocprofv3 --pmc, separate passes)"
             # the two dominant 7x7 kernels take turns at the top of the table: always show the worse traffic ratio of the pair
             pair = {k: v for k, v in tj["kernels"].items() if k.startswith("conv k7 s1") and k in table}

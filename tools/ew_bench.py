@@ -54,6 +54,7 @@ def main():
         f2.buf.uniform_()
         fc = hip.T.empty(n, h // 2, w // 2, 2, dev)
         fc.buf.normal_()
+        fc.buf.mul_(0.25)                   # (displacements of a fraction of a pixel after the x2: the gathers stay near the diagonal, as in the model)
         feat = hip.T.empty(n, h, w, 8, dev, "sp3")
         up = hip.T.empty(n, h, w, 2, dev)
         mb = n * h * w * (4.0 * (3 + 3 + 0.5 + 2) + 48.0) / 1e6

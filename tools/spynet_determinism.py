@@ -141,6 +141,18 @@ def main():
         if bad:
             print(f"run {r}: first stages that differ: {bad[:4]}", flush=True)
             for k, _ in bad[:3]:
+                if k.endswith("level input (split)"):
+                    size = [q for q in ref if q.startswith(k.split()[0] + " ") and q.endswith("pyramid")][0].split()[1]
+                    hh, ww = (int(v) for v in size.split("x"))
+                    c_, r_ = cur[k].view(torch.int16).reshape(n, hh, ww, 3, 8).cpu(), ref[k].view(torch.int16).reshape(n, hh, ww, 3, 8).cpu()
+                    d_ = c_ != r_
+                    px = torch.nonzero(d_.any(-1).any(-1))
+                    lanes = sorted(set((px[:, 2] % 64).tolist()))
+                    chans = sorted(set(torch.nonzero(d_.any(0).any(0).any(0).any(0)).reshape(-1).tolist()))
+                    pieces = sorted(set(torch.nonzero(d_.any(0).any(0).any(0).any(-1)).reshape(-1).tolist()))
+                    print(f"    {k}: {px.shape[0]} wrong pixels; x % 64 in {lanes[:4]}..{lanes[-4:]} ({len(lanes)} distinct); x % 256 // 64 = "
+                          f"{sorted(set(((px[:, 2] % 256) // 64).tolist()))}; channels {chans}; pieces {pieces}; images {sorted(set(px[:, 0].tolist()))}; "
+                          f"rows {sorted(set(px[:, 1].tolist()))[:8]}", flush=True)
                 if k.endswith(" up"):
                     size = [q for q in ref if q.startswith(k.split()[0] + " ") and q.endswith("pyramid")][0].split()[1]
                     describe(k, cur[k], ref[k], n, *(int(v) for v in size.split("x")))

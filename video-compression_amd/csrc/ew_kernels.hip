@@ -864,6 +864,82 @@ template <bool VEC, bool SP3 = false> __global__ void k_spynet_level_input(vc_vi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 6 form of the level input (split record output): same values as k_spynet_level_input<true, true> up to fp32 contraction,
+//   * work items are (image, row, strip of EW_BLOCK pixels), walked grid-stride by whole workgroups: the row / image of an item come
+//     out of two SCALAR divisions per workgroup-iteration (no per-lane 64-bit index division), lanes are consecutive pixels of a row;
+//   * each bilinear corner of the warped frame is ONE 12-byte load (three channels) instead of three 4-byte loads, the first frame's
+//     pixel likewise: 9 gathers per pixel instead of 19;
+//   * the row's records leave through LDS as whole lines (vc_store_records_256);
+//   * the two flow components are interpolated in separate dependency chains behind opaque barriers (the un-paired forms of the
+//     3-D-grid diagnostic kernels never failed: DESIGN section 5f).
+// Opt-in only (VC_LI_FORM=rows): two processes on one device still bring out wrong lanes 48-63 in it -- see the launch site.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) vc_f3 { float a, b, c; };
+__global__ void __launch_bounds__(EW_BLOCK) k_spynet_level_input_rows(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up, int strips)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char sm[VC_RECORDS_LDS(1)];
+    const int items = feat.n * feat.h * strips;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int strip = item % strips, row = item / strips;
+        int y = row % feat.h;
+        const int n = row / feat.h;
+        const int x_run = strip * EW_BLOCK, x = x_run + (int)threadIdx.x;
+        vc_u32x4 ph = {0, 0, 0, 0}, pm = ph, pl = ph;
+        if (x < feat.w) {
+            float u = 0.0f, v = 0.0f;
+            if (fc.p) {
+                const int uh = 2 * fc.h, uw = 2 * fc.w;
+                const int yy = y < uh ? y : uh - 1, xx = x < uw ? x : uw - 1;
+                int y0, y1, x0, x1;
+                float ly0, ly1, lx0, lx1;
+                bilinear_src(yy, fc.h, uh, 2, 1, y0, y1, ly0, ly1);
+                bilinear_src(xx, fc.w, uw, 2, 1, x0, x1, lx0, lx1);
+                const float *b = fc.p + (long long)n * fc.sn;
+                const float *p00 = b + (long long)y0 * fc.sh + (long long)x0 * fc.sw, *p01 = b + (long long)y0 * fc.sh + (long long)x1 * fc.sw;
+                const float *p10 = b + (long long)y1 * fc.sh + (long long)x0 * fc.sw, *p11 = b + (long long)y1 * fc.sh + (long long)x1 * fc.sw;
+                float a0 = p00[0], a1 = p01[0], a2 = p10[0], a3 = p11[0], b0 = p00[1], b1 = p01[1], b2 = p10[1], b3 = p11[1];
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+                u = (ly0 * (lx0 * a0 + lx1 * a1) + ly1 * (lx0 * a2 + lx1 * a3)) * 2.0f;
+                asm volatile("" : "+v"(u), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+                v = (ly0 * (lx0 * b0 + lx1 * b1) + ly1 * (lx0 * b2 + lx1 * b3)) * 2.0f;
+                asm volatile("" : "+v"(v));
+            }
+            const float gx = grid_coord(VC_WARP_W1, x, u, feat.w, second.w);
+            const float gy = grid_coord(VC_WARP_W1, y, v, feat.h, second.h);
+            // sample_bilinear(border, align_corners = false) of the three channels, the corner pixels as whole 12-byte loads
+            const int W = second.w, H = second.h;
+            float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+            ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));
+            iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+            const float xw = floorf(ix), yn = floorf(iy);
+            const float w_ = ix - xw, e = 1.0f - w_, nn = iy - yn, s_ = 1.0f - nn;
+            const int sx0 = (int)xw, sy0 = (int)yn, sx1 = sx0 + 1, sy1 = sy0 + 1;
+            const bool x1ok = sx1 < W, y1ok = sy1 < H;            // (after the border clamp x0 / y0 are always inside)
+            const float *s2 = second.p + (long long)n * second.sn;
+            const int cx1 = x1ok ? sx1 : sx0, cy1 = y1ok ? sy1 : sy0;
+            const vc_f3 nw = *reinterpret_cast<const vc_f3 *>(s2 + (long long)sy0 * second.sh + (long long)sx0 * second.sw);
+            vc_f3 ne = *reinterpret_cast<const vc_f3 *>(s2 + (long long)sy0 * second.sh + (long long)cx1 * second.sw);
+            vc_f3 sw = *reinterpret_cast<const vc_f3 *>(s2 + (long long)cy1 * second.sh + (long long)sx0 * second.sw);
+            vc_f3 se = *reinterpret_cast<const vc_f3 *>(s2 + (long long)cy1 * second.sh + (long long)cx1 * second.sw);
+            if (!x1ok) ne = vc_f3{0.0f, 0.0f, 0.0f};
+            if (!y1ok) sw = vc_f3{0.0f, 0.0f, 0.0f};
+            if (!(x1ok && y1ok)) se = vc_f3{0.0f, 0.0f, 0.0f};
+            const float w0 = nw.a * (s_ * e) + ne.a * (s_ * w_) + sw.a * (nn * e) + se.a * (nn * w_);
+            const float w1 = nw.b * (s_ * e) + ne.b * (s_ * w_) + sw.b * (nn * e) + se.b * (nn * w_);
+            const float w2 = nw.c * (s_ * e) + ne.c * (s_ * w_) + sw.c * (nn * e) + se.c * (nn * w_);
+            const vc_f3 f1 = *reinterpret_cast<const vc_f3 *>(first.p + view_off(first, n, y, x));
+            const f32x4 lo = {f1.a, f1.b, f1.c, w0}, hi = {w1, w2, u, v};
+            vc_split_record(lo, hi, ph, pm, pl);
+            const f32x2 uv = {u, v};
+            *reinterpret_cast<f32x2 *>(up.p + view_off(up, n, y, x)) = uv;
+        }
+        vc_store_records_256<1>(sm, threadIdx.x, x < feat.w, ph, pm, pl,
+                                reinterpret_cast<unsigned char *>(feat.p) + (((long long)n * feat.h + y) * feat.w + x_run) * 48, 0, min(EW_BLOCK, feat.w - x_run));
+        __syncthreads();               // (the LDS image is re-used by the next item)
+    }
+}
+
 #ifdef VC_LI_DIAG
 // ------------------------------------------------------------------------------------------------------------------------------
 // Diagnostic build only (make li_diag -> libvc_hip_lidiag.so; tools/li_diag.sh): the 3-D-grid form of the level-input kernel that gave
@@ -1038,6 +1114,19 @@ extern "C" int vc_spynet_level_input_sp3(vc_stream s, vc_view first, vc_view sec
 #ifdef VC_LI_DIAG
     if (li_launch_3d<true>(as_stream(s), first, second, fc, feat, up)) return VC_OK;
 #endif
+    {   // VC_LI_FORM=rows (read once) selects the round-6 row form: 1.7x faster (160 against 278 us at 4 x 1088 x 1920) but NOT the default --
+        // with a second process on the device it shows the lane-48..63 fault of DESIGN section 5f (8-9 of 200 runs, this time in the
+        // warped channels), the grid-stride form over pixels never has (0 of 600)
+        static const bool rows_form = [] { const char *e = getenv("VC_LI_FORM"); return e && e[0] == 'r'; }();
+        const long long items = (long long)feat.n * feat.h * ((feat.w + EW_BLOCK - 1) / EW_BLOCK);
+        if (rows_form && first.sw == 3 && second.sw == 3 && items < (1ll << 30)) {
+            const int strips = (feat.w + EW_BLOCK - 1) / EW_BLOCK;
+            hipLaunchKernelGGL(k_spynet_level_input_rows, dim3((unsigned)(items < 256 * 16 ? items : 256 * 16)), dim3(EW_BLOCK), 0, as_stream(s), first,
+                               second, fc, feat, up, strips);
+            VC_LAUNCH_CHECK();
+            return VC_OK;
+        }
+    }
     hipLaunchKernelGGL((k_spynet_level_input<true, true>), dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), first, second, fc, feat, up);
     VC_LAUNCH_CHECK();
     return VC_OK;
