@@ -1,4 +1,4 @@
-"""The committed rocprofv3 evidence of the headline run (profiles/r05/, collected by tools/profile_r05.sh on the MI355X box:
+"""The committed rocprofv3 evidence of the headline run (profiles/r06/, collected by tools/profile_r06.sh on the MI355X box:
 `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-strong-block --skip-extras --steps 3 --warmup 1`) is parsed
 and held against the bench line printed by the SAME process:
 
@@ -18,13 +18,13 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "profiles", "r05")
+PROF = os.path.join(ROOT, "profiles", "r06")
 STATS = os.path.join(PROF, "a_rocprofv3_kernel_stats.csv")
 TRACE = os.path.join(PROF, "a_kernel_trace_by_grid.json")
 LINE = os.path.join(PROF, "a_headline_under_rocprofv3_line.json")
 
 needs_profile = pytest.mark.skipif(not all(os.path.exists(p) for p in (STATS, TRACE, LINE)),
-                                   reason="profiles/r05 headline trace not collected yet (tools/profile_r05.sh)")
+                                   reason="profiles/r06 headline trace not collected yet (tools/profile_r06.sh)")
 
 
 def bench_line():

@@ -103,8 +103,13 @@ template <int K> static void pack_split_period(const float *w, int cout, int cin
 static bool split_period(int k, int cin, int bn)
 {
     if (bn == 16) return false;      // (7 x 7 32 -> 16 on 24-row tiles: the period instance measured 2.49 ms against 2.42)
-    const char *e = getenv("VC_SPLIT_PADDED"), *e3 = getenv("VC_SPLIT3_PADDED");
-    if ((e && e[0] && e[0] != '0') || (e3 && e3[0] && e3[0] != '0')) return false;
+    // read ONCE per process: the packed buffer carries no layout tag, so packing and every later launch must agree on the choice
+    // whatever happens to the environment in between
+    static const bool padded = [] {
+        const char *e = getenv("VC_SPLIT_PADDED"), *e3 = getenv("VC_SPLIT3_PADDED");
+        return (e && e[0] && e[0] != '0') || (e3 && e3[0] && e3[0] != '0');
+    }();
+    if (padded) return false;
     return (k == 3 && (cin % 32) == 0) || ((k == 5 || k == 7) && (cin % 16) == 0);
 }
 

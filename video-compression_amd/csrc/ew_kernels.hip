@@ -1115,8 +1115,8 @@ extern "C" int vc_spynet_level_input_sp3(vc_stream s, vc_view first, vc_view sec
     if (li_launch_3d<true>(as_stream(s), first, second, fc, feat, up)) return VC_OK;
 #endif
     {   // VC_LI_FORM=rows (read once) selects the round-6 row form: 1.7x faster (160 against 278 us at 4 x 1088 x 1920) but NOT the default --
-        // with a second process on the device it shows the lane-48..63 fault of DESIGN section 5f (8-9 of 200 runs, this time in the
-        // warped channels), the grid-stride form over pixels never has (0 of 600)
+        // with a second process on the device it shows the lane-48..63 fault of DESIGN section 5f (17 of 400 runs, this time in the
+        // warped channels), the grid-stride form over pixels never has (0 of 480)
         static const bool rows_form = [] { const char *e = getenv("VC_LI_FORM"); return e && e[0] == 'r'; }();
         const long long items = (long long)feat.n * feat.h * ((feat.w + EW_BLOCK - 1) / EW_BLOCK);
         if (rows_form && first.sw == 3 && second.sw == 3 && items < (1ll << 30)) {
