@@ -32,6 +32,8 @@ def main():
                     help="fp32 layers on the split-operand pipeline (VC_CFG_SPLIT, csrc/conv_split.h); the input is converted to a split "
                          "tensor ONCE before the timed launches (inside a chain the producing epilogue writes it)")
     ap.add_argument("--residual", action="store_true", help="add an fp32 residual tensor in the epilogue (bottleneck blocks)")
+    ap.add_argument("--residual-split", action="store_true",
+                    help="with --split: add a SPLIT-tensor residual in the epilogue (conv2 of a residual block inside a split chain)")
     ap.add_argument("--residual-half", action="store_true",
                     help="fp16 path with --half-io: add a HALF-precision residual (VC_CFG_RES_F16: the identity of a residual block)")
     ap.add_argument("shapes", nargs="*", default=DEFAULT)
@@ -64,6 +66,9 @@ def main():
         if args.residual_half:
             res = hip.T.empty(n, ho, wo, co, dev, "f16")
             res.buf.normal_()
+        if args.residual_split and args.split and co % 8 == 0:
+            res = hip.T.empty(n, ho, wo, co, dev, "sp3")
+            res.buf.zero_()
         if args.split:
             if not pc.split_ok:
                 print(f"conv k{k} s{s} {cin}->{cout}: no split-operand instance")
@@ -73,7 +78,7 @@ def main():
                 out = hip.T.empty(n, ho, wo, co, dev, "sp3")
         for _ in range(2):
             pc(x, out=out, act=hip.ACT_LRELU, res=res)
-        stamps = hasattr(hip.lib(), "vc_debug_dma_stamps") and os.environ.get("VC_DMA_VARIANT") == "64"
+        stamps = hasattr(hip.lib(), "vc_debug_dma_stamps") and "64" in (os.environ.get("VC_DMA_VARIANT"), os.environ.get("VC_SPLIT_VARIANT"))
         if stamps:          # diagnostic library (make dma_diag): shader-clock totals per segment of the LDS-DMA kernel
             import ctypes
             import numpy as np

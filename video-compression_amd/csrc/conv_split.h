@@ -183,13 +183,137 @@ template <int K_, int NTW_, int CPL_ = 1, int TH_ = 16, int RING_ = 4, int KO_ =
 // 4 consecutive channels per accumulator -> one 16-byte access (or the 3 x 8 bytes of a split record) per (M-tile, N-tile).  Stores of
 // pixels / channels outside the output are simply masked: the counted waits of these kernels count DMA only -- an uncounted younger
 // store makes a wait longer, never shorter.
-template <class C>
-__device__ __forceinline__ void split_epilogue(const ConvArgs &p, f32x4 (&acc)[C::WM][C::WN], const DmaTile &cur, int wave, int px, int q)
+// Round 6: a SPLIT output leaves through LDS as whole records.  The direct form below stores 3 x 8 bytes per lane and accumulator tile
+// at a 48-byte stride -- 24 partial 64-byte lines per wave-instruction, 36 instructions per 12-tile wave: the epilogue was 10.6 % of a
+// 3x3 wave's lifetime (tools/split_stamps.sh) and, both wave groups passing through it one after the other, about twice that of the
+// matrix pipe's idle time.  Here the lanes of a wave stage the pieces of NG N-tiles of one M-tile in a private LDS slice
+// ([plane][pixel][48 bytes]: exactly the record image of 2 NG planes x 16 pixels) and write it back out 16 bytes per lane, contiguous:
+// every global store instruction covers 1 KiB of whole records (the 768 contiguous bytes of a plane's 16 pixels, then the next plane's).
+// `sc`: this wave's slice of a chunk-image buffer nobody reads or fills during the epilogue (the period kernels' Y buffer), >= NG * 1536 bytes.
+// (What is left of the epilogue -- 7 % of a 3x3 wave's lifetime, 4 % of it the CU's vector-memory path taking the tile's 147 KB -- could
+//  only hide behind the NEXT tile's phases; that needs a second accumulator set, and two waves per SIMD leave 256 registers per wave: the
+//  64-channel instances spill 100-190 of them to scratch with it.  Tried and removed)
+template <class C, int NG, int T0 = 0, int T1 = C::WM>
+__device__ __forceinline__ void split_epilogue_records(const ConvArgs &p, f32x4 (&acc)[C::WM][C::WN], const DmaTile &cur, int wave, int px, int q,
+                                                       unsigned char *sc)
+{
+    constexpr int WM = C::WM, WN = C::WN, UNITS = 96 * NG, NJ = (UNITS + 63) / 64, NGRP = (T1 - T0) * (WN / NG);
+    static_assert(WN % NG == 0, "N-tiles are staged in whole groups");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
+    const int lane = px + 16 * q;
+    int u_plane[NJ], u_w16[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int u = 64 * j + lane;
+        u_plane[j] = u / 48;
+        u_w16[j] = u - 48 * u_plane[j];
+    }
+    unsigned char *const outb = reinterpret_cast<unsigned char *>(p.out) + (long long)cur.img * p.out_sn;
+    const unsigned char *const resb = reinterpret_cast<const unsigned char *>(p.res) + (long long)cur.img * p.res_sn;
+    // group g = (M-tile T0 + g / (WN / NG), N-tiles (g % (WN / NG)) * NG ..): its 2 NG planes x 16 pixels of records, unit u of lane
+    auto unit_ok = [&](int g, int j, int &oy, int &oxb, int &plane0) {
+        const int t = T0 + g / (WN / NG), n0 = (g % (WN / NG)) * NG, m = WM * wave + t;
+        oy = cur.oy0 + (m >> 1);
+        oxb = cur.ox0 + 16 * (m & 1);
+        plane0 = (cur.nblk * C::BN + 16 * n0) >> 3;
+        return (64 * j + lane < UNITS) && oy < p.Ho && (oxb + u_w16[j] / 3 < p.Wo);
+    };
+    // A SPLIT residual (the identity of a residual block inside a split chain) is read the same way: whole records, 16 bytes per lane,
+    // one group ahead of its use (the direct form: 3 x 8 bytes per lane and accumulator tile, as scattered as the stores were -- with it
+    // the epilogue was 16 % of a 3x3 wave's lifetime, 7 % without a residual)
+    vc_u32x4 rnext[NJ];
+    auto fetch_res = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int oy, oxb, plane0;
+            const bool ok = unit_ok(g, j, oy, oxb, plane0);
+            rnext[j] = vc_u32x4{0u, 0u, 0u, 0u};
+            if (ok) rnext[j] = *reinterpret_cast<const vc_u32x4 *>(resb + ((((long long)(plane0 + u_plane[j])) * p.Ho + oy) * p.Wo + oxb) * 48 + u_w16[j] * 16);
+        }
+    };
+    if (p.res_sp3) fetch_res(0);
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g) {
+        const int t = T0 + g / (WN / NG), n0 = (g % (WN / NG)) * NG;
+        const int m = WM * wave + t;
+        const int oy = cur.oy0 + (m >> 1), oxb = cur.ox0 + 16 * (m & 1), ox = oxb + px;
+        const bool row_ok = oy < p.Ho, pix_ok = row_ok && ox < p.Wo;
+        if (p.res_sp3) {
+            // this group's residual records into the staging area, the next group's on their way
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (64 * j + lane < UNITS) *reinterpret_cast<vc_u32x4 *>(sc + u_plane[j] * 768 + u_w16[j] * 16) = rnext[j];
+            if (g + 1 < NGRP) fetch_res(g + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int nn = 0; nn < NG; ++nn) {
+            const int n = n0 + nn;
+            const int co = cur.nblk * C::BN + 16 * n + 4 * q;
+            unsigned char *rec = sc + ((2 * nn + (q >> 1)) * 16 + px) * 48 + 8 * (q & 1);
+            f32x4 v = acc[t][n];
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (p.res_sp3) {
+                r = vc_load_split4(rec - 8 * (q & 1), q & 1);         // (pixels outside the output: zero records were staged)
+            } else if (p.res) {
+                if (pix_ok) r = *reinterpret_cast<const f32x4 *>(p.res + (long long)cur.img * p.res_sn + (long long)oy * p.res_sh + (long long)ox * p.res_sw + co);
+            }
+            if (p.res_first) v += r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : v[e] * neg;
+            if (p.chscale) v *= *reinterpret_cast<const f32x4 *>(p.chscale + co);
+            if (p.res && !p.res_first) v += r;
+            unsigned h[4], mm[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vc_split3(v[e], h[e], mm[e], l[e]);
+            const u32x2 ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+            const u32x2 pm = {(mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3]};
+            const u32x2 pl = {(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+            if constexpr (C::KO & 256) {          // (diagnostic: arithmetic only)
+                VC_DMA_KEEP(ph); VC_DMA_KEEP(pm); VC_DMA_KEEP(pl);
+            } else {
+                // (each lane overwrites exactly the 3 x 8 bytes it has just read its residual from)
+                *reinterpret_cast<u32x2 *>(rec) = ph;
+                *reinterpret_cast<u32x2 *>(rec + 16) = pm;
+                *reinterpret_cast<u32x2 *>(rec + 32) = pl;
+            }
+        }
+        if constexpr (C::KO & 256) continue;
+        // (LDS operations of one wave execute in order: the reads below see every lane's writes above; the compiler must keep the order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int plane0 = (cur.nblk * C::BN + 16 * n0) >> 3;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool ok = (64 * j + lane < UNITS) && row_ok && (oxb + u_w16[j] / 3 < p.Wo);
+            if (ok) {
+                const vc_u32x4 val = *reinterpret_cast<const vc_u32x4 *>(sc + u_plane[j] * 768 + u_w16[j] * 16);
+                if constexpr (C::KO & 128) VC_DMA_KEEP(val);      // (diagnostic: no global stores)
+                else *reinterpret_cast<vc_u32x4 *>(outb + ((((long long)(plane0 + u_plane[j])) * p.Ho + oy) * p.Wo + oxb) * 48 + u_w16[j] * 16) = val;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the staging area is re-used by the next group)
+    }
+}
+
+// M-tiles T0 .. T1 - 1 of the wave.  SC_NG: N-tiles the record staging area `sc` holds (0: sized from the chunk-image buffer the full
+// epilogue borrows; 1: the small per-wave area of the deferred epilogue)
+template <class C, int T0 = 0, int T1 = C::WM, int SC_NG = 0>
+__device__ __forceinline__ void split_epilogue(const ConvArgs &p, f32x4 (&acc)[C::WM][C::WN], const DmaTile &cur, int wave, int px, int q,
+                                               unsigned char *sc = nullptr)
 {
     constexpr int WM = C::WM, WN = C::WN;
+    if constexpr (SC_NG > 0 || (C::A_BYTES / 8 >= 3072 && WN % 2 == 0)) {
+        // whole-record stores of a split output (plain layout; the pixel-shuffle store keeps the direct form)
+        if (sc && p.out_sp3 && p.out_mode == VC_OUT_PLAIN) {
+            constexpr int NG = SC_NG > 0 ? SC_NG : ((C::A_BYTES / 8 >= WN * 1536) ? WN : 2);
+            split_epilogue_records<C, NG, T0, T1>(p, acc, cur, wave, px, q, sc);
+            return;
+        }
+    }
     const float neg = (p.act == VC_ACT_NONE) ? 1.0f : (p.act == VC_ACT_RELU ? 0.0f : p.slope);
 #pragma unroll
-    for (int t = 0; t < WM; ++t) {
+    for (int t = T0; t < T1; ++t) {
         const int m = WM * wave + t;
         const int oy = cur.oy0 + (m >> 1), ox = cur.ox0 + 16 * (m & 1) + px;
         const bool pix_ok = oy < p.Ho && ox < p.Wo;
@@ -612,6 +736,10 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_period_k
     }
     const int b_lane = C::B_OFF + lane * 16;
 
+#ifdef VC_DMA_DIAG
+    unsigned st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    VC_DMA_STAMP(t_begin);
     f32x4 acc[WM][WN];
     f32x4 af[3][WM], bf[3][WN];
     for (int it = 0;; ++it) {
@@ -628,6 +756,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_period_k
             const int g0 = pr * U;
             static_for<0, U>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
+                VC_DMA_STAMP(t0);
                 const int bslot = b_lane + (int)((gbase + (unsigned)(g0 + u)) % RING) * C::SLOTB;
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
@@ -636,6 +765,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_period_k
 #pragma unroll
                     for (int t = 0; t < WM; ++t) af[pc][t] = *reinterpret_cast<const f32x4 *>(lds8 + (a_t[t] + a_unit[u]) + 16 * pc);
                 }
+                VC_DMA_STAMP(t1);            // (a stamp waits for lgkmcnt(0): the fragment reads issued AND returned)
                 static_for<0, NA>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (C::piece_phase(1, k) == u) issue_a(cur, cur_base, 2 * pr + 1, k, 1);          // this period's second chunk -> Y
@@ -645,12 +775,15 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_period_k
                     }
                 });
                 issue_b(g0 + u + D, cur.nblk, nxt.nblk);
+                VC_DMA_STAMP(t2);
                 if constexpr (!(C::KO & 2)) {
                     if constexpr (C::nwait(u, 0) == C::nwait(u, 1)) vc_wait_vmcnt<C::nwait(u, 0)>();
                     else if (grp == 0) vc_wait_vmcnt<C::nwait(u, 0)>();
                     else vc_wait_vmcnt<C::nwait(u, 1)>();
                 }
+                VC_DMA_STAMP(t3);
                 VC_DMA_BARRIER();
+                VC_DMA_STAMP(t4);
                 if constexpr (!(C::KO & 4)) {
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -676,19 +809,33 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_period_k
                         for (int n = 0; n < WN; ++n) VC_DMA_KEEP(bf[pc][n]);
                     }
                 }
+                VC_DMA_STAMP(t5);
                 VC_DMA_BARRIER();
+                VC_DMA_STAMP(t6);
+                VC_DMA_ACC(0, t2, t1);   // DMA issue
+                VC_DMA_ACC(1, t1, t0);   // fragment reads
+                VC_DMA_ACC(2, t3, t2);   // vmcnt wait
+                VC_DMA_ACC(3, t4, t3);   // barrier after R
+                VC_DMA_ACC(4, t5, t4);   // MFMA issue
+                VC_DMA_ACC(5, t6, t5);   // barrier after M
             });
         }
         if (grp == 0) VC_DMA_BARRIER();
         gbase = (gbase + (unsigned)upt) % RING;
+        VC_DMA_STAMP(t_e0);
         if constexpr (!(C::KO & 1)) {
-            split_epilogue<C>(p, acc, cur, wave, px, q);
+            // (scratch of the record stores: this wave's eighth of buffer Y -- last read in the tile's last phase, next filled from
+            //  phase 1 of the next tile on, which no wave reaches before BOTH wave groups have left their epilogues: the group that is
+            //  ahead waits at the barrier of its phase 0 for the other one's start-of-tile barrier)
+            split_epilogue<C>(p, acc, cur, wave, px, q, (C::KO & 32) ? nullptr : lds8 + C::A_BYTES + wave * (C::A_BYTES / 8));
         } else {
 #pragma unroll
             for (int t = 0; t < WM; ++t)
 #pragma unroll
                 for (int n = 0; n < WN; ++n) VC_DMA_KEEP(acc[t][n]);
         }
+        VC_DMA_STAMP(t_e1);
+        VC_DMA_ACC(6, t_e1, t_e0);       // epilogue
         if (!nxt.valid) break;
         cur = nxt;
         cur_base = nxt_base;
@@ -696,6 +843,14 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_split_period_k
         nxt_base = tile_base(nxt);
     }
     vc_wait_vmcnt<0>();
+#ifdef VC_DMA_DIAG
+    if constexpr (C::KO & 64) {
+        VC_DMA_STAMP(t_end);
+        st_sum[7] = t_end - t_begin;                 // wave lifetime
+        if (lane == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_vc_dma_stamps[i], (unsigned long long)st_sum[i]);
+    }
+#endif
 }
 
 template <class C> int launch_conv_split_period(hipStream_t st, const ConvArgs &a)

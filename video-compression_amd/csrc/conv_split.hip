@@ -210,6 +210,17 @@ int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
     {
         const char *e = getenv("VC_SPLIT_VARIANT");
         const int v = e ? atoi(e) : 0;
+#ifdef VC_DMA_DIAG
+        if (k == 3 && split_period(k, a.Cin, bn) && bn == 64) {
+            if (v == 64 + 128) return launch_conv_split_period<SplitPeriodCfg<3, 4, 12, 4, 64 + 128>>(st, a);      // stamps, epilogue without global stores
+            if (v == 64 + 256) return launch_conv_split_period<SplitPeriodCfg<3, 4, 12, 4, 64 + 256>>(st, a);      // stamps, epilogue arithmetic only
+            if (v == 64 + 32) return launch_conv_split_period<SplitPeriodCfg<3, 4, 12, 4, 64 + 32>>(st, a);        // stamps, the direct (8-byte) stores of round 5
+        }
+        if (v == 64 && split_period(k, a.Cin, bn) && bn == 64) {          // cycle stamps per phase segment (make split_diag; tools/conv_bench.py prints them)
+            if (k == 3) return launch_conv_split_period<SplitPeriodCfg<3, 4, 12, 4, 64>>(st, a);
+            if (k == 7) return launch_conv_split_period<SplitPeriodCfg<7, 4, 16, 4, 64>>(st, a);
+        }
+#endif
         if (k == 7 && bn == 64) {
             switch (v) {
             case 1: return launch_conv_split<SplitCfg<7, 4, 1, 16, 4, 1>>(st, a);
@@ -232,3 +243,14 @@ int conv_dispatch_split(hipStream_t st, ConvArgs a, int k, int stride)
     if (k == 3) return bn == 64 ? launch_conv_split<SplitCfg<3, 4, 2, 12>>(st, a) : launch_conv_split<SplitCfg<3, 2, 2, 12>>(st, a);
     return VC_EINVAL;
 }
+
+#if defined(VC_SPLIT_DIAG) && defined(VC_DMA_DIAG)
+extern "C" int vc_debug_dma_stamps(unsigned long long *out8)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return VC_ELAUNCH;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vc_dma_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return VC_ELAUNCH;
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_vc_dma_stamps), zero, sizeof(zero)) != hipSuccess) return VC_ELAUNCH;
+    return VC_OK;
+}
+#endif
