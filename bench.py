@@ -39,7 +39,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # BF16/FP16 matrix peak, dense
 PEAK_HBM_GBPS = 8000.0           # HBM3E peak (same guide)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06", "traffic.json")
-PMC_JSON = os.path.join(ROOT, "profiles", "r06", "b_pmc_split.json")     # SQ counters of the split kernels (tools/profile_split_r06.sh)
+PMC_JSON = os.path.join(ROOT, "profiles", "r06", "b_pmc_split.json")     # SQ counters of the split kernels (tools/r06.sh split-pmc)
 PMC_KEYS = {"conv k7 s1 32->64 @4x1088x1920": "k7_32_64", "conv k7 s1 64->32 @4x1088x1920": "k7_64_32",
             "conv k3 s1 128->128 @1x544x960": "k3_128_128", "conv k7 s1 32->16 @4x1088x1920": "k7_32_16"}
 

@@ -1,4 +1,4 @@
-"""The committed rocprofv3 evidence of the headline run (profiles/r06/, collected by tools/profile_r06.sh on the MI355X box:
+"""The committed rocprofv3 evidence of the headline run (profiles/r06/, collected by tools/r06.sh headline on the MI355X box:
 `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-strong-block --skip-extras --steps 3 --warmup 1`) is parsed
 and held against the bench line printed by the SAME process:
 
@@ -24,7 +24,7 @@ TRACE = os.path.join(PROF, "a_kernel_trace_by_grid.json")
 LINE = os.path.join(PROF, "a_headline_under_rocprofv3_line.json")
 
 needs_profile = pytest.mark.skipif(not all(os.path.exists(p) for p in (STATS, TRACE, LINE)),
-                                   reason="profiles/r06 headline trace not collected yet (tools/profile_r06.sh)")
+                                   reason="profiles/r06 headline trace not collected yet (tools/r06.sh headline)")
 
 
 def bench_line():

@@ -3,7 +3,7 @@
 Production is one process per GPU, but rocprofv3, a monitoring agent or a second tenant are "a second process" too.  Round 5 met an
 intermittent difference that only a second process on the device brought out (DESIGN section 5f has the round-6 diagnosis: lanes
 48-63 of single waves, second flow component only, in a packed-fp32 form of the SPyNet level-input kernel that the library no longer
-ships; tools/li_diag.sh + the li_diag make target reproduce it).  This test keeps the shipped kernels under that condition:
+ships; tools/r06.sh li-diag + the li_diag make target reproduce it).  This test keeps the shipped kernels under that condition:
   * tools/spynet_determinism.py: SPyNet alone, 40 runs per process, every stage of every level compared;
   * tools/forward_determinism.py: the whole B-frame (mask U-Net with its 3-D-grid split-tensor kernels: vc_split3, up-sampling and
     pooling on split tensors; both codecs; blend), 40 runs per process.

@@ -185,7 +185,7 @@ template <int K_, int NTW_, int CPL_ = 1, int TH_ = 16, int RING_ = 4, int KO_ =
 // store makes a wait longer, never shorter.
 // Round 6: a SPLIT output leaves through LDS as whole records.  The direct form below stores 3 x 8 bytes per lane and accumulator tile
 // at a 48-byte stride -- 24 partial 64-byte lines per wave-instruction, 36 instructions per 12-tile wave: the epilogue was 10.6 % of a
-// 3x3 wave's lifetime (tools/split_stamps.sh) and, both wave groups passing through it one after the other, about twice that of the
+// 3x3 wave's lifetime (tools/r06.sh stamps) and, both wave groups passing through it one after the other, about twice that of the
 // matrix pipe's idle time.  Here the lanes of a wave stage the pieces of NG N-tiles of one M-tile in a private LDS slice
 // ([plane][pixel][48 bytes]: exactly the record image of 2 NG planes x 16 pixels) and write it back out 16 bytes per lane, contiguous:
 // every global store instruction covers 1 KiB of whole records (the 768 contiguous bytes of a plane's 16 pixels, then the next plane's).

@@ -942,7 +942,7 @@ __global__ void __launch_bounds__(EW_BLOCK) k_spynet_level_input_rows(vc_view fi
 
 #ifdef VC_LI_DIAG
 // ------------------------------------------------------------------------------------------------------------------------------
-// Diagnostic build only (make li_diag -> libvc_hip_lidiag.so; tools/li_diag.sh): the 3-D-grid form of the level-input kernel that gave
+// Diagnostic build only (make li_diag -> libvc_hip_lidiag.so; tools/r06.sh li-diag): the 3-D-grid form of the level-input kernel that gave
 // intermittent wrong pixels when two processes shared the GPU, with one suspect removed per variant
 // (VC_LI_VARIANT): 1 = as it was; 2 = coarse flow through non-temporal loads; 3 = coarse flow through system-scope (sc0 sc1) loads;
 // 4 = ~2 us of s_sleep before the first load; 5 = row index kept in a VGPR (no wave-uniform hoisting of the row weights through
