@@ -234,6 +234,34 @@ def test_native_layers_write_split_tensors_and_split_layers_add_split_residuals(
     assert float(_unsplit(o_wide.channels(0, 128)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,k,n,h,w", [(128, 128, 3, 2, 100, 170), (32, 64, 7, 1, 101, 203), (64, 32, 7, 2, 100, 250), (192, 64, 5, 1, 131, 203),
+                                                (32, 128, 7, 1, 97, 130), (64, 32, 3, 1, 150, 261)])
+def test_record_epilogue_equals_the_plain_one(dev, cin, cout, k, n, h, w):
+    """Round 6: a split output leaves the period kernels through LDS as whole records and a split residual is read as whole records
+    (csrc/conv_split.h: split_epilogue_records).  Same arithmetic as the fp32-output / fp32-residual epilogue: the split result must hold
+    exactly the fp32 result's values -- ragged right / bottom tiles (rows of records that must not run into the next image row), blocks of
+    32 and 64 output channels, with and without residual, residual before / after the activation, channel gain."""
+    from vcamd import hip
+    hip.set_fp32_mode("split")
+    wt, b, pc = _layer(cin, cout, k, 31, dev)
+    assert pc.split_ok and pc.split_pays(n, h, w)
+    g = torch.Generator().manual_seed(32)
+    x = hip.nchw_to_nhwc(torch.randn(n, cin, h, w, generator=g).to(dev))
+    r = hip.nchw_to_nhwc(torch.randn(n, cout, h, w, generator=g).to(dev))
+    gain = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    xs, rs = hip.split3(x), hip.split3(r)
+    guard = 7.5
+    for res32, ressp, first, ch in ((None, None, False, None), (r, rs, False, None), (r, rs, True, gain), (None, None, False, gain)):
+        want = hip.nhwc_to_nchw(pc(xs, act=hip.ACT_LRELU, slope=0.1, res=res32, res_first=first, chscale=ch)).cpu()
+        # the split output sits in the middle planes of a wider tensor filled with a guard value: nothing outside its planes may change
+        wide = hip.T.empty(n, h, w, cout + 16, dev, "sp3")
+        hip.split3(hip.nchw_to_nhwc(torch.full((n, cout + 16, h, w), guard).to(dev)), out=wide)
+        got = pc(xs, act=hip.ACT_LRELU, slope=0.1, res=ressp, res_first=first, chscale=ch, out=wide.channels(8, 8 + cout))
+        assert got.dtype == "sp3"
+        assert torch.equal(_unsplit(wide.channels(8, 8 + cout)), want), (res32 is not None, first, ch is not None)
+        assert bool((_unsplit(wide.channels(0, 8)) == guard).all()) and bool((_unsplit(wide.channels(8 + cout, 16 + cout)) == guard).all())
+
+
 def test_pooling_and_upsampling_on_split_tensors(dev):
     """vc_maxpool2_sp3 / vc_upsample_bilinear_sp3 (the mask U-Net between split-operand layers, LHBDC/model/layers.py:200-246): exactly the
     fp32 kernels followed by vc_split3, also into a window of planes of a wider split tensor."""
