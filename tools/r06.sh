@@ -7,6 +7,8 @@
 #   logs                 printed reports of the parity tests, ew_bench, suite durations, default bench line -> gpurun_out/logs_r06/
 #   all                  headline, split-pmc, final, then the default `python bench.py` line
 #   li-diag              two processes x the diagnostic variants of the level-input kernel (make li_diag; VARIANTS / REPS / ROUNDS)
+#   li-corun             variant 1 beside a torch tenant / tools/hammer.py / itself / alone (REPS)
+#   li-vashift           variant 1 beside a twin with a shifted virtual-address layout (REPS)
 #   two-process-spynet   two processes, production library, tools/spynet_determinism.py (REPS / ROUNDS)
 #   two-process-forward  two processes, production library, tools/forward_determinism.py (150 runs each)
 #   stamps               shader-clock stamps per phase segment of the split period kernels (make split_diag)
@@ -141,7 +143,7 @@ for v in ${VARIANTS:-1 0 5 3 4 6}; do
     timeout 400 python tools/spynet_determinism.py ${REPS:-40} $SPYARGS > gpurun_out/li/v${v}_r${r}_b.log 2>&1
     sleep 12
     echo "== variant $v round $r: $(grep -h 'runs differ' gpurun_out/li/v${v}_r${r}_a.log gpurun_out/li/v${v}_r${r}_b.log | tr '\n' ';')"
-    grep -h "wrong pixels by" gpurun_out/li/v${v}_r${r}_a.log gpurun_out/li/v${v}_r${r}_b.log | cut -c1-300 | head -12
+    grep -h "wrong pixels by\|wave lifetimes" gpurun_out/li/v${v}_r${r}_a.log gpurun_out/li/v${v}_r${r}_b.log | cut -c1-700 | head -16
   done
 done
 ls gpurun_out/li/*.pt 2>/dev/null | grep -v "dump_v${KEEP_DUMP:-1}.pt" | xargs -r rm -f
@@ -179,6 +181,47 @@ export VC_HIP_LIB=$PWD/video-compression_amd/libvc_hip_splitdiag.so VC_AUTOTUNE=
 for extra in "" "--residual-split"; do
 for v in 64 0; do echo "== variant $v $extra"; VC_SPLIT_VARIANT=$v python tools/conv_bench.py --split --split-out $extra --reps 5 128,128,3,1,4,544,960 2>&1 | grep -v amdgpu.ids; done; done
 ;;
+li-corun)
+# co-runner experiment: the 3-D-grid form (variant 1) beside (a) a torch-only tenant, (b) the hammer (our persistent conv kernel), (c) itself
+export VC_HIP_LIB=$PWD/video-compression_amd/libvc_hip_lidiag.so VC_LI_VARIANT=1
+mkdir -p gpurun_out/li
+cat > /tmp/torch_tenant.py <<'PY'
+import time, torch
+a = torch.randn(8192, 8192, device="cuda"); b = torch.randn(8192, 8192, device="cuda")
+t = time.time() + 150
+while time.time() < t:
+    for _ in range(20): c = a @ b
+    torch.cuda.synchronize()
+PY
+(timeout 200 python /tmp/torch_tenant.py > /dev/null 2>&1 &)
+sleep 8
+timeout 300 python tools/spynet_determinism.py ${REPS:-120} > gpurun_out/li/corun_torch.log 2>&1
+echo "beside a torch matmul tenant: $(grep -h 'runs differ' gpurun_out/li/corun_torch.log)"
+sleep 10
+(VC_HIP_LIB= timeout 200 python tools/hammer.py 150 > /dev/null 2>&1 &)
+sleep 8
+timeout 300 python tools/spynet_determinism.py ${REPS:-120} > gpurun_out/li/corun_hammer.log 2>&1
+echo "beside the persistent-convolution tenant: $(grep -h 'runs differ' gpurun_out/li/corun_hammer.log)"
+sleep 10
+(timeout 300 python tools/spynet_determinism.py ${REPS:-120} > gpurun_out/li/corun_self_a.log 2>&1 &)
+timeout 300 python tools/spynet_determinism.py ${REPS:-120} > gpurun_out/li/corun_self_b.log 2>&1
+sleep 10
+echo "beside itself: $(grep -h 'runs differ' gpurun_out/li/corun_self_a.log gpurun_out/li/corun_self_b.log | tr '\n' ';')"
+timeout 300 python tools/spynet_determinism.py ${REPS:-120} > gpurun_out/li/corun_alone.log 2>&1
+echo "alone: $(grep -h 'runs differ' gpurun_out/li/corun_alone.log)"
+grep -h "wave lifetimes" gpurun_out/li/corun_*.log | cut -c1-500 | head -6
+;;
+li-vashift)
+# the 3-D-grid form (variant 1), two identical processes -- one of them with a shifted virtual-address layout
+export VC_HIP_LIB=$PWD/video-compression_amd/libvc_hip_lidiag.so VC_LI_VARIANT=1
+mkdir -p gpurun_out/li
+for shift in 3001 0 777 0; do
+  (VC_VA_SHIFT_MB=$shift timeout 400 python tools/spynet_determinism.py ${REPS:-200} > gpurun_out/li/va_${shift}_a.log 2>&1 &)
+  VC_VA_SHIFT_MB= timeout 400 python tools/spynet_determinism.py ${REPS:-200} > gpurun_out/li/va_${shift}_b.log 2>&1
+  sleep 12
+  echo "twin shifted by $shift MiB: $(grep -h 'runs differ' gpurun_out/li/va_${shift}_a.log gpurun_out/li/va_${shift}_b.log | tr '\n' ';') $(grep -h 'virtual-address' gpurun_out/li/va_${shift}_a.log | cut -c1-80)"
+done
+;;
 epilogue-ab)
 for i in 1 2; do
 VC_HIP_LIB=$OLD_LIB python bench.py --no-cpu-baseline --no-strong-block --skip-extras --steps 4 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('other library ', round(d['value'],2), round(d['roofline']['avg_launch_ms'],3), d['conv_engine']['timed_region_tflops'])"
@@ -192,5 +235,5 @@ bash tools/r06.sh final > gpurun_out/final_r06_summary.log 2>&1
 python bench.py > gpurun_out/final_r06/h_bench_line_final.json 2> gpurun_out/final_r06/h_bench.err
 tail -5 gpurun_out/prof_r06_headline.log | cut -c1-300; tail -12 gpurun_out/prof_r06_split.log | cut -c1-400; cat gpurun_out/final_r06_summary.log; tail -c 1500 gpurun_out/final_r06/h_bench_line_final.json
 ;;
-*) echo "usage: bash tools/r06.sh headline|split-pmc|fp16-pmc|final|logs|all|li-diag|two-process-spynet|two-process-forward|stamps|stamps-epilogue|epilogue-ab"; exit 2;;
+*) echo "usage: bash tools/r06.sh headline|split-pmc|fp16-pmc|final|logs|all|li-diag|li-corun|li-vashift|two-process-spynet|two-process-forward|stamps|stamps-epilogue|epilogue-ab"; exit 2;;
 esac

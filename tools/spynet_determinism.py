@@ -46,26 +46,37 @@ def where(cur, ref, n, h, w, slot):
     if not hasattr(L, "vc_li_diag_read"):
         return
     SLOT = 1 << 17
-    buf = np.zeros(6 * SLOT * 2, dtype=np.uint32)
+    buf = np.zeros(6 * SLOT * 4, dtype=np.uint32)
     L.vc_li_diag_read.argtypes = [ctypes.c_void_p]
     if L.vc_li_diag_read(buf.ctypes.data) != 0:
         return
-    buf = buf.reshape(6, SLOT, 2)
+    buf = buf.reshape(6, SLOT, 4)
     cur, ref = cur.reshape(n, h, w, 2).cpu(), ref.reshape(n, h, w, 2).cpu()
     bad = torch.nonzero((cur != ref).any(-1))
     gx = (w + 255) // 256
-    units, all_units = {}, set()
+    units, bad_waves = {}, set()
 
     def unit(hw, xcc):
         return (int(xcc) & 15, (int(hw) >> 13) & 7, (int(hw) >> 12) & 1, (int(hw) >> 8) & 15, (int(hw) >> 4) & 3)     # XCC, SE, SH, CU, SIMD
     for img, y, x in bad.tolist():
         idx = ((img * h + y) * gx + x // 256) * 4 + (x % 256) // 64
         if idx < SLOT:
-            u = unit(*buf[slot, idx])
+            u = unit(buf[slot, idx, 0], buf[slot, idx, 1])
             units[u] = units.get(u, 0) + 1
-    for idx in range(min(SLOT, n * h * gx * 4)):
-        all_units.add(unit(*buf[slot, idx]))
-    print(f"    wrong pixels by (XCC, SE, SH, CU, SIMD) of the wave that produced them: {units}; the launch used {len(all_units)} distinct SIMDs", flush=True)
+            bad_waves.add(idx)
+    nw = min(SLOT, n * h * gx * 4)
+    life = buf[slot, :nw, 2].astype(np.int64) * 10           # ns (100 MHz ticks)
+    moved = buf[slot, :nw, 0] != buf[slot, :nw, 3]            # HW_ID at the end differs from the start: the wave came back on another slot
+    bw = np.array(sorted(bad_waves), dtype=np.int64)
+    good = np.ones(nw, dtype=bool)
+    good[bw] = False
+    q = lambda a, p_: int(np.percentile(a, p_)) if a.size else -1          # noqa: E731
+    print(f"    wrong pixels by (XCC, SE, SH, CU, SIMD) of the wave that produced them: {dict(list(units.items())[:12])}{' ...' if len(units) > 12 else ''}; "
+          f"{len(set(unit(a, b) for a, b in buf[slot, :nw, :2].tolist()))} distinct SIMDs in the launch", flush=True)
+    print(f"    wave lifetimes (s_memrealtime, ns): the {bw.size} waves with wrong lanes median {q(life[bw], 50)} min {int(life[bw].min()) if bw.size else -1} "
+          f"max {int(life[bw].max()) if bw.size else -1}; the {int(good.sum())} others median {q(life[good], 50)} p99 {q(life[good], 99)} max {int(life[good].max())}; "
+          f"waves longer than 100 us: {int((life > 100000).sum())} of {nw}, of them with wrong lanes: {int((life[bw] > 100000).sum())}; "
+          f"HW_ID changed between start and end: {int(moved.sum())} waves, of them with wrong lanes: {int(moved[bw].sum())}", flush=True)
 
 
 def main():
@@ -73,6 +84,9 @@ def main():
     if "--native" in sys.argv:
         hip.set_fp32_mode("native")
     dev = torch.device("cuda:0")
+    if os.environ.get("VC_VA_SHIFT_MB"):          # a different virtual-address layout than a twin process: every later allocation moves
+        shift = torch.empty(int(os.environ["VC_VA_SHIFT_MB"]) << 20, dtype=torch.uint8, device=dev)
+        print(f"virtual-address shift: {shift.numel() >> 20} MiB held at {shift.data_ptr():#x}", flush=True)
     from vcamd.seeding import calibrated_state_dict
     m = lhbdc.Model()
     m.load_state_dict(calibrated_state_dict(m.state_dict(), seed=1234))

@@ -961,20 +961,24 @@ template <int VAR> __device__ __forceinline__ float li_load(const float *p)
 }
 // where each wave ran: HW_ID (wave / SIMD / CU / SE ...) and XCC_ID per (image, row, strip, wave) of the launch, one slot per pyramid level
 #define LI_DBG_SLOT (1 << 17)
-__device__ unsigned li_dbg[6 * LI_DBG_SLOT * 2];
-extern "C" int vc_li_diag_read(unsigned *host_dst)      // 6 slots x LI_DBG_SLOT x {HW_ID, XCC_ID}
+__device__ unsigned li_dbg[6 * LI_DBG_SLOT * 4];
+extern "C" int vc_li_diag_read(unsigned *host_dst)      // 6 slots x LI_DBG_SLOT x {HW_ID, XCC_ID, wave lifetime in 100 MHz ticks, HW_ID at the end}
 {
-    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(li_dbg), sizeof(unsigned) * 6 * LI_DBG_SLOT * 2) == hipSuccess ? VC_OK : VC_ELAUNCH;
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(li_dbg), sizeof(unsigned) * 6 * LI_DBG_SLOT * 4) == hipSuccess ? VC_OK : VC_ELAUNCH;
 }
 template <bool SP3, int VAR> __global__ void k_spynet_level_input_3d(vc_view first, vc_view second, vc_view fc, vc_view feat, vc_view up, int slot)
 {
+    // (s_memrealtime: the constant 100 MHz counter -- it keeps running while a wave is saved and swapped out, so a wave that was
+    //  preempted shows a lifetime of milliseconds instead of microseconds)
+    const unsigned li_idx = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+    unsigned long long li_t0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(li_t0)::"memory");
     if ((threadIdx.x & 63) == 0) {
-        const unsigned idx = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
-        if (idx < LI_DBG_SLOT) {
+        if (li_idx < LI_DBG_SLOT) {
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-            li_dbg[(slot * LI_DBG_SLOT + idx) * 2] = hw;
-            li_dbg[(slot * LI_DBG_SLOT + idx) * 2 + 1] = xcc;
+            li_dbg[(slot * LI_DBG_SLOT + li_idx) * 4] = hw;
+            li_dbg[(slot * LI_DBG_SLOT + li_idx) * 4 + 1] = xcc;
         }
     }
     if (VAR == 4) {
@@ -1047,6 +1051,14 @@ template <bool SP3, int VAR> __global__ void k_spynet_level_input_3d(vc_view fir
         const int x_run = (int)blockIdx.x * EW_BLOCK;
         vc_store_records_256<1>(sm, threadIdx.x, x < feat.w, ph, pm, pl,
                                 reinterpret_cast<unsigned char *>(feat.p) + (((long long)n * feat.h + y) * feat.w + x_run) * 48, 0, min(EW_BLOCK, feat.w - x_run));
+    }
+    unsigned long long li_t1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(li_t1)::"memory");
+    if ((threadIdx.x & 63) == 0 && li_idx < LI_DBG_SLOT) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        li_dbg[(slot * LI_DBG_SLOT + li_idx) * 4 + 2] = (unsigned)(li_t1 - li_t0);
+        li_dbg[(slot * LI_DBG_SLOT + li_idx) * 4 + 3] = hw;
     }
 }
 static int li_variant()
