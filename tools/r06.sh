@@ -8,6 +8,7 @@
 #   all                  headline, split-pmc, final, then the default `python bench.py` line
 #   li-diag              two processes x the diagnostic variants of the level-input kernel (make li_diag; VARIANTS / REPS / ROUNDS)
 #   li-corun             variant 1 beside a torch tenant / tools/hammer.py / itself / alone (REPS)
+#   li-corun2            variant 1 beside a tenant of tiny torch kernels / of this library's short element-wise kernels / itself (REPS)
 #   li-vashift           variant 1 beside a twin with a shifted virtual-address layout (REPS)
 #   two-process-spynet   two processes, production library, tools/spynet_determinism.py (REPS / ROUNDS)
 #   two-process-forward  two processes, production library, tools/forward_determinism.py (150 runs each)
@@ -211,6 +212,50 @@ timeout 300 python tools/spynet_determinism.py ${REPS:-120} > gpurun_out/li/coru
 echo "alone: $(grep -h 'runs differ' gpurun_out/li/corun_alone.log)"
 grep -h "wave lifetimes" gpurun_out/li/corun_*.log | cut -c1-500 | head -6
 ;;
+li-corun2)
+export VC_HIP_LIB=$PWD/video-compression_amd/libvc_hip_lidiag.so VC_LI_VARIANT=1
+mkdir -p gpurun_out/li
+cat > /tmp/tiny_tenant.py <<'PY'
+import time, torch
+xs = [torch.randn(1 << 16, device="cuda") for _ in range(8)]
+t = time.time() + 150
+while time.time() < t:
+    for _ in range(2000):
+        for x in xs: x.mul_(1.0001)
+    torch.cuda.synchronize()
+PY
+cat > /tmp/ew_tenant.py <<'PY'
+import sys, time, torch
+sys.path.insert(0, "video-compression_amd")
+from vcamd import hip
+dev = torch.device("cuda:0")
+a = hip.T.empty(2, 136, 240, 64, dev); a.buf.normal_()
+imgs = [hip.T.empty(2, 272, 480, 3, dev) for _ in range(2)]
+for t_ in imgs: t_.buf.uniform_()
+fl = hip.T.empty(2, 272, 480, 2, dev); fl.buf.normal_()
+t = time.time() + 150
+while time.time() < t:
+    for _ in range(300):
+        hip.upsample_bilinear(a, 2)
+        hip.warp(hip.WARP_W1, imgs[0], fl)
+        hip.avgpool_reflectpad(imgs[1], 2)
+    torch.cuda.synchronize()
+PY
+(timeout 200 python /tmp/tiny_tenant.py > /dev/null 2>&1 &)
+sleep 8
+timeout 300 python tools/spynet_determinism.py ${REPS:-260} > gpurun_out/li/corun_tiny.log 2>&1
+echo "beside a tenant of tiny torch kernels: $(grep -h 'runs differ' gpurun_out/li/corun_tiny.log)"
+sleep 12
+(VC_LI_VARIANT=0 timeout 200 python /tmp/ew_tenant.py > gpurun_out/li/ew_tenant.log 2>&1 &)
+sleep 10
+timeout 300 python tools/spynet_determinism.py ${REPS:-260} > gpurun_out/li/corun_ew.log 2>&1
+echo "beside a tenant of this library's short element-wise kernels: $(grep -h 'runs differ' gpurun_out/li/corun_ew.log)"; tail -2 gpurun_out/li/ew_tenant.log | cut -c1-200
+sleep 12
+(timeout 300 python tools/spynet_determinism.py ${REPS:-260} > gpurun_out/li/corun2_self_a.log 2>&1 &)
+timeout 300 python tools/spynet_determinism.py ${REPS:-260} > gpurun_out/li/corun2_self_b.log 2>&1
+sleep 10
+echo "control, beside itself: $(grep -h 'runs differ' gpurun_out/li/corun2_self_a.log gpurun_out/li/corun2_self_b.log | tr '\n' ';')"
+;;
 li-vashift)
 # the 3-D-grid form (variant 1), two identical processes -- one of them with a shifted virtual-address layout
 export VC_HIP_LIB=$PWD/video-compression_amd/libvc_hip_lidiag.so VC_LI_VARIANT=1
@@ -235,5 +280,5 @@ bash tools/r06.sh final > gpurun_out/final_r06_summary.log 2>&1
 python bench.py > gpurun_out/final_r06/h_bench_line_final.json 2> gpurun_out/final_r06/h_bench.err
 tail -5 gpurun_out/prof_r06_headline.log | cut -c1-300; tail -12 gpurun_out/prof_r06_split.log | cut -c1-400; cat gpurun_out/final_r06_summary.log; tail -c 1500 gpurun_out/final_r06/h_bench_line_final.json
 ;;
-*) echo "usage: bash tools/r06.sh headline|split-pmc|fp16-pmc|final|logs|all|li-diag|li-corun|li-vashift|two-process-spynet|two-process-forward|stamps|stamps-epilogue|epilogue-ab"; exit 2;;
+*) echo "usage: bash tools/r06.sh headline|split-pmc|fp16-pmc|final|logs|all|li-diag|li-corun|li-corun2|li-vashift|two-process-spynet|two-process-forward|stamps|stamps-epilogue|epilogue-ab"; exit 2;;
 esac
