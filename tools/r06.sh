@@ -9,6 +9,7 @@
 #   li-diag              two processes x the diagnostic variants of the level-input kernel (make li_diag; VARIANTS / REPS / ROUNDS)
 #   li-corun             variant 1 beside a torch tenant / tools/hammer.py / itself / alone (REPS)
 #   li-corun2            variant 1 beside a tenant of tiny torch kernels / of this library's short element-wise kernels / itself (REPS)
+#   li-mix               variant 1 beside a twin on the shipped form / on variant 1, alternating (REPS)
 #   li-vashift           variant 1 beside a twin with a shifted virtual-address layout (REPS)
 #   two-process-spynet   two processes, production library, tools/spynet_determinism.py (REPS / ROUNDS)
 #   two-process-forward  two processes, production library, tools/forward_determinism.py (150 runs each)
@@ -256,6 +257,17 @@ timeout 300 python tools/spynet_determinism.py ${REPS:-260} > gpurun_out/li/coru
 sleep 10
 echo "control, beside itself: $(grep -h 'runs differ' gpurun_out/li/corun2_self_a.log gpurun_out/li/corun2_self_b.log | tr '\n' ';')"
 ;;
+li-mix)
+export VC_HIP_LIB=$PWD/video-compression_amd/libvc_hip_lidiag.so
+mkdir -p gpurun_out/li
+for pair in "1 0" "1 1" "1 0" "1 1"; do
+  set -- $pair
+  (VC_LI_VARIANT=$2 timeout 300 python tools/spynet_determinism.py ${REPS:-260} > gpurun_out/li/mix_b.log 2>&1 &)
+  VC_LI_VARIANT=$1 timeout 300 python tools/spynet_determinism.py ${REPS:-260} > gpurun_out/li/mix_a.log 2>&1
+  sleep 12
+  echo "process A on variant $1 beside a twin on variant $2: A $(grep -h 'runs differ' gpurun_out/li/mix_a.log); twin $(grep -h 'runs differ' gpurun_out/li/mix_b.log)"
+done
+;;
 li-vashift)
 # the 3-D-grid form (variant 1), two identical processes -- one of them with a shifted virtual-address layout
 export VC_HIP_LIB=$PWD/video-compression_amd/libvc_hip_lidiag.so VC_LI_VARIANT=1
@@ -280,5 +292,5 @@ bash tools/r06.sh final > gpurun_out/final_r06_summary.log 2>&1
 python bench.py > gpurun_out/final_r06/h_bench_line_final.json 2> gpurun_out/final_r06/h_bench.err
 tail -5 gpurun_out/prof_r06_headline.log | cut -c1-300; tail -12 gpurun_out/prof_r06_split.log | cut -c1-400; cat gpurun_out/final_r06_summary.log; tail -c 1500 gpurun_out/final_r06/h_bench_line_final.json
 ;;
-*) echo "usage: bash tools/r06.sh headline|split-pmc|fp16-pmc|final|logs|all|li-diag|li-corun|li-corun2|li-vashift|two-process-spynet|two-process-forward|stamps|stamps-epilogue|epilogue-ab"; exit 2;;
+*) echo "usage: bash tools/r06.sh headline|split-pmc|fp16-pmc|final|logs|all|li-diag|li-corun|li-corun2|li-mix|li-vashift|two-process-spynet|two-process-forward|stamps|stamps-epilogue|epilogue-ab"; exit 2;;
 esac
