@@ -165,8 +165,8 @@ def strong_frames_per_sequence(seconds_per_step, world, sequences):
 def strong_hbm_plan(args, dev, world, rank, H, W, G, frames_per_sequence, head_pool_gb, limit=0.85):
     """Will the strong block fit?  need = this rank's resident frames (uint8) + one graph pool per captured pass size, each
     ``head_pool_gb`` (the headline's pool for G GOPs) x GOPs of the pass / G; budget = ``limit`` x device memory - what the process
-    already holds.  Returns the (possibly shrunk) sizing and what was done: "none", "whole_passes" (frames per sequence cut so that
-    this rank's GOP count is a multiple of G: one graph size instead of two) or "eager" (no graphs at all)."""
+    already holds.  Returns the (possibly shrunk) sizing and what was done: "none", "whole_passes" (frames per sequence moved to the
+    nearest length at which this rank's GOP count is a multiple of G: one graph size instead of two) or "eager" (no graphs at all)."""
     from vcamd import gop as vgop
     total_gb = torch.cuda.get_device_properties(dev).total_memory / 2 ** 30
     held_gb = torch.cuda.memory_reserved(dev) / 2 ** 30
@@ -185,14 +185,14 @@ def strong_hbm_plan(args, dev, world, rank, H, W, G, frames_per_sequence, head_p
     out.update({"estimated_gb": round(est, 1), "pass_sizes_gops": sizes})
     if est <= budget_gb:
         return out
-    fps = frames_per_sequence
-    while fps > 9:                         # shorter sequences until this rank codes whole passes only
-        fps -= 8
+    k0 = (frames_per_sequence - 1) // 8    # GOPs per sequence; the nearest count (shorter first) at which this rank codes whole passes only
+    for k in sorted(range(1, k0 + G + 1), key=lambda k: (abs(k - k0), k)):
+        fps = 8 * k + 1
         e2, s2 = need(fps)
         if len(s2) == 1 and e2 <= budget_gb:
             out.update({"frames_per_sequence": fps, "action": "whole_passes", "estimated_gb": round(e2, 1), "pass_sizes_gops": s2,
                         "message": f"estimated pool {est:.0f} GB + {held_gb:.0f} GB held exceeds {100 * limit:.0f} % of {total_gb:.0f} GB: "
-                                   f"sequences cut from {frames_per_sequence} to {fps} frames (whole passes of {G} GOPs only, {e2:.0f} GB)"})
+                                   f"sequences resized from {frames_per_sequence} to {fps} frames (whole passes of {G} GOPs only, {e2:.0f} GB)"})
             return out
     frames_gb = need(frames_per_sequence)[0] - (0.0 if args.no_graph else head_pool_gb * sum(sizes) / G)
     out.update({"action": "eager", "estimated_gb": round(frames_gb, 1),
