@@ -16,6 +16,11 @@ both sides, eight different frame triples per size:
     value sits within 2e-3 of a half-integer (test_fullsize_gpu.check_teacher_forced); indexes: the oracle's own scale
     within 2e-5 of a table entry, one bin apart, at most 2e-5 N of them.
 bench.py reports the same count as ``byte_equality``.  The oracle passes run side by side (oracle.pool).
+
+Round 6: three settings side by side per frame -- plain fp32, + scale refinement (vc_refine_scales, round 5), + symbol refinement
+(vc_refine_y_symbols / vc_refine_z_symbols: latents and hyper-latents within 2e-5 of a rounding boundary decided from fp64
+re-evaluations of the layers that produce them) -- with the differing indexes, differing symbols, identical containers and the number of
+elements decided in fp64 printed for each.  Measured at 1088x1920: 92 / 66 / 66 indexes, 3 / 3 / 2 symbols, 0 / 5 / 6 of 8 containers.
 """
 import numpy as np
 import pytest
