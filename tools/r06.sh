@@ -15,6 +15,7 @@
 #   two-process-forward  two processes, production library, tools/forward_determinism.py (150 runs each)
 #   stamps               shader-clock stamps per phase segment of the split period kernels (make split_diag)
 #   stamps-epilogue      the same with / without a split residual
+#   f16-stamps           the same stamps for the fp16 LDS-DMA kernel (make dma_diag)
 #   epilogue-ab          headline with another library (OLD_LIB=path) against the shipped one, alternating
 # Copy what is to be judged from gpurun_out/ into profiles/r06/ (profiles/README.md lists what went where).
 what=${1:-}
@@ -279,6 +280,13 @@ for shift in 3001 0 777 0; do
   echo "twin shifted by $shift MiB: $(grep -h 'runs differ' gpurun_out/li/va_${shift}_a.log gpurun_out/li/va_${shift}_b.log | tr '\n' ';') $(grep -h 'virtual-address' gpurun_out/li/va_${shift}_a.log | cut -c1-80)"
 done
 ;;
+f16-stamps)
+export VC_HIP_LIB=$PWD/video-compression_amd/libvc_hip_dmadiag.so VC_AUTOTUNE=0 VC_DMA_VARIANT=64
+for shape in 128,128,3,1,4,544,960,8 128,128,3,1,1,1088,1920,8 64,64,3,1,1,1088,1920,8 64,32,7,1,4,1088,1920,8; do
+  python tools/conv_bench.py --precision fp16 --half-io --reps 5 $shape 2>&1 | grep -v amdgpu.ids
+done
+python tools/conv_bench.py --precision fp16 --half-io --residual-half --reps 5 128,128,3,1,1,544,960 2>&1 | grep -v amdgpu.ids
+;;
 epilogue-ab)
 for i in 1 2; do
 VC_HIP_LIB=$OLD_LIB python bench.py --no-cpu-baseline --no-strong-block --skip-extras --steps 4 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('other library ', round(d['value'],2), round(d['roofline']['avg_launch_ms'],3), d['conv_engine']['timed_region_tflops'])"
@@ -292,5 +300,5 @@ bash tools/r06.sh final > gpurun_out/final_r06_summary.log 2>&1
 python bench.py > gpurun_out/final_r06/h_bench_line_final.json 2> gpurun_out/final_r06/h_bench.err
 tail -5 gpurun_out/prof_r06_headline.log | cut -c1-300; tail -12 gpurun_out/prof_r06_split.log | cut -c1-400; cat gpurun_out/final_r06_summary.log; tail -c 1500 gpurun_out/final_r06/h_bench_line_final.json
 ;;
-*) echo "usage: bash tools/r06.sh headline|split-pmc|fp16-pmc|final|logs|all|li-diag|li-corun|li-corun2|li-mix|li-vashift|two-process-spynet|two-process-forward|stamps|stamps-epilogue|epilogue-ab"; exit 2;;
+*) echo "usage: bash tools/r06.sh headline|split-pmc|fp16-pmc|final|logs|all|li-diag|li-corun|li-corun2|li-mix|li-vashift|two-process-spynet|two-process-forward|stamps|stamps-epilogue|f16-stamps|epilogue-ab"; exit 2;;
 esac
