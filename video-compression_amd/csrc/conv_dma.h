@@ -177,7 +177,6 @@ __device__ unsigned long long g_vc_dma_stamps[8];
 struct DmaTile {
     int img, oy0, ox0, nblk;
     bool valid;
-    bool interior;      // (conv_dma_kernel only) the whole input footprint lies inside the image: no per-lane border test when it is staged
 };
 
 // Epilogue of conv_epilogue_coalesced (same arithmetic per value, same LDS exchange) with UNCONDITIONAL stores: a pixel
@@ -577,7 +576,6 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         vc_tile_xy(t1 - t.img * per_img, p.tiles_x, p.tiles_y, p.tile_band, tx, ty);
         t.oy0 = ty * C::TH;
         t.ox0 = tx * C::TW;
-        t.interior = t.valid && t.oy0 >= C::KH / 2 && t.ox0 >= KW / 2 && t.oy0 - C::KH / 2 + C::ROWS_IN <= p.H && t.ox0 - KW / 2 + C::COLS <= p.W;
         return t;
     };
     DmaTile cur = tile_at(0);
@@ -600,9 +598,7 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         const int q = s >> 2;
         const int row = q / C::COLS, col = q - row * C::COLS;
         const int g = (s & 3) ^ ((col >> 2) & 3);
-        // (slots past the footprint -- the tail of the last piece -- re-read the footprint's first pixel on the interior path: their
-        //  16 bytes land in LDS padding nobody reads)
-        a_off[k] = q < C::PIX ? C::ESZ * (row * (int)p.in_sh + col * (int)p.in_sw + g * (16 / C::ESZ)) : 0;
+        a_off[k] = C::ESZ * (row * (int)p.in_sh + col * (int)p.in_sw + g * (16 / C::ESZ));
         a_rc[k] = q < C::PIX ? (row | (col << 8)) : 0x7f7f7f;       // (a row / column no image reaches)
     }
     auto tile_base = [&](const DmaTile &t) {           // address of the footprint's first pixel (may lie outside the tensor)
@@ -613,13 +609,6 @@ template <class C> __global__ void __launch_bounds__(512, 2) conv_dma_kernel(con
         //  of the tile loop for all pieces of both tiles at once -- 20 registers the accumulators need)
         int rc = a_rc[k], off = a_off[k];
         asm volatile("" : "+v"(rc), "+v"(off));
-        // Round 6: a tile whose footprint lies inside the image (all but the border tiles) needs no border test -- the DMA issue was
-        // 18 % of a wave's lifetime on the fp16 3x3 instance against 22 % MFMA issue, the phases read-slot bound;
-        // the test, the zero-page select and the 64-bit select are most of a piece's address arithmetic.  Wave-uniform branch.
-        if (t.interior) {
-            if constexpr (!(C::KO & (16 | 1024))) vc_glds16<!(C::KO & 512)>(tbase + (off + c * 64), (unsigned)(buf * C::A_BYTES + k * 8192 + wave * 1024));
-            return;
-        }
         const unsigned iy = (unsigned)(t.oy0 - C::KH / 2 + (rc & 0xff)), ix = (unsigned)(t.ox0 - KW / 2 + (rc >> 8));
         const bool ok = t.valid && iy < (unsigned)p.H && ix < (unsigned)p.W;
         const unsigned char *sp = ok ? tbase + (off + c * 64) : zero_lane;
