@@ -283,11 +283,20 @@ int vc_offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc
                         float magnitude, const float *wpk, const float *bias, int groups, vc_view out);
 /* fp16 path: the same with HALF-precision features -- x1.p / x2.p point at _Float16 tensors (strides in elements), as
  * vc_to_half writes them.  The deformable fusion (helpers.py:35-58) is bound by its gathers; half features halve them.
- * 8 or 16 channels per group; offsets, modulation, bilinear weights and accumulation stay fp32. */
+ * 8 or 16 channels per group; offsets, modulation, bilinear weights and accumulation stay fp32.  One image of the features
+ * stays below 4 GiB (the gathers use 32-bit byte offsets from the image's base; VC_EINVAL above -- the fp32 entry points have
+ * no such limit). */
 int vc_offset_diversity_hx(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2,
                         float magnitude, const float *wpk, const float *bias, int groups, vc_view out);
 /* Dense half-precision copy [n,h,w,c] of a channels-last window (c % 4 == 0), round to nearest even. */
 int vc_to_half(vc_stream s, vc_view a, void *out_half);
+/* The same on GROUP-PLANAR half features, the layout the fp16 path uses (same values, same arithmetic, same result bit for bit;
+ * the gathers of neighbouring pixels then share cache lines).  vc_to_half_planar writes [n][c/cg][h][w][cg] halves (cg in
+ * {4, 8, 12, 16}); x1 / x2 of vc_offset_diversity_hxp describe ONE group's plane of such a tensor: c = cg, sw = cg, sh = w * cg,
+ * sn = (G/2) * h * w * cg (strides in elements).  One image of the features stays below 4 GiB (32-bit byte offsets). */
+int vc_offset_diversity_hxp(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2,
+                            float magnitude, const float *wpk, const float *bias, int groups, vc_view out);
+int vc_to_half_planar(vc_stream s, vc_view a, int cg, void *out_half);
 
 /* Gate of compressai.layers.AttentionBlock (ELIC intra codec of ICIP2024, src/model/elic.py:97-121):
  * out = a * sigmoid(b) + identity. */

@@ -1,5 +1,6 @@
 """The C-ABI library loads without a GPU and exports every symbol include/vc_hip.h declares;
 host-side entry points (weight packing, table construction) behave."""
+import ctypes
 import os
 import re
 
@@ -79,3 +80,26 @@ def test_weight_packing_is_a_permutation_with_zero_padding():
 def test_conv_desc_rejects_bad_shapes_without_touching_a_gpu():
     d = hip.ConvDesc()
     assert hip.lib().vc_conv2d_nhwc(None, d) == -1
+
+
+def test_planar_deformable_entry_rejects_inconsistent_planes_without_touching_a_gpu():
+    """vc_offset_diversity_hxp: x1 / x2 describe ONE group's plane of a [n][G/2][h][w][cg] half tensor -- c = sw = cg, sh = w * cg,
+    sn = (G/2) * h * w * cg; anything else is VC_EINVAL before any launch (include/vc_hip.h).  vc_to_half_planar: cg in {4, 8, 12, 16}
+    dividing c."""
+    L = hip.lib()
+    n, h, w, cg, groups = 1, 4, 6, 8, 16
+    hg = groups // 2
+    buf = (ctypes.c_float * (n * h * w * 27 * hg))()
+    p = ctypes.cast(buf, ctypes.c_void_p).value
+    good = hip.View(p, n, h, w, cg, hg * h * w * cg, w * cg, cg)
+    raw = hip.View(p, n, h, w, 27 * hg, h * w * 27 * hg, w * 27 * hg, 27 * hg)
+    flow = hip.View(p, n, h, w, 2, h * w * 2, w * 2, 2)
+    out = hip.View(p, n, h, w, groups * 4, h * w * groups * 4, w * groups * 4, groups * 4)
+    for bad in (hip.View(p, n, h, w, cg, hg * h * w * cg, w * cg, 2 * cg),           # pixel stride is not cg
+                hip.View(p, n, h, w, cg, hg * h * w * cg, w * cg + 8, cg),           # padded rows
+                hip.View(p, n, h, w, cg, h * w * cg, w * cg, cg)):                   # image stride of ONE plane
+        assert L.vc_offset_diversity_hxp(None, bad, raw, flow, good, raw, flow, 10.0, p, None, groups, out) == -1
+        assert L.vc_offset_diversity_hxp(None, good, raw, flow, bad, raw, flow, 10.0, p, None, groups, out) == -1
+    x = hip.View(p, n, h, w, 64, h * w * 64, w * 64, 64)
+    for cg_bad in (0, 2, 6, 20, 24):
+        assert L.vc_to_half_planar(None, x, cg_bad, p) == -1

@@ -81,12 +81,15 @@ def test_offset_diversity_matches_oracle(dev, c, mag):
     assert ((out - ref).abs() / (1 + ref.abs()))[ok].max().item() < 5e-5
 
 
+@pytest.mark.parametrize("planar", [True, False])
 @pytest.mark.parametrize("c,mag", [(64, 40), (96, 20), (128, 10)])
-def test_offset_diversity_half_precision_features(dev, c, mag):
-    """fp16 path (hip.HALF_DEFORM, vc_offset_diversity_hx): the fusion gathers from half-precision copies of its feature maps
+def test_offset_diversity_half_precision_features(dev, c, mag, planar):
+    """fp16 path (hip.HALF_DEFORM, vc_offset_diversity_hxp / _hx): the fusion gathers from half-precision copies of its feature maps
     -- the fp32 kernel's result on features that were rounded to half beforehand (offsets, modulation, bilinear weights and
     accumulation stay fp32), up to the compiler's choice of fused multiply-adds in the two instances: 1e-6 relative, 500x
-    below one half-precision rounding; 8, 12 and 16 channels per group (12: a 16-byte and an 8-byte gather per corner)."""
+    below one half-precision rounding; 8, 12 and 16 channels per group (12: a 16-byte and an 8-byte gather per corner).
+    Both layouts of the half copies: group-planar (the default, hip.HALF_DEFORM_PLANAR) and pixel-interleaved -- the same
+    values through the same arithmetic, so the two results are equal bit for bit."""
     from vcamd import hip, icip2024
     g = torch.Generator().manual_seed(c + 1)
     h, w, n = 27, 44, 2
@@ -100,20 +103,40 @@ def test_offset_diversity_half_precision_features(dev, c, mag):
     f1, f2 = torch.randn(n, 2, h, w, generator=g) * 3, torch.randn(n, 2, h, w, generator=g) * 3
     rest = [_nhwc(t, dev) for t in (o1, f1, o2, f2)]
     calls = []
-    orig = hip.to_half
-    hip.to_half = lambda t: (calls.append(t.c), orig(t))[1]
+    orig, orig_p, keep = hip.to_half, hip.to_half_planar, hip.HALF_DEFORM_PLANAR
+    hip.to_half = lambda t: (calls.append(("interleaved", t.c)), orig(t))[1]
+    hip.to_half_planar = lambda t, cg: (calls.append(("planar", t.c)), orig_p(t, cg))[1]
     try:
         ref = hip.nhwc_to_nchw(prod.run(_nhwc(x1.half().float(), dev), rest[0], rest[1], _nhwc(x2.half().float(), dev), rest[2], rest[3]))
         assert not calls                                        # fp32 precision: fp32 features
         hip.set_conv_precision("fp16")
+        hip.HALF_DEFORM_PLANAR = planar
         out = hip.nhwc_to_nchw(prod.run(_nhwc(x1, dev), rest[0], rest[1], _nhwc(x2, dev), rest[2], rest[3]))
-        assert calls == [c, c]
+        assert calls == [("planar" if planar else "interleaved", c)] * 2
+        hip.HALF_DEFORM_PLANAR = not planar
+        other = hip.nhwc_to_nchw(prod.run(_nhwc(x1, dev), rest[0], rest[1], _nhwc(x2, dev), rest[2], rest[3]))
     finally:
-        hip.to_half = orig
+        hip.to_half, hip.to_half_planar, hip.HALF_DEFORM_PLANAR = orig, orig_p, keep
         hip.set_conv_precision("fp32")
     d = ((out - ref).abs() / (1 + ref.abs())).max().item()
-    print(f"c={c}: max relative difference {d:.2e}")
+    print(f"c={c} planar={planar}: max relative difference {d:.2e}")
     assert d < 1e-6
+    assert torch.equal(out, other)
+
+
+@pytest.mark.parametrize("c,cg,h,w", [(64, 8, 9, 13), (96, 12, 5, 7), (128, 16, 4, 6), (8, 4, 3, 5)])
+def test_to_half_planar_layout(dev, c, cg, h, w):
+    """vc_to_half_planar: [n][c / cg][h][w][cg] halves, round to nearest even -- against torch's own cast and permutation"""
+    from vcamd import hip
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(2, c, h, w, generator=g) * 3
+    x[0, 0, 0, 0] = 1.0 + 2.0 ** -11                            # a tie: rounds to even (1.0)
+    t = _nhwc(x, dev)
+    out = hip.to_half_planar(t, cg)
+    got = out.buf.flatten()                                     # (the window's flat half buffer)
+    assert got.dtype == torch.float16 and got.numel() == 2 * c * h * w
+    want = x.half().view(2, c // cg, cg, h, w).permute(0, 1, 3, 4, 2).contiguous().flatten()
+    assert torch.equal(got.cpu(), want)
 
 
 def test_quantize_mask(dev):

@@ -1,8 +1,8 @@
 // Modulated deformable 3x3 convolution (torchvision.ops.deform_conv2d semantics) for the ICIP2024 OffsetDiversity
 // fusion (ICIP2024/src/model/helpers.py:35-58).  Gather-bound, not matrix-bound: per output pixel and group the
-// kernel samples 9 taps x 4 corners x cg channels (cg = 8..16 contiguous floats in NHWC) and contracts them with
-// 9*cg*og weights held in LDS; one lane owns one (pixel, group) pair and the group index is uniform per wave
-// (broadcast LDS reads of the weights).  The offset/mask preparation of OffsetDiversity.prep (tanh *
+// kernel samples 9 taps x 4 corners x cg channels (cg = 8..16 contiguous values) and contracts them with
+// 9*cg*og weights; one lane owns one (pixel, group) pair and the group index is uniform per wave
+// (the vector path reads the weights through the scalar cache, the scalar path from LDS).  The offset/mask preparation of OffsetDiversity.prep (tanh *
 // magnitude + flipped flow, sigmoid) is folded into the offset fetch in the fused entry point.
 #include "common.h"
 
@@ -17,13 +17,40 @@ struct DeformArgs {
     const float *wpk, *bias;
     float magnitude;
     int groups;
-    int x_half;            // fp16 path: x1 / x2 point at half-precision features (strides in elements)
+    int x_half;            // fp16 path: x1 / x2 point at half-precision features (strides in elements); 2: group-planar ones
+    int twl;               // log2 of the pixel tile's width: a wave's 64 lanes are a (64 >> twl) x (1 << twl) tile
+    unsigned gstride;      // vector path: bytes from one group's channels to the next one's (cg * element size; planar: h * w * cg * 2)
 };
 
-// One workgroup = one 8x8 pixel tile x all G/2 groups of ONE reference (wave w <-> group w of that half): the
+// Branch-free tanh / logistic for the half-precision vector path: the library's tanhf spelled out (its polynomial below 0.625,
+// 1 - 2 / (e^2|x| + 1) with the library's expf and the hardware reciprocal above) as ONE straight-line sequence with a select
+// instead of two branch sides that a divergent wave both runs -- the same bits as tanhf, which the fp32 instances call; the
+// logistic is their expression too.  (tests/test_icip2024_gpu.py holds the two instances together at 1e-6.)
+__device__ __forceinline__ float tanh_bf(float x)
+{
+    const float ax = fabsf(x), x2 = x * x;
+    const float big = fmaf(__builtin_amdgcn_rcpf(expf(2.0f * ax) + 1.0f), -2.0f, 1.0f);   // e^(2|x|) = +inf for large |x| -> 1
+    float p = fmaf(x2, -0x1.758e7ap-8f, 0x1.521192p-6f);
+    p = fmaf(x2, p, -0x1.b8389cp-5f);
+    p = fmaf(x2, p, 0x1.110704p-3f);
+    p = fmaf(x2, p, -0x1.555532p-2f);
+    const float small = fmaf(x2, ax * p, ax);
+    return copysignf(ax < 0.625f ? small : big, x);                            // (NaN: the comparison is false, `big` is NaN)
+}
+
+__device__ __forceinline__ float sigmoid_bf(float x)
+{
+    return 1.0f / (1.0f + expf(-x));
+}
+
+// One workgroup = one 4 x 16 pixel tile (args.twl) x all G/2 groups of ONE reference (wave w <-> group w of that half): the
 // waves of a workgroup then consume every channel of the 128-byte lines they pull in (a group alone uses only
 // cg of the C channels of a pixel), and the per-pixel offset/mask record of that reference is read completely
 // by the workgroup.  Lanes of a wave are the 64 pixels of the tile, so the group (and its weights) is wave-uniform.
+// With pixel-interleaved features every lane of a gather meets its own 128-byte line (a pixel is C * 2 or C * 4 bytes);
+// the fp16 path therefore gathers from GROUP-PLANAR half features (vc_to_half_planar, vc_offset_diversity_hxp: one group's
+// cg halves of neighbouring pixels are neighbours in memory), 8-16 lines per gather when neighbouring pixels sample
+// neighbouring positions: 3.21 -> 2.10 ms on the 128 -> 64 fusion @1088x1920 of the configs[4] frame, bit-identical results.
 // MAXT: 512 when the half has at most 8 groups (the ICIP2024 model: 16 groups) -- leaves the register file for the batched
 // gathers; 1024 (up to 16 groups per half) keeps 128 registers and gathers one tap at a time.
 template <int CG, int OG, bool FUSED, bool VEC, int RV = 1, int MAXT = 1024, bool XH = false>
@@ -35,7 +62,9 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
     const int n = blockIdx.z;
     const int nthreads = 64 * half;
     const float *wsrc = a.wpk + (long long)(second ? half : 0) * 9 * CG * OG;
-    for (int i = threadIdx.x; i < half * 9 * CG * OG; i += nthreads) wsm_all[i] = wsrc[i];
+    constexpr bool WLDS = !(VEC && XH);                // (the half-precision vector path reads its group's weights through the scalar cache)
+    if constexpr (WLDS)
+        for (int i = threadIdx.x; i < half * 9 * CG * OG; i += nthreads) wsm_all[i] = wsrc[i];
     const int gl = threadIdx.x >> 6;                  // group inside its half == wave index
     const int g = second ? gl + half : gl;
     const int lane = threadIdx.x & 63;
@@ -45,14 +74,15 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
     const vc_view &M = second ? a.msk2 : a.msk1;
     const vc_view &FL = second ? a.flow2 : a.flow1;
     const int H = a.out.h, W = a.out.w;
-    const int tiles_x = (W + 7) >> 3;
-    const int ty0 = (blockIdx.x / tiles_x) * 8, tx0 = (blockIdx.x % tiles_x) * 8;
-    const int y = ty0 + (lane >> 3), x = tx0 + (lane & 7);
+    const int twl = a.twl, twm = (1 << twl) - 1;
+    const int tiles_x = (W + twm) >> twl;
+    const int ty0 = (blockIdx.x / tiles_x) * (64 >> twl), tx0 = (blockIdx.x % tiles_x) << twl;
+    const int y = ty0 + (lane >> twl), x = tx0 + (lane & twm);
     // FUSED: the 27*half-float offset/mask record of each of the 64 pixels is fetched ONCE by the workgroup with
     // coalesced loads (a lane reading its own 18+9 values straight from global touches 27 separate 4-byte words
     // 1.7 KB apart from its neighbours': 1.4 of 3.2 ms at 544x960) and parked in LDS at an odd pixel stride.
     const int RS = 27 * half + 1;                      // record stride in floats (odd for half = 8: 217)
-    float *rec = wsm_all + half * 9 * CG * OG;
+    float *rec = wsm_all + (WLDS ? half * 9 * CG * OG : 0);
     if (FUSED) {
         // `half` threads per pixel, thread s of a pixel takes the RV-float pieces s, s + half, ... of its record: a wave
         // instruction reads whole contiguous stretches (128 bytes per pixel for RV = 4, half = 8), and the (27 + RV - 1) / RV
@@ -61,7 +91,7 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
         constexpr int IT = (27 + RV - 1) / RV;
         const int per_px = 27 * half, pieces = per_px / RV;           // per_px % RV == 0 (checked by the launcher)
         const int px = threadIdx.x / half, s = threadIdx.x - px * half;
-        const int yy = min(ty0 + (px >> 3), H - 1), xx = min(tx0 + (px & 7), W - 1);
+        const int yy = min(ty0 + (px >> twl), H - 1), xx = min(tx0 + (px & twm), W - 1);
         const float *src = O.p + view_off(O, n, yy, xx);
         float v[IT][RV];
 #pragma unroll
@@ -141,7 +171,116 @@ __global__ void __launch_bounds__(MAXT) k_deform(DeformArgs a)
         q.p1 = xbase + r0 + c0, q.p2 = xbase + r0 + c1, q.p3 = xbase + r1 + c0, q.p4 = xbase + r1 + c1;
         return q;
     };
-    if constexpr (VEC) {
+    if constexpr (VEC && XH) {
+        // Half-precision features (round 6).  The round-5 form of this path issued ~3 200 vector instructions per (pixel, group):
+        // 12 of every 356 per tap quarter-rate 64-bit multiplies of the address arithmetic, ~95 the two library tanhf calls (both
+        // sides of their branch run in a divergent wave).  Here ~1 700: 32-bit byte offsets from a wave-uniform base (24-bit
+        // multiplies; the launcher refuses images above 4 GiB), branch-free tanh (the library's arithmetic, both sides computed,
+        // one select), the out-of-image zeroing on the four bilinear weights instead of the gathered values, two channels per
+        // packed-fp32 instruction, the group's weights through the scalar cache (wave-uniform: no LDS, no vector registers).
+        // That alone bought 3 % (3.34 -> 3.22 ms, C = 64 @1088x1920): the kernel is bound by its gathers, by how many cache lines
+        // each one meets -- what pays is the group-planar layout of the features (a.gstride; 3.22 -> 2.36 ms), and NOT more gathers
+        // in flight: a fence that issues a whole batch before its first use costs 30 %.
+#ifndef VC_DEFORM_TB
+#define VC_DEFORM_TB 3
+#endif
+        constexpr int TB = (MAXT > 512 || CG > 8) ? 1 : VC_DEFORM_TB;       // taps per batch (divides 9; one tap per batch measured 5 % slower)
+        constexpr int V = (CG + 7) / 8;                          // gathers per corner: 16 bytes each; CG % 8 == 4: the last one 8 bytes
+        constexpr int EPV = 8;                                   // channels per gather
+        constexpr bool TAIL8 = (CG % 8) == 4;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const unsigned char *xb = reinterpret_cast<const unsigned char *>(X.p) + (long long)n * X.sn * ESZ;      // wave-uniform
+        const unsigned rowB = (unsigned)(X.sh * ESZ), pixB = (unsigned)(X.sw * ESZ), goff = (unsigned)gl * a.gstride;
+        const int gu = __builtin_amdgcn_readfirstlane(g);
+        const float *wg = a.wpk + (long long)gu * 9 * CG * OG;
+        struct TapV {
+            unsigned o1, o2, o3, o4;
+            float w1, w2, w3, w4, m;
+        };
+        auto tapv = [&](int k) {
+            TapV q;
+            float dy = op[2 * k], dx = op[2 * k + 1], m = 1.0f;
+            if (FUSED) {
+                dy = fmaf(tanh_bf(dy), a.magnitude, fv);          // flow.flip(1): (v, u) pairs with (dy, dx)
+                dx = fmaf(tanh_bf(dx), a.magnitude, fu);
+                m = sigmoid_bf(mp[k]);
+            } else if (mp) {
+                m = mp[k];
+            }
+            const float py = (float)(y - 1 + k / 3) + dy;
+            const float px = (float)(x - 1 + k % 3) + dx;
+            const bool ok = py > -1.0f && py < (float)H && px > -1.0f && px < (float)W;      // also rejects NaN
+            const float fy = floorf(py), fx = floorf(px);
+            const int y0 = ok ? (int)fy : 0, x0 = ok ? (int)fx : 0, y1 = y0 + 1, x1 = x0 + 1;
+            const float lh = py - fy, lw = px - fx, hh = 1.0f - lh, hw = 1.0f - lw;
+            const bool t = y0 >= 0, b = y1 <= H - 1, l = x0 >= 0, r = x1 <= W - 1;
+            // (a corner -- or a whole tap -- outside the image: address clamped into the image, WEIGHT zero; a NaN position ends here too)
+            q.w1 = (ok && t && l) ? hh * hw : 0.0f, q.w2 = (ok && t && r) ? hh * lw : 0.0f;
+            q.w3 = (ok && b && l) ? lh * hw : 0.0f, q.w4 = (ok && b && r) ? lh * lw : 0.0f;
+            q.m = m;
+            const unsigned r0 = __umul24((unsigned)max(y0, 0), rowB) + goff, r1 = __umul24((unsigned)min(y1, H - 1), rowB) + goff;
+            const unsigned c0 = __umul24((unsigned)max(x0, 0), pixB), c1 = __umul24((unsigned)min(x1, W - 1), pixB);
+            q.o1 = r0 + c0, q.o2 = r0 + c1, q.o3 = r1 + c0, q.o4 = r1 + c1;
+            return q;
+        };
+        f32x2 acc2[OG / 2];
+#pragma unroll
+        for (int o = 0; o < OG / 2; ++o) acc2[o] = f32x2{acc[2 * o], acc[2 * o + 1]};
+#pragma unroll 1
+        for (int k0 = 0; k0 < 9; k0 += TB) {     // (rolled: unrolled, the compiler hoists all 9 * CG * OG weight reads and spills)
+            TapV q[TB];
+            f32x4 v[TB][4][V];
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                q[j] = tapv(k0 + j);
+#pragma unroll
+                for (int c = 0; c < V; ++c) {
+                    if (TAIL8 && c == V - 1) {
+                        const float2 t1 = *reinterpret_cast<const float2 *>(xb + (size_t)(q[j].o1 + 16 * c)), t2 = *reinterpret_cast<const float2 *>(xb + (size_t)(q[j].o2 + 16 * c));
+                        const float2 t3 = *reinterpret_cast<const float2 *>(xb + (size_t)(q[j].o3 + 16 * c)), t4 = *reinterpret_cast<const float2 *>(xb + (size_t)(q[j].o4 + 16 * c));
+                        v[j][0][c] = f32x4{t1.x, t1.y, 0.f, 0.f}, v[j][1][c] = f32x4{t2.x, t2.y, 0.f, 0.f};
+                        v[j][2][c] = f32x4{t3.x, t3.y, 0.f, 0.f}, v[j][3][c] = f32x4{t4.x, t4.y, 0.f, 0.f};
+                    } else {
+                        v[j][0][c] = *reinterpret_cast<const f32x4 *>(xb + (size_t)(q[j].o1 + 16 * c));
+                        v[j][1][c] = *reinterpret_cast<const f32x4 *>(xb + (size_t)(q[j].o2 + 16 * c));
+                        v[j][2][c] = *reinterpret_cast<const f32x4 *>(xb + (size_t)(q[j].o3 + 16 * c));
+                        v[j][3][c] = *reinterpret_cast<const f32x4 *>(xb + (size_t)(q[j].o4 + 16 * c));
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const float *wk = wg + (k0 + j) * CG * OG;
+                const f32x2 w1 = {q[j].w1, q[j].w1}, w2 = {q[j].w2, q[j].w2}, w3 = {q[j].w3, q[j].w3}, w4 = {q[j].w4, q[j].w4}, mm = {q[j].m, q[j].m};
+#pragma unroll
+                for (int c = 0; c < V; ++c) {
+#pragma unroll
+                    for (int e = 0; e < ((TAIL8 && c == V - 1) ? 4 : EPV); e += 2) {
+                        const h8 h1 = __builtin_bit_cast(h8, v[j][0][c]), h2 = __builtin_bit_cast(h8, v[j][1][c]);
+                        const h8 h3 = __builtin_bit_cast(h8, v[j][2][c]), h4 = __builtin_bit_cast(h8, v[j][3][c]);
+                        const f32x2 e1 = {(float)h1[e], (float)h1[e + 1]}, e2 = {(float)h2[e], (float)h2[e + 1]};
+                        const f32x2 e3 = {(float)h3[e], (float)h3[e + 1]}, e4 = {(float)h4[e], (float)h4[e + 1]};
+                        f32x2 val = e1 * w1;
+                        val = __builtin_elementwise_fma(e2, w2, val);
+                        val = __builtin_elementwise_fma(e3, w3, val);
+                        val = __builtin_elementwise_fma(e4, w4, val) * mm;
+                        const float *wc = wk + (EPV * c + e) * OG;
+#pragma unroll
+                        for (int o = 0; o < OG / 2; ++o) {
+                            acc2[o] = __builtin_elementwise_fma(f32x2{wc[2 * o], wc[2 * o + 1]}, f32x2{val.x, val.x}, acc2[o]);
+                            acc2[o] = __builtin_elementwise_fma(f32x2{wc[OG + 2 * o], wc[OG + 2 * o + 1]}, f32x2{val.y, val.y}, acc2[o]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OG / 2; ++o) acc[2 * o] = acc2[o].x, acc[2 * o + 1] = acc2[o].y;
+    } else if constexpr (VEC) {
+        // fp32 features: the round-2 form (64-bit addresses, library tanhf / expf, weights from LDS).  The half-precision form above
+        // measured 7-30 % SLOWER here on the same box (1.47 / 0.63 / 0.19 ms against 1.37 / 0.48 / 0.15 at the three ICIP2024 levels):
+        // its shorter instruction stream puts more gathers in flight at once, and this kernel loses L1 hits when it does.
         constexpr int TB = (MAXT > 512 || CG > 8) ? 1 : 3;       // taps per batch (divides 9): 12-24 16-byte gathers in flight per lane
         constexpr int V = XH ? (CG + 7) / 8 : CG / 4;            // gathers per corner: 16 bytes each; XH with CG % 8 == 4: the last one 8 bytes
         constexpr int EPV = XH ? 8 : 4;                          // channels per gather
@@ -222,13 +361,23 @@ inline bool aligned16(const vc_view &v)
     return (reinterpret_cast<uintptr_t>(v.p) % 16 == 0) && v.sn % 4 == 0 && v.sh % 4 == 0 && v.sw % 4 == 0;
 }
 
-template <int CG, int OG, bool FUSED> int launch(hipStream_t st, const DeformArgs &a, bool vec)
+template <int CG, int OG, bool FUSED> int launch(hipStream_t st, const DeformArgs &a_in, bool vec)
 {
+    DeformArgs a = a_in;
+    a.gstride = a.x_half == 2 ? (unsigned)((long long)a.x1.h * a.x1.sh * 2) : (unsigned)(CG * (a.x_half ? 2 : 4));
     const int half = a.groups / 2;
     if (half > 16) return VC_EINVAL;                       // one wave per group of a half, 1024 threads at most
-    const unsigned tiles = (unsigned)(((a.out.h + 7) / 8) * ((a.out.w + 7) / 8));
+    // pixels per wave: 4 x 16 on group-planar features, 8 x 8 on pixel-interleaved ones (measured against each other and 2 x 32, 1 x 64)
+    a.twl = a.x_half == 2 ? 4 : 3;
+    const int tw = 1 << a.twl, th = 64 >> a.twl;
+    const unsigned tiles = (unsigned)(((a.out.h + th - 1) / th) * ((a.out.w + tw - 1) / tw));
     const dim3 grid(tiles, 2u, (unsigned)a.out.n), block((unsigned)(64 * half));
-    const size_t lds = ((size_t)half * 9 * CG * OG + (FUSED ? 64 * (27 * half + 1) : 0)) * sizeof(float);
+    // half-precision features: 32-bit byte offsets inside one image of the features (24-bit row / pixel multiplies)
+    auto fits32 = [&](const vc_view &v) {
+        return (long long)v.h * v.sh * 2 * (a.x_half == 2 ? a.groups / 2 : 1) < (1ll << 32) && v.sh * 2 < (1ll << 24) && v.sw * 2 < (1ll << 24) && v.h < (1 << 24) && v.w < (1 << 24);
+    };
+    if (a.x_half && !(fits32(a.x1) && fits32(a.x2))) return VC_EINVAL;
+    const size_t lds = (((vec && a.x_half) ? (size_t)0 : (size_t)half * 9 * CG * OG) + (FUSED ? 64 * (27 * half + 1) : 0)) * sizeof(float);
     auto launch_one = [&](auto kern) {
         if (lds > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -335,12 +484,27 @@ extern "C" int vc_offset_diversity_hx(vc_stream s, vc_view x1, vc_view raw1, vc_
     return offset_diversity(s, x1, raw1, flow1, x2, raw2, flow2, magnitude, wpk, bias, groups, out, 1);
 }
 
+// The same on GROUP-PLANAR half features ([n][G/2][h][w][cg], vc_to_half_planar): x1 / x2 describe ONE group's plane (c = cg, sw = cg,
+// sh = w * cg, sn = (G/2) * h * w * cg; the planes of an image follow one another).  Neighbouring pixels of a group are then 2 * cg bytes
+// apart instead of a whole pixel: the 64 lanes of a gather (a 4 x 16 pixel tile of one group) meet 8-16 cache lines instead of 64.
+extern "C" int vc_offset_diversity_hxp(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2,
+                                       vc_view flow2, float magnitude, const float *wpk, const float *bias, int groups,
+                                       vc_view out)
+{
+    return offset_diversity(s, x1, raw1, flow1, x2, raw2, flow2, magnitude, wpk, bias, groups, out, 2);
+}
+
 static int offset_diversity(vc_stream s, vc_view x1, vc_view raw1, vc_view flow1, vc_view x2, vc_view raw2, vc_view flow2, float magnitude,
                             const float *wpk, const float *bias, int groups, vc_view out, int x_half)
 {
     if (!x1.p || !x2.p || !raw1.p || !raw2.p || !flow1.p || !flow2.p || !wpk || !out.p) return VC_EINVAL;
     if (groups < 2 || groups % 2) return VC_EINVAL;
     const int half = groups / 2;
+    if (x_half == 2) {          // planar: the views describe one group's plane
+        if (x1.c != x2.c || x1.sw != x1.c || x2.sw != x2.c || x1.sh != (long long)x1.w * x1.c || x2.sh != (long long)x2.w * x2.c) return VC_EINVAL;
+        if (x1.sn != (long long)half * x1.h * x1.sh || x2.sn != (long long)half * x2.h * x2.sh) return VC_EINVAL;
+        x1.c *= half, x2.c *= half;
+    }
     if (x1.c != x2.c || x1.c % half || out.c % groups || raw1.c != 27 * half || raw2.c != 27 * half) return VC_EINVAL;
     if (flow1.c < 2 || flow2.c < 2) return VC_EINVAL;
     const vc_view *vs[] = {&x1, &x2, &raw1, &raw2, &flow1, &flow2};

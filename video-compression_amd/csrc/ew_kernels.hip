@@ -525,6 +525,46 @@ extern "C" int vc_to_half(vc_stream s, vc_view a, void *out_half)
     return VC_OK;
 }
 
+// group-planar half copy: one thread per (pixel, group) in that order (group fastest): a wave reads whole pixels and writes
+// 64 / G pixels x cg halves contiguously into each of the G planes
+template <int CG> __global__ void k_to_half_planar(vc_view a, _Float16 *__restrict__ out)
+{
+    const int G = a.c / CG;
+    const long long total = (long long)a.n * a.h * a.w * G;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        long long t = i / G;
+        const int x = (int)(t % a.w); t /= a.w;
+        const int y = (int)(t % a.h);
+        const int n = (int)(t / a.h);
+        const float *src = a.p + view_off(a, n, y, x) + g * CG;
+        _Float16 *dst = out + ((((long long)n * G + g) * a.h + y) * a.w + x) * CG;
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < CG; c += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + c);
+            *reinterpret_cast<h4 *>(dst + c) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        }
+    }
+}
+
+// group-planar half-precision copy [n][c / cg][h][w][cg] of a channels-last window: the layout vc_offset_diversity_hxp gathers from
+extern "C" int vc_to_half_planar(vc_stream s, vc_view a, int cg, void *out_half)
+{
+    if (!a.p || !out_half || cg < 4 || (cg % 4) || (a.c % cg) || (a.sw % 4) || (a.sh % 4) || (a.sn % 4) || ((uintptr_t)a.p % 16) || ((uintptr_t)out_half % 8)) return VC_EINVAL;
+    const long long total = (long long)a.n * a.h * a.w * (a.c / cg);
+    _Float16 *o = static_cast<_Float16 *>(out_half);
+    switch (cg) {
+    case 4: hipLaunchKernelGGL(k_to_half_planar<4>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, o); break;
+    case 8: hipLaunchKernelGGL(k_to_half_planar<8>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, o); break;
+    case 12: hipLaunchKernelGGL(k_to_half_planar<12>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, o); break;
+    case 16: hipLaunchKernelGGL(k_to_half_planar<16>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, o); break;
+    default: return VC_EINVAL;
+    }
+    VC_LAUNCH_CHECK();
+    return VC_OK;
+}
+
 __global__ void k_channel_scale(vc_view a, const float *__restrict__ gain, vc_view out)
 {
     const long long total = (long long)out.n * out.h * out.w * out.c;

@@ -167,6 +167,8 @@ def lib():
     sig("vc_offset_diversity", ci, vp, View, View, View, View, View, View, cf, vp, vp, ci, View)
     sig("vc_offset_diversity_hx", ci, vp, View, View, View, View, View, View, cf, vp, vp, ci, View)
     sig("vc_to_half", ci, vp, View, vp)
+    sig("vc_offset_diversity_hxp", ci, vp, View, View, View, View, View, View, cf, vp, vp, ci, View)
+    sig("vc_to_half_planar", ci, vp, View, ci, vp)
     sig("vc_attention_gate", ci, vp, View, View, View, View)
     sig("vc_sse_clamp01", ci, vp, View, View, vp, ci)
     sig("vc_select_flow", ci, vp, vp, ci, ctypes.c_double, ctypes.POINTER(View), View, vp)
@@ -199,7 +201,7 @@ EXPORTED_SYMBOLS = [
     "vc_conv_pack_weights_split", "vc_split3", "vc_split3_pad", "vc_nchw_to_nhwc",
     "vc_nhwc_to_nchw", "vc_u8hwc_to_f32nchw_pad", "vc_f32nchw_to_u8hwc", "vc_avgpool_reflectpad", "vc_maxpool2", "vc_maxpool2_sp3", "vc_avgpool2_sp3", "vc_upsample_bilinear", "vc_upsample_bilinear_sp3", "vc_axpby", "vc_clamp01", "vc_channel_scale", "vc_warp",
     "vc_spynet_preprocess", "vc_spynet_level_input", "vc_spynet_level_input_sp3", "vc_lhbdc_blend", "vc_flex_blend",
-    "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half",
+    "vc_flex_motion_split", "vc_quantize_mask", "vc_deform_pack_weights", "vc_deform_conv2d", "vc_offset_diversity", "vc_offset_diversity_hx", "vc_to_half", "vc_offset_diversity_hxp", "vc_to_half_planar",
     "vc_attention_gate", "vc_sse_clamp01", "vc_select_flow", "vc_eb_forward", "vc_eb_dequant", "vc_gc_forward", "vc_gc_indexes", "vc_refine_scales",
     "vc_refine_y_symbols", "vc_refine_z_symbols", "vc_gc_dequant", "vc_bits_reduce", "vc_bits_slots", "vc_psnr_uint8", "vc_pmf_to_quantized_cdf", "vc_rans_bound",
     "vc_rans_encode_with_indexes", "vc_rans_decode_with_indexes", "vc_rans_decode_stream",
@@ -379,6 +381,7 @@ FUSE_TAIL = bool(int(os.environ.get("VC_FUSE_TAIL", "1")))
 # group: one 16-byte gather per corner instead of two; the kernel is bound by its gathers).  Offsets, modulation, bilinear
 # weights and accumulation stay fp32.  VC_HALF_DEFORM=0 gathers fp32 features (A/B, tests).
 HALF_DEFORM = bool(int(os.environ.get("VC_HALF_DEFORM", "1")))
+HALF_DEFORM_PLANAR = bool(int(os.environ.get("VC_HALF_DEFORM_PLANAR", "1")))   # group-planar half features under the deformable gathers
 # Bitstream paths (compress / decompress): scales within SCALE_REFINE_EPS (relative) of a scale-table entry are recomputed in fp64
 # from the last hyper-synthesis layer's input (vc_refine_scales): this side's table indexes stop depending on its summation order.
 # VC_SCALE_REFINE=0 keeps the plain fp32 scales (A/B, tests).
@@ -868,6 +871,13 @@ def to_half(x):
     return out
 
 
+def to_half_planar(x, cg):
+    """Group-planar half-precision copy [n][c / cg][h][w][cg] of a channels-last fp32 window (vc_to_half_planar)."""
+    out = T.empty(x.n, x.h, x.w, x.c, x.buf.device, "f16")
+    check(lib().vc_to_half_planar(stream(), x.view(), int(cg), out.ptr), "vc_to_half_planar")
+    return out
+
+
 def clamp01(x, out=None):
     """clamp(x, 0, 1) of a channels-last window (``torch.clamp(x_hat, 0, 1)`` of ICIP2024/src/test.py:94 on the device path)."""
     if out is None:
@@ -1004,14 +1014,21 @@ class PackedDeform:
                   and raw2.c % 4 == 0 and x1.dtype == "f32" and x2.dtype == "f32"
                   and all(t.ptr % 16 == 0 and t.sw % 4 == 0 and t.sh % 4 == 0 and t.sn % 4 == 0 and t.c % 4 == 0 for t in (x1, x2))
                   and all(t.ptr % 16 == 0 and t.sw % 4 == 0 and t.sh % 4 == 0 and t.sn % 4 == 0 for t in (raw1, raw2)))
-        if half_x:
+        planar = half_x and HALF_DEFORM_PLANAR
+        if planar:
+            n_, h_, w_ = x1.n, x1.h, x1.w
+            p1, p2 = to_half_planar(x1, cg), to_half_planar(x2, cg)
+            hg = self.groups // 2
+            v1 = View(p1.ptr, n_, h_, w_, cg, hg * h_ * w_ * cg, w_ * cg, cg)
+            v2 = View(p2.ptr, n_, h_, w_, cg, hg * h_ * w_ * cg, w_ * cg, cg)
+        elif half_x:
             x1, x2 = to_half(x1), to_half(x2)
-        fn = lib().vc_offset_diversity_hx if half_x else lib().vc_offset_diversity
+        fn = lib().vc_offset_diversity_hxp if planar else (lib().vc_offset_diversity_hx if half_x else lib().vc_offset_diversity)
 
         def launch():
-            check(fn(stream(), x1.view(True), raw1.view(), flow1.view(), x2.view(True), raw2.view(),
+            check(fn(stream(), v1 if planar else x1.view(True), raw1.view(), flow1.view(), v2 if planar else x2.view(True), raw2.view(),
                      flow2.view(), float(magnitude), self.wpk.data_ptr(), self._bias_ptr(),
-                     self.groups, out.view()), "vc_offset_diversity_hx" if half_x else "vc_offset_diversity")
+                     self.groups, out.view()), "vc_offset_diversity_hxp" if planar else ("vc_offset_diversity_hx" if half_x else "vc_offset_diversity"))
         if timer is None:
             launch()
         else:
