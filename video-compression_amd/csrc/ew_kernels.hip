@@ -8,6 +8,60 @@
 #define EW_BLOCK 256
 
 // ------------------------------------------------------------------------------------------------
+// Row-mapped indexing (round 6).  The grid-stride form below every kernel of this file started with -- a 64-bit linear index
+// taken apart by three 64-bit divisions per element -- costs ~300 vector instructions per element, more than the element's own
+// work (k_axpby, one float per thread, was 4.8 % of the configs[4] frame).  ROWS: blockIdx.z = image, blockIdx.y = row, the threads
+// of blockIdx.x walk the w * per_px work items of the row; item -> (x, c) by ONE multiply-high with a host-made reciprocal
+// (exact while item * per_px < 2^32; vc_rowmap_make checks it).  The linear form stays as the fallback for shapes outside that.
+// The body of a kernel is the same lambda under both forms: same arithmetic per element, same bits.
+// ------------------------------------------------------------------------------------------------
+struct vc_rowmap {
+    unsigned items, per_px, magic;
+};
+
+static inline bool vc_rowmap_make(vc_rowmap &m, int n, int h, int w, int per_px)
+{
+    if (n < 1 || h < 1 || w < 1 || per_px < 1 || n > 65535 || h > 65535) return false;
+    const unsigned long long items = (unsigned long long)w * (unsigned long long)per_px;
+    if (items >= (1ull << 24) || items * (unsigned long long)per_px >= (1ull << 32)) return false;
+    m.items = (unsigned)items;
+    m.per_px = (unsigned)per_px;
+    m.magic = per_px == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned long long)per_px) + 1u;
+    return true;
+}
+
+template <bool ROWS, class F>
+__device__ __forceinline__ void ew_for_each(const vc_rowmap &m, int N, int H, int W, int PP, F f)
+{
+    if constexpr (ROWS) {
+        const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+        if (j >= m.items) return;
+        const unsigned x = m.per_px == 1 ? j : __umulhi(j, m.magic);
+        f((int)blockIdx.z, (int)blockIdx.y, (int)x, (int)(j - __umul24(x, m.per_px)));
+    } else {
+        const long long total = (long long)N * H * W * PP;
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % PP);
+            long long t = i / PP;
+            const int x = (int)(t % W); t /= W;
+            const int y = (int)(t % H);
+            const int n = (int)(t / H);
+            f(n, y, x, c);
+        }
+    }
+}
+
+// launch `rows` (the ROWS = true instance) on the row grid when the shape allows it, `lin` (ROWS = false) on the grid-stride grid otherwise
+#define VC_EW_LAUNCH(st, KERN, N, H, W, PP, ...)                                                                                   \
+    do {                                                                                                                           \
+        vc_rowmap m_;                                                                                                              \
+        if (vc_rowmap_make(m_, (N), (H), (W), (PP)))                                                                               \
+            KERN<true><<<dim3((m_.items + EW_BLOCK - 1) / EW_BLOCK, (unsigned)(H), (unsigned)(N)), dim3(EW_BLOCK), 0, (st)>>>(__VA_ARGS__, m_); \
+        else                                                                                                                       \
+            KERN<false><<<dim3(ew_grid((long long)(N) * (H) * (W) * (PP), EW_BLOCK)), dim3(EW_BLOCK), 0, (st)>>>(__VA_ARGS__, vc_rowmap{0, 0, 0}); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
 // layout conversion
 // ------------------------------------------------------------------------------------------------
 __global__ void k_nchw_to_nhwc(const float *__restrict__ src, vc_view d)
@@ -102,24 +156,18 @@ extern "C" int vc_nhwc_to_nchw(vc_stream s, vc_view src, float *dst)
 // ------------------------------------------------------------------------------------------------
 // pooling
 // ------------------------------------------------------------------------------------------------
-__global__ void k_avgpool_reflectpad(vc_view in, vc_view out, int k, float scale)
+template <bool ROWS> __global__ void k_avgpool_reflectpad(vc_view in, vc_view out, int k, float scale, vc_rowmap m)
 {
     const int hp = in.h / k, wp = in.w / k;  // pooled size before padding
     const float inv = 1.0f / (float)(k * k);
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        long long t = i / out.c;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c, [&](int n, int y, int x, int c) {
         const int py = y < hp ? y : 2 * (hp - 1) - y;  // ReflectionPad2d bottom/right
         const int px = x < wp ? x : 2 * (wp - 1) - x;
         float sum = 0.0f;
         for (int dy = 0; dy < k; ++dy)
             for (int dx = 0; dx < k; ++dx) sum += in.p[view_off(in, n, py * k + dy, px * k + dx) + c];
         out.p[view_off(out, n, y, x) + c] = sum * inv * scale;
-    }
+    });
 }
 
 extern "C" int vc_avgpool_reflectpad(vc_stream s, vc_view in, vc_view out, int k, float scale)
@@ -127,43 +175,32 @@ extern "C" int vc_avgpool_reflectpad(vc_stream s, vc_view in, vc_view out, int k
     if (!in.p || !out.p || k < 1 || in.c != out.c || in.n != out.n) return VC_EINVAL;
     const int hp = in.h / k, wp = in.w / k;
     if (out.h < hp || out.w < wp || out.h - hp >= hp || out.w - wp >= wp) return VC_EINVAL;  // reflect needs pad < size
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    hipLaunchKernelGGL(k_avgpool_reflectpad, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out, k, scale);
+    if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_avgpool_reflectpad, out.n, out.h, out.w, out.c, in, out, k, scale);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
 
-__global__ void k_maxpool2(vc_view in, vc_view out)
+template <bool ROWS> __global__ void k_maxpool2(vc_view in, vc_view out, vc_rowmap m)
 {
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        long long t = i / out.c;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c, [&](int n, int y, int x, int c) {
         const float *p = in.p + view_off(in, n, 2 * y, 2 * x) + c;
         const float a = fmaxf(p[0], p[in.sw]);
         const float b = fmaxf(p[in.sh], p[in.sh + in.sw]);
         out.p[view_off(out, n, y, x) + c] = fmaxf(a, b);
-    }
+    });
 }
 
 // nn.MaxPool2d(2, 2) on a SPLIT tensor, split result (between the split-operand encoder layers of the mask U-Net, LHBDC/model/
 // layers.py:200,224-230): the pieces of a record sum to the exact fp32 value, the maximum is split again -- bit for bit what the fp32
 // kernel followed by vc_split3 gives.
-__global__ void k_maxpool2_sp3(const unsigned char *__restrict__ in, long long in_img_bytes, int n_img, int h, int w, int cg,
-                               unsigned char *__restrict__ out, long long out_img_bytes)
+template <bool ROWS> __global__ void k_maxpool2_sp3(const unsigned char *__restrict__ in, long long in_img_bytes, int n_img, int h, int w, int cg,
+                                                    unsigned char *__restrict__ out, long long out_img_bytes, vc_rowmap m)
 {
     const int oh = h >> 1, ow = w >> 1;
-    const long long total = (long long)n_img * cg * oh * ow * 2;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int half = (int)(i & 1);
-        long long t = i >> 1;
-        const int x = (int)(t % ow); t /= ow;
-        const int y = (int)(t % oh); t /= oh;
-        const int g = (int)(t % cg);
-        const int n = (int)(t / cg);
+    // "image" of the row map = (image, plane): its split is one division of a wave-uniform value per thread
+    ew_for_each<ROWS>(m, n_img * cg, oh, ow, 2, [&](int ng, int y, int x, int half) {
+        const int n = ng / cg, g = ng - n * cg;
         const unsigned char *b = in + n * in_img_bytes + (((long long)g * h + 2 * y) * w + 2 * x) * 48;
         const f32x4 a0 = vc_load_split4(b, half), a1 = vc_load_split4(b + 48, half);
         const f32x4 a2 = vc_load_split4(b + (long long)w * 48, half), a3 = vc_load_split4(b + (long long)w * 48 + 48, half);
@@ -171,23 +208,17 @@ __global__ void k_maxpool2_sp3(const unsigned char *__restrict__ in, long long i
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaxf(a0[e], a1[e]), fmaxf(a2[e], a3[e]));
         vc_store_split4(out + n * out_img_bytes + (((long long)g * oh + y) * ow + x) * 48, half, v);
-    }
+    });
 }
 
 // F.avg_pool2d(x, 2) on a SPLIT tensor (the skip tensor of a Flex-Rate U-Net level lives inside a split concat buffer and is pooled
 // from there: Flex.../b_model/unet.py:62-68), result split or fp32.  Same sum order and scaling as k_avgpool_reflectpad (k = 2).
-template <bool OSP> __global__ void k_avgpool2_sp3(const unsigned char *__restrict__ in, long long in_img_bytes, int n_img, int h, int w, int cg,
-                                                   float scale, unsigned char *__restrict__ out, long long out_img_bytes, vc_view of)
+template <bool OSP, bool ROWS> __global__ void k_avgpool2_sp3(const unsigned char *__restrict__ in, long long in_img_bytes, int n_img, int h, int w, int cg,
+                                                              float scale, unsigned char *__restrict__ out, long long out_img_bytes, vc_view of, vc_rowmap m)
 {
     const int oh = h >> 1, ow = w >> 1;
-    const long long total = (long long)n_img * cg * oh * ow * 2;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int half = (int)(i & 1);
-        long long t = i >> 1;
-        const int x = (int)(t % ow); t /= ow;
-        const int y = (int)(t % oh); t /= oh;
-        const int g = (int)(t % cg);
-        const int n = (int)(t / cg);
+    ew_for_each<ROWS>(m, n_img * cg, oh, ow, 2, [&](int ng, int y, int x, int half) {
+        const int n = ng / cg, g = ng - n * cg;
         const unsigned char *b = in + n * in_img_bytes + (((long long)g * h + 2 * y) * w + 2 * x) * 48;
         const f32x4 a0 = vc_load_split4(b, half), a1 = vc_load_split4(b + 48, half);
         const f32x4 a2 = vc_load_split4(b + (long long)w * 48, half), a3 = vc_load_split4(b + (long long)w * 48 + 48, half);
@@ -200,7 +231,7 @@ template <bool OSP> __global__ void k_avgpool2_sp3(const unsigned char *__restri
         }
         if (OSP) vc_store_split4(out + n * out_img_bytes + (((long long)g * oh + y) * ow + x) * 48, half, v);
         else *reinterpret_cast<f32x4 *>(of.p + view_off(of, n, y, x) + 8 * g + 4 * half) = v;
-    }
+    });
 }
 
 extern "C" int vc_avgpool2_sp3(vc_stream s, const void *in_split, long long in_image_bytes, int n, int h, int w, int c, float scale,
@@ -209,18 +240,23 @@ extern "C" int vc_avgpool2_sp3(vc_stream s, const void *in_split, long long in_i
     if (!in_split || n < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || (c % 8) || ((uintptr_t)in_split % 8) || (in_image_bytes % 8)) return VC_EINVAL;
     if ((out_split != nullptr) == (out_f32.p != nullptr)) return VC_EINVAL;            // exactly one result
     const long long ii = in_image_bytes ? in_image_bytes : (long long)(c / 8) * h * w * 48;
-    const long long total = (long long)n * (c / 8) * (h / 2) * (w / 2) * 2;
+    vc_rowmap m = {0, 0, 0};
+    const bool rows = vc_rowmap_make(m, n * (c / 8), h / 2, w / 2, 2);
+    const dim3 grid = rows ? dim3((m.items + EW_BLOCK - 1) / EW_BLOCK, (unsigned)(h / 2), (unsigned)(n * (c / 8)))
+                           : dim3(ew_grid((long long)n * (c / 8) * (h / 2) * (w / 2) * 2, EW_BLOCK));
+    const unsigned char *src = static_cast<const unsigned char *>(in_split);
     if (out_split) {
         if (((uintptr_t)out_split % 8) || (out_image_bytes % 8)) return VC_EINVAL;
         const long long oi = out_image_bytes ? out_image_bytes : (long long)(c / 8) * (h / 2) * (w / 2) * 48;
-        hipLaunchKernelGGL(k_avgpool2_sp3<true>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s),
-                           static_cast<const unsigned char *>(in_split), ii, n, h, w, c / 8, scale, static_cast<unsigned char *>(out_split), oi, out_f32);
+        unsigned char *dst = static_cast<unsigned char *>(out_split);
+        if (rows) k_avgpool2_sp3<true, true><<<grid, dim3(EW_BLOCK), 0, as_stream(s)>>>(src, ii, n, h, w, c / 8, scale, dst, oi, out_f32, m);
+        else k_avgpool2_sp3<true, false><<<grid, dim3(EW_BLOCK), 0, as_stream(s)>>>(src, ii, n, h, w, c / 8, scale, dst, oi, out_f32, m);
     } else {
         if (out_f32.n != n || out_f32.h != h / 2 || out_f32.w != w / 2 || out_f32.c != c || (out_f32.sw % 4) || (out_f32.sh % 4) || (out_f32.sn % 4) ||
             ((uintptr_t)out_f32.p % 16))
             return VC_EINVAL;
-        hipLaunchKernelGGL(k_avgpool2_sp3<false>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s),
-                           static_cast<const unsigned char *>(in_split), ii, n, h, w, c / 8, scale, nullptr, 0, out_f32);
+        if (rows) k_avgpool2_sp3<false, true><<<grid, dim3(EW_BLOCK), 0, as_stream(s)>>>(src, ii, n, h, w, c / 8, scale, nullptr, 0, out_f32, m);
+        else k_avgpool2_sp3<false, false><<<grid, dim3(EW_BLOCK), 0, as_stream(s)>>>(src, ii, n, h, w, c / 8, scale, nullptr, 0, out_f32, m);
     }
     VC_LAUNCH_CHECK();
     return VC_OK;
@@ -234,9 +270,8 @@ extern "C" int vc_maxpool2_sp3(vc_stream s, const void *in_split, long long in_i
         return VC_EINVAL;
     const long long ii = in_image_bytes ? in_image_bytes : (long long)(c / 8) * h * w * 48;
     const long long oi = out_image_bytes ? out_image_bytes : (long long)(c / 8) * (h / 2) * (w / 2) * 48;
-    const long long total = (long long)n * (c / 8) * (h / 2) * (w / 2) * 2;
-    hipLaunchKernelGGL(k_maxpool2_sp3, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), static_cast<const unsigned char *>(in_split), ii,
-                       n, h, w, c / 8, static_cast<unsigned char *>(out_split), oi);
+    VC_EW_LAUNCH(as_stream(s), k_maxpool2_sp3, n * (c / 8), h / 2, w / 2, 2, static_cast<const unsigned char *>(in_split), ii,
+                 n, h, w, c / 8, static_cast<unsigned char *>(out_split), oi);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -271,8 +306,8 @@ extern "C" int vc_maxpool2(vc_stream s, vc_view in, vc_view out)
         VC_LAUNCH_CHECK();
         return VC_OK;
     }
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    hipLaunchKernelGGL(k_maxpool2, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out);
+    if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_maxpool2, out.n, out.h, out.w, out.c, in, out);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -299,15 +334,9 @@ __device__ __forceinline__ void bilinear_src(int dst, int in_size, int out_size,
     l0 = 1.0f - l1;
 }
 
-__global__ void k_upsample_bilinear(vc_view in, vc_view out, int factor, int align_corners, float scale)
+template <bool ROWS> __global__ void k_upsample_bilinear(vc_view in, vc_view out, int factor, int align_corners, float scale, vc_rowmap m)
 {
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        long long t = i / out.c;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c, [&](int n, int y, int x, int c) {
         int y0, y1, x0, x1;
         float ly0, ly1, lx0, lx1;
         bilinear_src(y, in.h, out.h, factor, align_corners, y0, y1, ly0, ly1);
@@ -317,7 +346,7 @@ __global__ void k_upsample_bilinear(vc_view in, vc_view out, int factor, int ali
         const float v10 = b[(long long)y1 * in.sh + (long long)x0 * in.sw], v11 = b[(long long)y1 * in.sh + (long long)x1 * in.sw];
         const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
         out.p[view_off(out, n, y, x) + c] = v * scale;
-    }
+    });
 }
 
 // one bilinear sample of 4 channels: ONE definition (contraction pinned off) shared by the fp32 and the split-tensor kernel, so that
@@ -333,16 +362,10 @@ __device__ __forceinline__ f32x4 bilinear4(const f32x4 &v00, const f32x4 &v01, c
 
 // 4 channels per lane (16-byte loads/stores) when the views allow it: the U-Net up-sampling layers move
 // hundreds of MB per call and are purely HBM-bound
-__global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int align_corners, float scale)
+template <bool ROWS> __global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int align_corners, float scale, vc_rowmap m)
 {
-    const int c4n = out.c >> 2;
-    const long long total = (long long)out.n * out.h * out.w * c4n;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
-        long long t = i / c4n;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c >> 2, [&](int n, int y, int x, int c4) {
+        const int c = 4 * c4;
         int y0, y1, x0, x1;
         float ly0, ly1, lx0, lx1;
         bilinear_src(y, in.h, out.h, factor, align_corners, y0, y1, ly0, ly1);
@@ -353,7 +376,7 @@ __global__ void k_upsample_bilinear_v4(vc_view in, vc_view out, int factor, int 
         const f32x4 v10 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x0 * in.sw);
         const f32x4 v11 = *reinterpret_cast<const f32x4 *>(b + (long long)y1 * in.sh + (long long)x1 * in.sw);
         *reinterpret_cast<f32x4 *>(out.p + view_off(out, n, y, x) + c) = bilinear4(v00, v01, v10, v11, lx0, lx1, ly0, ly1, scale);
-    }
+    });
 }
 
 // The same into a SPLIT tensor (the up-sampled half of a concat buffer a split-operand convolution reads: LHBDC/model/layers.py:
@@ -429,16 +452,11 @@ extern "C" int vc_upsample_bilinear(vc_stream s, vc_view in, vc_view out, int fa
 {
     if (!in.p || !out.p || factor < 1 || in.c != out.c || in.n != out.n) return VC_EINVAL;
     if (out.h != in.h * factor || out.w != in.w * factor) return VC_EINVAL;
-    if (view_vec4(in) && view_vec4(out)) {
-        const long long total4 = (long long)out.n * out.h * out.w * (out.c / 4);
-        hipLaunchKernelGGL(k_upsample_bilinear_v4, dim3(ew_grid(total4, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out,
-                           factor, align_corners, scale);
-        VC_LAUNCH_CHECK();
-        return VC_OK;
-    }
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    hipLaunchKernelGGL(k_upsample_bilinear, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out,
-                       factor, align_corners, scale);
+    if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
+    if (out.c % 4 == 0 && view_vec4(in) && view_vec4(out))
+        VC_EW_LAUNCH(as_stream(s), k_upsample_bilinear_v4, out.n, out.h, out.w, out.c / 4, in, out, factor, align_corners, scale);
+    else
+        VC_EW_LAUNCH(as_stream(s), k_upsample_bilinear, out.n, out.h, out.w, out.c, in, out, factor, align_corners, scale);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -446,19 +464,24 @@ extern "C" int vc_upsample_bilinear(vc_stream s, vc_view in, vc_view out, int fa
 // ------------------------------------------------------------------------------------------------
 // out = alpha*a + beta*b
 // ------------------------------------------------------------------------------------------------
-__global__ void k_axpby(vc_view a, vc_view b, vc_view out, float alpha, float beta)
+template <bool ROWS> __global__ void k_axpby(vc_view a, vc_view b, vc_view out, float alpha, float beta, vc_rowmap m)
 {
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        long long t = i / out.c;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c, [&](int n, int y, int x, int c) {
         float v = alpha * a.p[view_off(a, n, y, x) + c];
         if (b.p) v += beta * b.p[view_off(b, n, y, x) + c];
         out.p[view_off(out, n, y, x) + c] = v;
-    }
+    });
+}
+
+// 4 channels per thread (16-byte loads / stores) when the three views allow it; the same expression per value
+template <bool ROWS> __global__ void k_axpby_v4(vc_view a, vc_view b, vc_view out, float alpha, float beta, vc_rowmap m)
+{
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c >> 2, [&](int n, int y, int x, int c4) {
+        const int c = 4 * c4;
+        f32x4 v = alpha * *reinterpret_cast<const f32x4 *>(a.p + view_off(a, n, y, x) + c);
+        if (b.p) v += beta * *reinterpret_cast<const f32x4 *>(b.p + view_off(b, n, y, x) + c);
+        *reinterpret_cast<f32x4 *>(out.p + view_off(out, n, y, x) + c) = v;
+    });
 }
 
 extern "C" int vc_axpby(vc_stream s, vc_view a, vc_view b, vc_view out, float alpha, float beta)
@@ -466,23 +489,20 @@ extern "C" int vc_axpby(vc_stream s, vc_view a, vc_view b, vc_view out, float al
     if (!a.p || !out.p) return VC_EINVAL;
     if (a.h < out.h || a.w < out.w || a.c < out.c || a.n != out.n) return VC_EINVAL;
     if (b.p && (b.h < out.h || b.w < out.w || b.c < out.c || b.n != out.n)) return VC_EINVAL;
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    hipLaunchKernelGGL(k_axpby, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, b, out, alpha, beta);
+    if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
+    if (out.c % 4 == 0 && view_vec4(a) && view_vec4(out) && (!b.p || view_vec4(b)))
+        VC_EW_LAUNCH(as_stream(s), k_axpby_v4, out.n, out.h, out.w, out.c / 4, a, b, out, alpha, beta);
+    else
+        VC_EW_LAUNCH(as_stream(s), k_axpby, out.n, out.h, out.w, out.c, a, b, out, alpha, beta);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
 
-__global__ void k_clamp01(vc_view a, vc_view out)
+template <bool ROWS> __global__ void k_clamp01(vc_view a, vc_view out, vc_rowmap m)
 {
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        long long t = i / out.c;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c, [&](int n, int y, int x, int c) {
         out.p[view_off(out, n, y, x) + c] = fminf(fmaxf(a.p[view_off(a, n, y, x) + c], 0.0f), 1.0f);
-    }
+    });
 }
 
 // out = clamp(a, 0, 1): decoded frames before they serve as references (ICIP2024/src/test.py:94 `torch.clamp(x_hat, 0, 1)`)
@@ -490,28 +510,22 @@ extern "C" int vc_clamp01(vc_stream s, vc_view a, vc_view out)
 {
     if (!a.p || !out.p) return VC_EINVAL;
     if (a.h < out.h || a.w < out.w || a.c < out.c || a.n != out.n) return VC_EINVAL;
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    hipLaunchKernelGGL(k_clamp01, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, out);
+    if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_clamp01, out.n, out.h, out.w, out.c, a, out);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
 
 // 4 consecutive channels per thread: 16 bytes in, 8 bytes out
-__global__ void k_to_half(vc_view a, _Float16 *__restrict__ out)
+template <bool ROWS> __global__ void k_to_half(vc_view a, _Float16 *__restrict__ out, vc_rowmap m)
 {
-    const int c4 = a.c >> 2;
-    const long long total = (long long)a.n * a.h * a.w * c4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4) * 4;
-        long long t = i / c4;
-        const int x = (int)(t % a.w); t /= a.w;
-        const int y = (int)(t % a.h);
-        const int n = (int)(t / a.h);
-        const float4 v = *reinterpret_cast<const float4 *>(a.p + view_off(a, n, y, x) + c);
+    const int c4n = a.c >> 2;
+    ew_for_each<ROWS>(m, a.n, a.h, a.w, c4n, [&](int n, int y, int x, int c4) {
+        const float4 v = *reinterpret_cast<const float4 *>(a.p + view_off(a, n, y, x) + 4 * c4);
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const h4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        *reinterpret_cast<h4 *>(out + 4 * i) = hv;
-    }
+        *reinterpret_cast<h4 *>(out + 4 * ((((long long)n * a.h + y) * a.w + x) * c4n + c4)) = hv;
+    });
 }
 
 // dense half-precision copy of a channels-last window (round to nearest even, what an fp16-path layer does to its input
@@ -519,24 +533,18 @@ __global__ void k_to_half(vc_view a, _Float16 *__restrict__ out)
 extern "C" int vc_to_half(vc_stream s, vc_view a, void *out_half)
 {
     if (!a.p || !out_half || (a.c % 4) || (a.sw % 4) || (a.sh % 4) || (a.sn % 4) || ((uintptr_t)a.p % 16) || ((uintptr_t)out_half % 8)) return VC_EINVAL;
-    const long long total = (long long)a.n * a.h * a.w * (a.c / 4);
-    hipLaunchKernelGGL(k_to_half, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, static_cast<_Float16 *>(out_half));
+    if ((long long)a.n * a.h * a.w * a.c <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_to_half, a.n, a.h, a.w, a.c / 4, a, static_cast<_Float16 *>(out_half));
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
 
 // group-planar half copy: one thread per (pixel, group) in that order (group fastest): a wave reads whole pixels and writes
 // 64 / G pixels x cg halves contiguously into each of the G planes
-template <int CG> __global__ void k_to_half_planar(vc_view a, _Float16 *__restrict__ out)
+template <int CG, bool ROWS> __global__ void k_to_half_planar(vc_view a, _Float16 *__restrict__ out, vc_rowmap m)
 {
     const int G = a.c / CG;
-    const long long total = (long long)a.n * a.h * a.w * G;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % G);
-        long long t = i / G;
-        const int x = (int)(t % a.w); t /= a.w;
-        const int y = (int)(t % a.h);
-        const int n = (int)(t / a.h);
+    ew_for_each<ROWS>(m, a.n, a.h, a.w, G, [&](int n, int y, int x, int g) {
         const float *src = a.p + view_off(a, n, y, x) + g * CG;
         _Float16 *dst = out + ((((long long)n * G + g) * a.h + y) * a.w + x) * CG;
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -545,44 +553,48 @@ template <int CG> __global__ void k_to_half_planar(vc_view a, _Float16 *__restri
             const float4 v = *reinterpret_cast<const float4 *>(src + c);
             *reinterpret_cast<h4 *>(dst + c) = h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         }
-    }
+    });
 }
 
 // group-planar half-precision copy [n][c / cg][h][w][cg] of a channels-last window: the layout vc_offset_diversity_hxp gathers from
 extern "C" int vc_to_half_planar(vc_stream s, vc_view a, int cg, void *out_half)
 {
     if (!a.p || !out_half || cg < 4 || (cg % 4) || (a.c % cg) || (a.sw % 4) || (a.sh % 4) || (a.sn % 4) || ((uintptr_t)a.p % 16) || ((uintptr_t)out_half % 8)) return VC_EINVAL;
-    const long long total = (long long)a.n * a.h * a.w * (a.c / cg);
+    if (cg != 4 && cg != 8 && cg != 12 && cg != 16) return VC_EINVAL;
+    if ((long long)a.n * a.h * a.w * a.c <= 0) return VC_OK;
     _Float16 *o = static_cast<_Float16 *>(out_half);
+    vc_rowmap m = {0, 0, 0};
+    const bool rows = vc_rowmap_make(m, a.n, a.h, a.w, a.c / cg);
+    const dim3 grid = rows ? dim3((m.items + EW_BLOCK - 1) / EW_BLOCK, (unsigned)a.h, (unsigned)a.n)
+                           : dim3(ew_grid((long long)a.n * a.h * a.w * (a.c / cg), EW_BLOCK));
+#define VC_PLANAR_CASE(CG)                                                                       \
+    case CG:                                                                                     \
+        if (rows) k_to_half_planar<CG, true><<<grid, dim3(EW_BLOCK), 0, as_stream(s)>>>(a, o, m); \
+        else k_to_half_planar<CG, false><<<grid, dim3(EW_BLOCK), 0, as_stream(s)>>>(a, o, m);     \
+        break;
     switch (cg) {
-    case 4: hipLaunchKernelGGL(k_to_half_planar<4>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, o); break;
-    case 8: hipLaunchKernelGGL(k_to_half_planar<8>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, o); break;
-    case 12: hipLaunchKernelGGL(k_to_half_planar<12>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, o); break;
-    case 16: hipLaunchKernelGGL(k_to_half_planar<16>, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, o); break;
-    default: return VC_EINVAL;
+        VC_PLANAR_CASE(4)
+        VC_PLANAR_CASE(8)
+        VC_PLANAR_CASE(12)
+        VC_PLANAR_CASE(16)
     }
+#undef VC_PLANAR_CASE
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
 
-__global__ void k_channel_scale(vc_view a, const float *__restrict__ gain, vc_view out)
+template <bool ROWS> __global__ void k_channel_scale(vc_view a, const float *__restrict__ gain, vc_view out, vc_rowmap m)
 {
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        long long t = i / out.c;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c, [&](int n, int y, int x, int c) {
         out.p[view_off(out, n, y, x) + c] = gain[c] * a.p[view_off(a, n, y, x) + c];
-    }
+    });
 }
 
 extern "C" int vc_channel_scale(vc_stream s, vc_view a, const float *gain, vc_view out)
 {
     if (!a.p || !gain || !out.p || a.c < out.c || a.h < out.h || a.w < out.w || a.n != out.n) return VC_EINVAL;
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    hipLaunchKernelGGL(k_channel_scale, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, gain, out);
+    if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_channel_scale, out.n, out.h, out.w, out.c, a, gain, out);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -590,18 +602,12 @@ extern "C" int vc_channel_scale(vc_stream s, vc_view a, const float *gain, vc_vi
 // ------------------------------------------------------------------------------------------------
 // compressai.layers.AttentionBlock gate: out = a * sigmoid(b) + identity (ICIP2024 ELIC intra codec, elic.py:97-121)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_attention_gate(vc_view a, vc_view b, vc_view identity, vc_view out)
+template <bool ROWS> __global__ void k_attention_gate(vc_view a, vc_view b, vc_view identity, vc_view out, vc_rowmap m)
 {
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        long long t = i / out.c;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c, [&](int n, int y, int x, int c) {
         const float g = 1.0f / (1.0f + expf(-b.p[view_off(b, n, y, x) + c]));
         out.p[view_off(out, n, y, x) + c] = a.p[view_off(a, n, y, x) + c] * g + identity.p[view_off(identity, n, y, x) + c];
-    }
+    });
 }
 
 extern "C" int vc_attention_gate(vc_stream s, vc_view a, vc_view b, vc_view identity, vc_view out)
@@ -610,8 +616,8 @@ extern "C" int vc_attention_gate(vc_stream s, vc_view a, vc_view b, vc_view iden
     const vc_view *vs[] = {&a, &b, &identity};
     for (const vc_view *v : vs)
         if (v->n != out.n || v->h != out.h || v->w != out.w || v->c < out.c) return VC_EINVAL;
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    hipLaunchKernelGGL(k_attention_gate, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), a, b, identity, out);
+    if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_attention_gate, out.n, out.h, out.w, out.c, a, b, identity, out);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -619,15 +625,9 @@ extern "C" int vc_attention_gate(vc_stream s, vc_view a, vc_view b, vc_view iden
 // ------------------------------------------------------------------------------------------------
 // quantise + checkerboard mask (ICIP2024 compression_bottlenecks.py:237-246,268-269)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_quantize_mask(vc_view in, vc_view out, const float *__restrict__ gain, int keep_parity, int do_round)
+template <bool ROWS> __global__ void k_quantize_mask(vc_view in, vc_view out, const float *__restrict__ gain, int keep_parity, int do_round, vc_rowmap m)
 {
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        long long t = i / out.c;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, out.c, [&](int n, int y, int x, int c) {
         float v = 0.0f;
         if (keep_parity < 0 || ((x + y) & 1) == keep_parity) {
             v = in.p[view_off(in, n, y, x) + c];
@@ -635,16 +635,15 @@ __global__ void k_quantize_mask(vc_view in, vc_view out, const float *__restrict
             if (gain) v *= gain[c];
         }
         out.p[view_off(out, n, y, x) + c] = v;
-    }
+    });
 }
 
 extern "C" int vc_quantize_mask(vc_stream s, vc_view in, vc_view out, const float *gain, int keep_parity, int do_round)
 {
     if (!in.p || !out.p || in.c < out.c || in.h != out.h || in.w != out.w || in.n != out.n) return VC_EINVAL;
     if (keep_parity < -1 || keep_parity > 1) return VC_EINVAL;
-    const long long total = (long long)out.n * out.h * out.w * out.c;
-    hipLaunchKernelGGL(k_quantize_mask, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), in, out, gain,
-                       keep_parity, do_round);
+    if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_quantize_mask, out.n, out.h, out.w, out.c, in, out, gain, keep_parity, do_round);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
@@ -723,14 +722,9 @@ __global__ void k_warp(int convention, vc_view img, vc_view flow, vc_view out)
 // frames (3 channels, or any count not a multiple of 4 up to 4): one thread per PIXEL -- the flow vector is read and the grid
 // coordinate computed once per pixel instead of once per channel, neighbouring lanes read neighbouring pixels.  Same
 // arithmetic per value (sample_bilinear per channel).
-__global__ void k_warp_px(int convention, vc_view img, vc_view flow, vc_view out)
+template <bool ROWS> __global__ void k_warp_px(int convention, vc_view img, vc_view flow, vc_view out, vc_rowmap m)
 {
-    const long long total = (long long)out.n * out.h * out.w;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % out.w);
-        long long t = i / out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, 1, [&](int n, int y, int x, int) {
         const float *f = flow.p + view_off(flow, n, y, x);
         const float gx = grid_coord(convention, x, f[0], flow.w, img.w);
         const float gy = grid_coord(convention, y, f[1], flow.h, img.h);
@@ -738,23 +732,18 @@ __global__ void k_warp_px(int convention, vc_view img, vc_view flow, vc_view out
         for (int c = 0; c < out.c; ++c)
             o[c] = sample_bilinear(img.p + (long long)n * img.sn + c, img.sh, img.sw, img.h, img.w, gx, gy,
                                    convention != VC_WARP_W2, convention == VC_WARP_W3);
-    }
+    });
 }
 
 // 4 channels per thread: the sample position and the bilinear weights are computed once per 16 bytes (feature maps
 // of 64-128 channels in ICIP2024 made the scalar version recompute them per element).  Same arithmetic per value.
-__global__ void k_warp_v4(int convention, vc_view img, vc_view flow, vc_view out)
+template <bool ROWS> __global__ void k_warp_v4(int convention, vc_view img, vc_view flow, vc_view out, vc_rowmap m)
 {
     const int c4n = out.c >> 2;
-    const long long total = (long long)out.n * out.h * out.w * c4n;
     const bool border = convention != VC_WARP_W2, ac = convention == VC_WARP_W3;
     const int H = img.h, W = img.w;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
-        long long t = i / c4n;
-        const int x = (int)(t % out.w); t /= out.w;
-        const int y = (int)(t % out.h);
-        const int n = (int)(t / out.h);
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, c4n, [&](int n, int y, int x, int c4) {
+        const int c = 4 * c4;
         const float *f = flow.p + view_off(flow, n, y, x);
         const float gx = grid_coord(convention, x, f[0], flow.w, img.w);
         const float gy = grid_coord(convention, y, f[1], flow.h, img.h);
@@ -779,7 +768,7 @@ __global__ void k_warp_v4(int convention, vc_view img, vc_view flow, vc_view out
         const f32x4 se = (x1ok && y1ok) ? *reinterpret_cast<const f32x4 *>(base + (long long)y1 * img.sh + (long long)x1 * img.sw) : z;
         const f32x4 r = nw * (s_ * e) + ne * (s_ * w) + sw_ * (nn * e) + se * (nn * w);
         *reinterpret_cast<f32x4 *>(out.p + view_off(out, n, y, x) + c) = r;
-    }
+    });
 }
 
 extern "C" int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, vc_view out)
@@ -790,9 +779,9 @@ extern "C" int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, v
     const long long total = (long long)out.n * out.h * out.w * out.c;
     if (total <= 0) return VC_OK;            // (an empty tensor: nothing to launch)
     if (out.c % 4 == 0 && view_vec4(img) && view_vec4(out))
-        hipLaunchKernelGGL(k_warp_v4, dim3(ew_grid(total / 4, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);
+        VC_EW_LAUNCH(as_stream(s), k_warp_v4, out.n, out.h, out.w, out.c / 4, convention, img, flow, out);
     else if (out.c <= 4)
-        hipLaunchKernelGGL(k_warp_px, dim3(ew_grid(total / out.c, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);
+        VC_EW_LAUNCH(as_stream(s), k_warp_px, out.n, out.h, out.w, 1, convention, img, flow, out);
     else
         hipLaunchKernelGGL(k_warp, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), convention, img, flow, out);
     VC_LAUNCH_CHECK();
@@ -1228,56 +1217,44 @@ extern "C" int vc_split3_pad(vc_stream s, vc_view a, void *out_split, long long 
 // ------------------------------------------------------------------------------------------------
 // blending
 // ------------------------------------------------------------------------------------------------
-__global__ void k_lhbdc_blend(vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid)
+template <bool ROWS> __global__ void k_lhbdc_blend(vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid, vc_rowmap m)
 {
-    const long long total = (long long)pred.n * pred.h * pred.w * 3;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % 3);
-        long long t = i / 3;
-        const int x = (int)(t % pred.w); t /= pred.w;
-        const int y = (int)(t % pred.h);
-        const int n = (int)(t / pred.h);
+    ew_for_each<ROWS>(m, pred.n, pred.h, pred.w, 3, [&](int n, int y, int x, int c) {
         const float m = mask.p[view_off(mask, n, y, x)];
         const float *f = fwbw.p + view_off(fwbw, n, y, x);
         const float pv = m * f[c] + (1.0f - m) * f[3 + c];   // m.py:65
         pred.p[view_off(pred, n, y, x) + c] = pv;
         if (resid.p) resid.p[view_off(resid, n, y, x) + c] = cur.p[view_off(cur, n, y, x) + c] - pv;
-    }
+    });
 }
 
 extern "C" int vc_lhbdc_blend(vc_stream s, vc_view fwbw, vc_view mask, vc_view cur, vc_view pred, vc_view resid)
 {
     if (!fwbw.p || !mask.p || !pred.p || fwbw.c < 6 || pred.c != 3) return VC_EINVAL;
     if (resid.p && !cur.p) return VC_EINVAL;
-    const long long total = (long long)pred.n * pred.h * pred.w * 3;
-    hipLaunchKernelGGL(k_lhbdc_blend, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), fwbw, mask, cur, pred, resid);
+    if ((long long)pred.n * pred.h * pred.w <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_lhbdc_blend, pred.n, pred.h, pred.w, 3, fwbw, mask, cur, pred, resid);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
 
-__global__ void k_flex_blend(vc_view xb, vc_view xa, vc_view mask, vc_view cur, vc_view pred, vc_view resid)
+template <bool ROWS> __global__ void k_flex_blend(vc_view xb, vc_view xa, vc_view mask, vc_view cur, vc_view pred, vc_view resid, vc_rowmap m)
 {
-    const long long total = (long long)pred.n * pred.h * pred.w * 3;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % 3);
-        long long t = i / 3;
-        const int x = (int)(t % pred.w); t /= pred.w;
-        const int y = (int)(t % pred.h);
-        const int n = (int)(t / pred.h);
+    ew_for_each<ROWS>(m, pred.n, pred.h, pred.w, 3, [&](int n, int y, int x, int c) {
         const float *m = mask.p + view_off(mask, n, y, x);
         const float w1 = 0.5f * m[0], w2 = 0.5f * m[1];    // b_model.py:70-71
         const float pv = (w1 * xb.p[view_off(xb, n, y, x) + c] + w2 * xa.p[view_off(xa, n, y, x) + c]) / (w1 + w2 + 1e-8f);
         pred.p[view_off(pred, n, y, x) + c] = pv;
         if (resid.p) resid.p[view_off(resid, n, y, x) + c] = cur.p[view_off(cur, n, y, x) + c] - pv;
-    }
+    });
 }
 
 extern "C" int vc_flex_blend(vc_stream s, vc_view xb, vc_view xa, vc_view mask, vc_view cur, vc_view pred, vc_view resid)
 {
     if (!xb.p || !xa.p || !mask.p || !pred.p || mask.c < 2 || pred.c != 3) return VC_EINVAL;
     if (resid.p && !cur.p) return VC_EINVAL;
-    const long long total = (long long)pred.n * pred.h * pred.w * 3;
-    hipLaunchKernelGGL(k_flex_blend, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0, as_stream(s), xb, xa, mask, cur, pred, resid);
+    if ((long long)pred.n * pred.h * pred.w <= 0) return VC_OK;
+    VC_EW_LAUNCH(as_stream(s), k_flex_blend, pred.n, pred.h, pred.w, 3, xb, xa, mask, cur, pred, resid);
     VC_LAUNCH_CHECK();
     return VC_OK;
 }
