@@ -10,8 +10,8 @@
 // ------------------------------------------------------------------------------------------------
 // Row-mapped indexing (round 6).  The grid-stride form below every kernel of this file started with -- a 64-bit linear index
 // taken apart by three 64-bit divisions per element -- costs ~300 vector instructions per element, more than the element's own
-// work (k_axpby, one float per thread, was 4.8 % of the configs[4] frame).  ROWS: blockIdx.z = image, blockIdx.y = row, the threads
-// of blockIdx.x walk the w * per_px work items of the row; item -> (x, c) by ONE multiply-high with a host-made reciprocal
+// work (k_axpby, one float per thread, was 4.8 % of the configs[4] frame).  ROWS: blockIdx.z = image, blockIdx.y (+ a grid stride) = row,
+// the threads of blockIdx.x walk the w * per_px work items of the row; item -> (x, c) by ONE multiply-high with a host-made reciprocal
 // (exact while item * per_px < 2^32; vc_rowmap_make checks it).  The linear form stays as the fallback for shapes outside that.
 // The body of a kernel is the same lambda under both forms: same arithmetic per element, same bits.
 // ------------------------------------------------------------------------------------------------
@@ -37,7 +37,8 @@ __device__ __forceinline__ void ew_for_each(const vc_rowmap &m, int N, int H, in
         const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
         if (j >= m.items) return;
         const unsigned x = m.per_px == 1 ? j : __umulhi(j, m.magic);
-        f((int)blockIdx.z, (int)blockIdx.y, (int)x, (int)(j - __umul24(x, m.per_px)));
+        const int c = (int)(j - __umul24(x, m.per_px));
+        for (int y = blockIdx.y; y < H; y += gridDim.y) f((int)blockIdx.z, y, (int)x, c);      // (x, c) once per thread, rows in a grid stride
     } else {
         const long long total = (long long)N * H * W * PP;
         for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -51,12 +52,23 @@ __device__ __forceinline__ void ew_for_each(const vc_rowmap &m, int N, int H, in
     }
 }
 
+// grid of the row form: enough rows per grid step that ~8192 workgroups exist (a workgroup per row of a big tensor would be 65 K
+// workgroups of one element per thread: measured slower than the grid-stride form on the pooling kernel), the rest in the row loop
+static inline dim3 vc_rowmap_grid(const vc_rowmap &m, int n, int h)
+{
+    const long long bx = (m.items + EW_BLOCK - 1) / EW_BLOCK;
+    long long gy = (8192 + bx * n - 1) / (bx * n);
+    if (gy < 1) gy = 1;
+    if (gy > h) gy = h;
+    return dim3((unsigned)bx, (unsigned)gy, (unsigned)n);
+}
+
 // launch `rows` (the ROWS = true instance) on the row grid when the shape allows it, `lin` (ROWS = false) on the grid-stride grid otherwise
 #define VC_EW_LAUNCH(st, KERN, N, H, W, PP, ...)                                                                                   \
     do {                                                                                                                           \
         vc_rowmap m_;                                                                                                              \
         if (vc_rowmap_make(m_, (N), (H), (W), (PP)))                                                                               \
-            KERN<true><<<dim3((m_.items + EW_BLOCK - 1) / EW_BLOCK, (unsigned)(H), (unsigned)(N)), dim3(EW_BLOCK), 0, (st)>>>(__VA_ARGS__, m_); \
+            KERN<true><<<vc_rowmap_grid(m_, (N), (H)), dim3(EW_BLOCK), 0, (st)>>>(__VA_ARGS__, m_);                                \
         else                                                                                                                       \
             KERN<false><<<dim3(ew_grid((long long)(N) * (H) * (W) * (PP), EW_BLOCK)), dim3(EW_BLOCK), 0, (st)>>>(__VA_ARGS__, vc_rowmap{0, 0, 0}); \
     } while (0)
@@ -242,7 +254,7 @@ extern "C" int vc_avgpool2_sp3(vc_stream s, const void *in_split, long long in_i
     const long long ii = in_image_bytes ? in_image_bytes : (long long)(c / 8) * h * w * 48;
     vc_rowmap m = {0, 0, 0};
     const bool rows = vc_rowmap_make(m, n * (c / 8), h / 2, w / 2, 2);
-    const dim3 grid = rows ? dim3((m.items + EW_BLOCK - 1) / EW_BLOCK, (unsigned)(h / 2), (unsigned)(n * (c / 8)))
+    const dim3 grid = rows ? vc_rowmap_grid(m, n * (c / 8), h / 2)
                            : dim3(ew_grid((long long)n * (c / 8) * (h / 2) * (w / 2) * 2, EW_BLOCK));
     const unsigned char *src = static_cast<const unsigned char *>(in_split);
     if (out_split) {
@@ -490,7 +502,18 @@ extern "C" int vc_axpby(vc_stream s, vc_view a, vc_view b, vc_view out, float al
     if (a.h < out.h || a.w < out.w || a.c < out.c || a.n != out.n) return VC_EINVAL;
     if (b.p && (b.h < out.h || b.w < out.w || b.c < out.c || b.n != out.n)) return VC_EINVAL;
     if ((long long)out.n * out.h * out.w * out.c <= 0) return VC_OK;
-    if (out.c % 4 == 0 && view_vec4(a) && view_vec4(out) && (!b.p || view_vec4(b)))
+    // rows that are dense in all three views (pixel stride == channel count: 3-channel frames, whole tensors) are runs of w * c floats:
+    // the same values through the 16-byte form, whatever c is
+    auto dense_row = [&](const vc_view &v) {
+        return v.sw == out.c && (v.sh % 4) == 0 && (v.sn % 4) == 0 && ((uintptr_t)v.p % 16) == 0;
+    };
+    if (((long long)out.w * out.c) % 4 == 0 && dense_row(a) && dense_row(out) && (!b.p || dense_row(b))) {
+        auto as_rows = [&](vc_view v) { v.w = out.w * out.c / 4, v.c = 4, v.sw = 4; return v; };
+        const vc_view a4 = as_rows(a), o4 = as_rows(out);
+        vc_view b4 = b;
+        if (b.p) b4 = as_rows(b);
+        VC_EW_LAUNCH(as_stream(s), k_axpby_v4, o4.n, o4.h, o4.w, 1, a4, b4, o4, alpha, beta);
+    } else if (out.c % 4 == 0 && view_vec4(a) && view_vec4(out) && (!b.p || view_vec4(b)))
         VC_EW_LAUNCH(as_stream(s), k_axpby_v4, out.n, out.h, out.w, out.c / 4, a, b, out, alpha, beta);
     else
         VC_EW_LAUNCH(as_stream(s), k_axpby, out.n, out.h, out.w, out.c, a, b, out, alpha, beta);
@@ -565,7 +588,7 @@ extern "C" int vc_to_half_planar(vc_stream s, vc_view a, int cg, void *out_half)
     _Float16 *o = static_cast<_Float16 *>(out_half);
     vc_rowmap m = {0, 0, 0};
     const bool rows = vc_rowmap_make(m, a.n, a.h, a.w, a.c / cg);
-    const dim3 grid = rows ? dim3((m.items + EW_BLOCK - 1) / EW_BLOCK, (unsigned)a.h, (unsigned)a.n)
+    const dim3 grid = rows ? vc_rowmap_grid(m, a.n, a.h)
                            : dim3(ew_grid((long long)a.n * a.h * a.w * (a.c / cg), EW_BLOCK));
 #define VC_PLANAR_CASE(CG)                                                                       \
     case CG:                                                                                     \
