@@ -758,6 +758,50 @@ template <bool ROWS> __global__ void k_warp_px(int convention, vc_view img, vc_v
     });
 }
 
+// 3-channel frames (the flow-resolution search of ICIP2024 warps 2176x3840 frames five times per B-frame; k_warp_px ran them at
+// 0.3-0.5 TB/s: twelve 4-byte loads per pixel, each under its own bounds test, so the compiler waited for them one by one).  Here ONE
+// 12-byte load per corner from an address clamped into the image, all four in flight together, and the value replaced by zero
+// afterwards where sample_bilinear would not have loaded it; the weights and the sum are sample_bilinear's expressions, per channel.
+struct vc_px3 {
+    float v[3];
+};
+template <bool ROWS> __global__ void k_warp_px3(int convention, vc_view img, vc_view flow, vc_view out, vc_rowmap m)
+{
+    const bool border = convention != VC_WARP_W2, align_corners = convention == VC_WARP_W3;
+    const int H = img.h, W = img.w;
+    ew_for_each<ROWS>(m, out.n, out.h, out.w, 1, [&](int n_img, int y, int x, int) {
+        const float *f = flow.p + view_off(flow, n_img, y, x);
+        const float gx = grid_coord(convention, x, f[0], flow.w, img.w);
+        const float gy = grid_coord(convention, y, f[1], flow.h, img.h);
+        float ix = align_corners ? ((gx + 1.0f) / 2.0f) * (float)(W - 1) : ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+        float iy = align_corners ? ((gy + 1.0f) / 2.0f) * (float)(H - 1) : ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+        if (border) {
+            ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));
+            iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+        } else {
+            ix = fminf(fmaxf(ix, -2.0f), (float)W + 1.0f);
+            iy = fminf(fmaxf(iy, -2.0f), (float)H + 1.0f);
+        }
+        const float xw = floorf(ix), yn = floorf(iy);
+        const float w = ix - xw, e = 1.0f - w, n = iy - yn, s_ = 1.0f - n;
+        const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
+        const bool x0ok = x0 >= 0 && x0 < W, x1ok = x1 >= 0 && x1 < W, y0ok = y0 >= 0 && y0 < H, y1ok = y1 >= 0 && y1 < H;
+        const float *base = img.p + (long long)n_img * img.sn;
+        const long long r0 = (long long)min(max(y0, 0), H - 1) * img.sh, r1 = (long long)min(max(y1, 0), H - 1) * img.sh;
+        const long long c0 = (long long)min(max(x0, 0), W - 1) * img.sw, c1 = (long long)min(max(x1, 0), W - 1) * img.sw;
+        const vc_px3 a = *reinterpret_cast<const vc_px3 *>(base + r0 + c0), b = *reinterpret_cast<const vc_px3 *>(base + r0 + c1);
+        const vc_px3 c = *reinterpret_cast<const vc_px3 *>(base + r1 + c0), d = *reinterpret_cast<const vc_px3 *>(base + r1 + c1);
+        vc_px3 o;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float nw = (x0ok && y0ok) ? a.v[k] : 0.0f, ne = (x1ok && y0ok) ? b.v[k] : 0.0f;
+            const float sw_ = (x0ok && y1ok) ? c.v[k] : 0.0f, se = (x1ok && y1ok) ? d.v[k] : 0.0f;
+            o.v[k] = nw * (s_ * e) + ne * (s_ * w) + sw_ * (n * e) + se * (n * w);
+        }
+        *reinterpret_cast<vc_px3 *>(out.p + view_off(out, n_img, y, x)) = o;
+    });
+}
+
 // 4 channels per thread: the sample position and the bilinear weights are computed once per 16 bytes (feature maps
 // of 64-128 channels in ICIP2024 made the scalar version recompute them per element).  Same arithmetic per value.
 template <bool ROWS> __global__ void k_warp_v4(int convention, vc_view img, vc_view flow, vc_view out, vc_rowmap m)
@@ -803,6 +847,8 @@ extern "C" int vc_warp(vc_stream s, int convention, vc_view img, vc_view flow, v
     if (total <= 0) return VC_OK;            // (an empty tensor: nothing to launch)
     if (out.c % 4 == 0 && view_vec4(img) && view_vec4(out))
         VC_EW_LAUNCH(as_stream(s), k_warp_v4, out.n, out.h, out.w, out.c / 4, convention, img, flow, out);
+    else if (out.c == 3)
+        VC_EW_LAUNCH(as_stream(s), k_warp_px3, out.n, out.h, out.w, 1, convention, img, flow, out);
     else if (out.c <= 4)
         VC_EW_LAUNCH(as_stream(s), k_warp_px, out.n, out.h, out.w, 1, convention, img, flow, out);
     else
